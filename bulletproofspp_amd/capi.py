@@ -1,0 +1,254 @@
+"""ctypes binding of include/bppp.h.  Data crosses as numpy uint64 arrays (4 limbs per scalar,
+8 per affine point, little-endian) or as raw device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NUM_STAGES = 5
+STAGE_NAMES = ["digits", "sort", "accumulate", "reduce", "finish"]
+
+# every symbol include/bppp.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "bppp_ctx_create", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_last_error", "bppp_version",
+    "bppp_msm", "bppp_msm_device", "bppp_msm_batch_device", "bppp_rational_reduce",
+    "bppp_fold_points", "bppp_fold_points_device",
+    "bppp_norm_round_sums_device", "bppp_lin_round_sums_device",
+    "bppp_norm_round_openings_device", "bppp_lin_round_openings_device",
+    "bppp_fold_scalars_device", "bppp_tensor_device",
+    "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
+    "bppp_profile_enable", "bppp_profile_read",
+]
+
+
+class BpppError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libbppp_hip.so")
+
+
+def load_library() -> C.CDLL:
+    p = lib_path()
+    if not os.path.exists(p):
+        raise BpppError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(p)
+    u64p, vp, sz, i = C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, C.c_int
+    lib.bppp_ctx_create.argtypes = [i, C.POINTER(vp)]
+    lib.bppp_ctx_destroy.argtypes = [vp]
+    lib.bppp_ctx_destroy.restype = None
+    lib.bppp_ctx_set_stream.argtypes = [vp, vp]
+    lib.bppp_last_error.argtypes = [vp]
+    lib.bppp_last_error.restype = C.c_char_p
+    lib.bppp_version.restype = C.c_char_p
+    lib.bppp_msm.argtypes = [vp, vp, vp, sz, vp]
+    lib.bppp_msm_device.argtypes = [vp, vp, vp, sz, i, vp]
+    lib.bppp_msm_batch_device.argtypes = [vp, vp, vp, sz, sz, i, i, vp]
+    lib.bppp_rational_reduce.argtypes = [vp, vp, C.POINTER(i), vp, C.POINTER(i)]
+    lib.bppp_fold_points.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
+    lib.bppp_fold_points_device.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
+    lib.bppp_norm_round_sums_device.argtypes = [vp, vp, sz, vp, vp, vp]
+    lib.bppp_lin_round_sums_device.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.bppp_norm_round_openings_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    lib.bppp_lin_round_openings_device.argtypes = [vp, vp, sz, vp, vp]
+    lib.bppp_fold_scalars_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.bppp_tensor_device.argtypes = [vp, vp, sz, vp, vp, sz, vp]
+    lib.bppp_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.bppp_device_free.argtypes = [vp, vp]
+    lib.bppp_upload.argtypes = [vp, vp, vp, sz]
+    lib.bppp_download.argtypes = [vp, vp, vp, sz]
+    lib.bppp_profile_enable.argtypes = [vp, i]
+    lib.bppp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]
+    return lib
+
+
+# ---- integer <-> limb helpers (host-side glue for tests / bench)
+def int_to_limbs(x: int, n: int = 4) -> np.ndarray:
+    return np.array([(x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(n)], dtype=np.uint64)
+
+
+def limbs_to_int(a) -> int:
+    return sum(int(v) << (64 * k) for k, v in enumerate(np.asarray(a).reshape(-1)))
+
+
+def scalars_to_array(xs: Sequence[int]) -> np.ndarray:
+    out = np.zeros((len(xs), 4), dtype=np.uint64)
+    for r, x in enumerate(xs):
+        out[r] = int_to_limbs(x)
+    return out
+
+
+def points_to_array(ps) -> np.ndarray:
+    out = np.zeros((len(ps), 8), dtype=np.uint64)
+    for r, p in enumerate(ps):
+        if p is not None:
+            out[r, :4] = int_to_limbs(p[0])
+            out[r, 4:] = int_to_limbs(p[1])
+    return out
+
+
+def array_to_point(a):
+    a = np.asarray(a).reshape(8)
+    x, y = limbs_to_int(a[:4]), limbs_to_int(a[4:])
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def array_to_scalars(a):
+    a = np.asarray(a).reshape(-1, 4)
+    return [limbs_to_int(r) for r in a]
+
+
+class _Ptr(C.c_void_p):
+    """c_void_p that keeps the numpy array it points into alive until the foreign call returns."""
+    _keep = None
+
+
+def _ptr(a) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == np.uint64
+        p = _Ptr(a.ctypes.data)
+        p._keep = a
+        return p
+    return C.c_void_p(int(a))  # raw device pointer
+
+
+class Bppp:
+    """One context = one GPU + one HIP stream (include/bppp.h)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.bppp_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise BpppError(f"bppp_ctx_create(device={device}) failed with {rc} "
+                            "(-3 = no GPU visible; this library has no CPU path)")
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bppp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise BpppError(f"{what} failed ({rc}): {self.lib.bppp_last_error(self.h).decode()}")
+
+    def set_stream(self, stream: int):
+        self._check(self.lib.bppp_ctx_set_stream(self.h, C.c_void_p(stream)), "bppp_ctx_set_stream")
+
+    # ---- MSM
+    def msm(self, scalars: np.ndarray, points: np.ndarray):
+        n = scalars.shape[0] if scalars.size else 0
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.bppp_msm(self.h, _ptr(np.ascontiguousarray(scalars)), _ptr(np.ascontiguousarray(points)), n, _ptr(out)), "bppp_msm")
+        return array_to_point(out)
+
+    def msm_device(self, d_scalars: int, d_points: int, n: int, window_bits: int = 0):
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.bppp_msm_device(self.h, _ptr(d_scalars), _ptr(d_points), n, window_bits, _ptr(out)), "bppp_msm_device")
+        return array_to_point(out)
+
+    def msm_batch_device(self, d_scalars: int, d_points: int, n: int, batch: int, shared_points: bool, window_bits: int = 0):
+        out = np.zeros((batch, 8), dtype=np.uint64)
+        self._check(self.lib.bppp_msm_batch_device(self.h, _ptr(d_scalars), _ptr(d_points), n, batch, int(shared_points), window_bits, _ptr(out)),
+                    "bppp_msm_batch_device")
+        return [array_to_point(out[b]) for b in range(batch)]
+
+    # ---- reduced scalars / folds
+    def rational_reduce(self, x: int) -> Tuple[int, int]:
+        am, bm = np.zeros(3, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+        an, bn = C.c_int(0), C.c_int(0)
+        rc = self.lib.bppp_rational_reduce(_ptr(int_to_limbs(x)), _ptr(am), C.byref(an), _ptr(bm), C.byref(bn))
+        if rc != 0:
+            raise BpppError(f"bppp_rational_reduce failed ({rc})")
+        a, b = limbs_to_int(am), limbs_to_int(bm)
+        return (-a if an.value else a, -b if bn.value else b)
+
+    def fold_points(self, b: int, a: int, points: np.ndarray) -> np.ndarray:
+        n = points.shape[0]
+        out = np.zeros(((n + 1) // 2, 8), dtype=np.uint64)
+        self._check(self.lib.bppp_fold_points(self.h, _ptr(int_to_limbs(abs(b), 3)), int(b < 0), _ptr(int_to_limbs(abs(a), 3)), int(a < 0),
+                                              _ptr(np.ascontiguousarray(points)), n, _ptr(out)), "bppp_fold_points")
+        return out
+
+    def fold_points_device(self, b: int, a: int, d_points: int, n: int, d_out: int):
+        self._check(self.lib.bppp_fold_points_device(self.h, _ptr(int_to_limbs(abs(b), 3)), int(b < 0), _ptr(int_to_limbs(abs(a), 3)), int(a < 0),
+                                                     _ptr(d_points), n, _ptr(d_out)), "bppp_fold_points_device")
+
+    # ---- round scalar kernels
+    def norm_round_sums(self, d_x: int, n: int, q4: int) -> Tuple[int, int]:
+        sx, sr = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.bppp_norm_round_sums_device(self.h, _ptr(d_x), n, _ptr(int_to_limbs(q4)), _ptr(sx), _ptr(sr)), "bppp_norm_round_sums_device")
+        return limbs_to_int(sx), limbs_to_int(sr)
+
+    def lin_round_sums(self, d_c: int, d_x: int, n: int) -> Tuple[int, int]:
+        sx, sr = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.bppp_lin_round_sums_device(self.h, _ptr(d_c), _ptr(d_x), n, _ptr(sx), _ptr(sr)), "bppp_lin_round_sums_device")
+        return limbs_to_int(sx), limbs_to_int(sr)
+
+    def norm_round_openings(self, d_x: int, n: int, q: int, qinv: int, d_xw: int, d_rw: int):
+        self._check(self.lib.bppp_norm_round_openings_device(self.h, _ptr(d_x), n, _ptr(int_to_limbs(q)), _ptr(int_to_limbs(qinv)), _ptr(d_xw), _ptr(d_rw)),
+                    "bppp_norm_round_openings_device")
+
+    def lin_round_openings(self, d_x: int, n: int, d_xw: int, d_rw: int):
+        self._check(self.lib.bppp_lin_round_openings_device(self.h, _ptr(d_x), n, _ptr(d_xw), _ptr(d_rw)), "bppp_lin_round_openings_device")
+
+    def fold_scalars(self, u: int, v: int, d_x: int, n: int, d_out: int):
+        self._check(self.lib.bppp_fold_scalars_device(self.h, _ptr(int_to_limbs(u)), _ptr(int_to_limbs(v)), _ptr(d_x), n, _ptr(d_out)), "bppp_fold_scalars_device")
+
+    def tensor(self, bs: Sequence[int], es: Sequence[int], qs: Sequence[int], d_out: int):
+        k = len(es)
+        assert len(qs) == k
+        self._check(self.lib.bppp_tensor_device(self.h, _ptr(scalars_to_array(bs)), len(bs), _ptr(scalars_to_array(es)) if k else None,
+                                                _ptr(scalars_to_array(qs)) if k else None, k, _ptr(d_out)), "bppp_tensor_device")
+
+    # ---- device memory
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.bppp_device_alloc(self.h, nbytes, C.byref(p)), "bppp_device_alloc")
+        return int(p.value)
+
+    def free(self, d_ptr: int):
+        self._check(self.lib.bppp_device_free(self.h, _ptr(d_ptr)), "bppp_device_free")
+
+    def upload(self, d_dst: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        self._check(self.lib.bppp_upload(self.h, _ptr(d_dst), C.c_void_p(src.ctypes.data), src.nbytes), "bppp_upload")
+
+    def download(self, d_src: int, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.zeros(shape, dtype=dtype)
+        self._check(self.lib.bppp_download(self.h, C.c_void_p(out.ctypes.data), _ptr(d_src), out.nbytes), "bppp_download")
+        return out
+
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(max(arr.nbytes, 16))
+        if arr.nbytes:
+            self.upload(p, arr)
+        return p
+
+    # ---- profiling
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.bppp_profile_enable(self.h, int(on)), "bppp_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        ms = (C.c_double * NUM_STAGES)()
+        calls = C.c_uint64(0)
+        self._check(self.lib.bppp_profile_read(self.h, ms, C.byref(calls), int(reset)), "bppp_profile_read")
+        return {STAGE_NAMES[k]: ms[k] for k in range(NUM_STAGES)}, int(calls.value)

@@ -1,0 +1,58 @@
+// ctx.hpp — the library context: one GPU, one stream, a grow-only HBM workspace.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/bppp.h"
+
+struct bppp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;      // stream all work is issued on
+  hipStream_t own_stream = nullptr;  // created by the context (used unless the caller binds its own)
+  std::string err;
+  // grow-only device workspace, carved per call (no hipMalloc on the steady-state path)
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+  // pinned host staging for small results
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // profiling
+  bool profile = false;
+  double stage_ms[BPPP_NUM_STAGES] = {0, 0, 0, 0, 0};
+  uint64_t calls = 0;
+  hipEvent_t ev[BPPP_NUM_STAGES + 1] = {};
+  bool ev_ready = false;
+};
+
+namespace bppp {
+
+inline int fail(bppp_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+#define BPPP_HIP(ctx, call)                                                                    \
+  do {                                                                                         \
+    hipError_t _e = (call);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return bppp::fail(ctx, BPPP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// bump allocator over the context workspace
+struct Carver {
+  char *base; size_t off = 0, cap;
+  Carver(void *b, size_t c) : base((char *)b), cap(c) {}
+  template <typename T> T *take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    T *p = (T *)(base ? base + off : nullptr);
+    off += bytes;
+    return p;
+  }
+};
+
+int ensure_workspace(bppp_ctx *ctx, size_t bytes);
+int ensure_pinned(bppp_ctx *ctx, size_t bytes);
+void prof_mark(bppp_ctx *ctx, int idx);   // record event idx on the stream when profiling
+void prof_collect(bppp_ctx *ctx, int nmarks);
+
+}  // namespace bppp

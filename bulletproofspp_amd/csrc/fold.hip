@@ -1,0 +1,57 @@
+// fold.hip — batched basis fold: out[j] = b * G[2j] + a * G[2j+1] with ONE (a, b) for all pairs.
+//
+// Replaces `collapsePoints b a gL gR = projectivePairIP (b, gL) (a, gR)` (src/Bulletproof.hs:213-214,
+// src/Commitment.hs:343-353) mapped over adjacent pairs by mapHalves (src/Bulletproof.hs:88-90), as
+// called from the three `collapse` methods (NormArgument.hs:71, :129; InnerProductArgument.hs:100-101).
+//
+// The reference runs a 129-row Straus loop per pair and pays one field inversion per pair
+// (normalizeBasis on two points, Commitment.hs:347).  Here every lane owns one pair and all lanes
+// walk the same 129-row double/add schedule (the scalars are wave-uniform, so the row branches
+// are scalar branches: no divergence); inputs are already affine, so no normalisation pass.
+#include <string.h>
+#include "ctx.hpp"
+#include "ec.cuh"
+
+namespace bppp {
+
+struct FoldK { uint32_t b[5], a[5]; int bneg, aneg; };
+
+__global__ void __launch_bounds__(64) k_fold_points(const uint32_t *__restrict__ pts, uint32_t n, FoldK K, uint32_t *__restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t np = (n + 1) / 2;
+  if (j >= np) return;
+  aff GL = aff_cneg(aff_load(pts + (size_t)(2 * j) * 16), K.bneg != 0);
+  aff GR = aff_inf();
+  if (2 * j + 1 < n) GR = aff_cneg(aff_load(pts + (size_t)(2 * j + 1) * 16), K.aneg != 0);
+  xyzz acc = xyzz_inf();
+  // rationalReducedScalarLength = 129 rows, most significant first (Commitment.hs:286, :348-353)
+  for (int row = 128; row >= 0; row--) {
+    acc = xyzz_dbl(acc);
+    if ((K.b[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GL);
+    if ((K.a[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GR);
+  }
+  aff_store(out + (size_t)j * 16, xyzz_to_aff(acc));
+}
+
+int fold_points_run(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
+                    const void *d_pts, size_t n, void *d_out) {
+  if (n == 0) return BPPP_OK;
+  if (!d_pts || !d_out || !b_mag || !a_mag) return fail(ctx, BPPP_ERR_ARG, "fold_points: null pointer");
+  if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_points: n too large");
+  FoldK K; memset(&K, 0, sizeof K);
+  for (int i = 0; i < 3; i++) {
+    if (2 * i < 5) K.b[2 * i] = (uint32_t)b_mag[i];
+    if (2 * i + 1 < 5) K.b[2 * i + 1] = (uint32_t)(b_mag[i] >> 32);
+    if (2 * i < 5) K.a[2 * i] = (uint32_t)a_mag[i];
+    if (2 * i + 1 < 5) K.a[2 * i + 1] = (uint32_t)(a_mag[i] >> 32);
+  }
+  // magnitudes must fit the 129 rows the reference walks
+  if ((b_mag[2] >> 1) || (a_mag[2] >> 1)) return fail(ctx, BPPP_ERR_ARG, "fold_points: reduced scalar exceeds 129 bits");
+  K.bneg = b_neg; K.aneg = a_neg;
+  uint32_t np = (uint32_t)((n + 1) / 2);
+  k_fold_points<<<dim3((np + 63) / 64), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_pts, (uint32_t)n, K, (uint32_t *)d_out);
+  BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
+
+}  // namespace bppp

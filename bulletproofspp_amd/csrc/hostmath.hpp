@@ -1,0 +1,230 @@
+// hostmath.hpp — host-side 256-bit arithmetic used by the PRODUCT (not the oracle).
+//
+// The device does the data-parallel work; the host keeps only the latency-bound scalar glue the
+// reference also evaluates once per call/round:
+//   * the final window combine of an MSM (<= 33 points; a 256-doubling dependency chain is
+//     ~6x faster on one CPU core than on one GPU lane),
+//   * rationalReduceScalar (src/Commitment.hs:242-255): one half-GCD per round,
+//   * Fr scalar glue of the round driver (makeEs, normalisation updates; src/Bulletproof.hs:346-378).
+// Independent of oracle/ by construction: different representation (u256 class, Montgomery-free
+// folding with __int128) and no shared source.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <utility>
+
+namespace bppp_host {
+
+typedef unsigned __int128 u128;
+
+struct U256 {
+  uint64_t w[4];
+  static U256 zero() { U256 r; memset(&r, 0, sizeof r); return r; }
+  static U256 one() { U256 r = zero(); r.w[0] = 1; return r; }
+  static U256 from_u64(uint64_t x) { U256 r = zero(); r.w[0] = x; return r; }
+  static U256 load(const uint64_t *p) { U256 r; memcpy(r.w, p, 32); return r; }
+  void store(uint64_t *p) const { memcpy(p, w, 32); }
+  bool is_zero() const { return (w[0] | w[1] | w[2] | w[3]) == 0; }
+  bool bit(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+  bool operator==(const U256 &o) const { return memcmp(w, o.w, 32) == 0; }
+};
+inline int cmp(const U256 &a, const U256 &b) {
+  for (int i = 3; i >= 0; i--) { if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1; }
+  return 0;
+}
+inline uint64_t add_raw(U256 &r, const U256 &a, const U256 &b) {
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)a.w[i] + b.w[i]; r.w[i] = (uint64_t)c; c >>= 64; }
+  return (uint64_t)c;
+}
+inline uint64_t sub_raw(U256 &r, const U256 &a, const U256 &b) {
+  uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a.w[i] - b.w[i] - br; r.w[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+  return br;
+}
+
+// Modulus of shape 2^256 - R, R up to 3 limbs.
+struct Mod { U256 m; uint64_t r[3]; };
+inline const Mod &FQ() {
+  static const Mod M = {{{0xFFFFFFFEFFFFFC2FULL, ~0ULL, ~0ULL, ~0ULL}}, {0x1000003D1ULL, 0, 0}};
+  return M;
+}
+inline const Mod &FR() {
+  static const Mod M = {{{0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, ~0ULL}},
+                        {0x402DA1732FC9BEBFULL, 0x4551231950B75FC4ULL, 1}};
+  return M;
+}
+
+inline U256 madd(const U256 &a, const U256 &b, const Mod &M) {
+  U256 s; uint64_t c = add_raw(s, a, b);
+  if (c || cmp(s, M.m) >= 0) sub_raw(s, s, M.m);
+  return s;
+}
+inline U256 msub(const U256 &a, const U256 &b, const Mod &M) {
+  U256 d; if (sub_raw(d, a, b)) add_raw(d, d, M.m);
+  return d;
+}
+inline U256 mneg(const U256 &a, const Mod &M) { return a.is_zero() ? a : msub(U256::zero(), a, M); }
+inline U256 mmul(const U256 &a, const U256 &b, const Mod &M) {
+  uint64_t t[8] = {0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a.w[i] * b.w[j] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+    t[i + 4] = (uint64_t)c;
+  }
+  while (t[4] | t[5] | t[6] | t[7]) {
+    uint64_t n[8] = {t[0], t[1], t[2], t[3], 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      u128 c = 0;
+      for (int j = 0; j < 3; j++) { c += (u128)t[4 + i] * M.r[j] + n[i + j]; n[i + j] = (uint64_t)c; c >>= 64; }
+      for (int k = i + 3; k < 8 && c; k++) { c += n[k]; n[k] = (uint64_t)c; c >>= 64; }
+    }
+    memcpy(t, n, sizeof t);
+  }
+  U256 r = {{t[0], t[1], t[2], t[3]}};
+  while (cmp(r, M.m) >= 0) sub_raw(r, r, M.m);
+  return r;
+}
+inline U256 mpow(const U256 &a, const U256 &e, const Mod &M) {
+  U256 acc = U256::one(), base = a;
+  for (int i = 0; i < 256; i++) { if (e.bit(i)) acc = mmul(acc, base, M); base = mmul(base, base, M); }
+  return acc;
+}
+inline U256 minv(const U256 &a, const Mod &M) {  // 0 -> 0 (BatchInverse.hs:18,23)
+  U256 e; sub_raw(e, M.m, U256::from_u64(2));
+  return mpow(a, e, M);
+}
+
+// ---- curve, Jacobian on the host (only for the <= 33-point window combine and group glue)
+struct HAff { U256 x, y; bool inf() const { return x.is_zero() && y.is_zero(); } };
+struct HJac { U256 X, Y, Z; bool inf() const { return Z.is_zero(); } };
+inline HJac hj_inf() { return {U256::one(), U256::one(), U256::zero()}; }
+inline HJac hj_dbl(const HJac &p) {
+  const Mod &M = FQ();
+  if (p.inf() || p.Y.is_zero()) return hj_inf();
+  U256 A = mmul(p.X, p.X, M), B = mmul(p.Y, p.Y, M), C = mmul(B, B, M);
+  U256 t = madd(p.X, B, M); t = msub(msub(mmul(t, t, M), A, M), C, M);
+  U256 D = madd(t, t, M), E = madd(madd(A, A, M), A, M), F = mmul(E, E, M);
+  HJac r;
+  r.X = msub(msub(F, D, M), D, M);
+  U256 c8 = madd(C, C, M); c8 = madd(c8, c8, M); c8 = madd(c8, c8, M);
+  r.Y = msub(mmul(E, msub(D, r.X, M), M), c8, M);
+  r.Z = mmul(p.Y, p.Z, M); r.Z = madd(r.Z, r.Z, M);
+  return r;
+}
+inline HJac hj_add(const HJac &p, const HJac &q) {  // complete general add (add-2007-bl shape)
+  const Mod &M = FQ();
+  if (p.inf()) return q;
+  if (q.inf()) return p;
+  U256 z1z1 = mmul(p.Z, p.Z, M), z2z2 = mmul(q.Z, q.Z, M);
+  U256 u1 = mmul(p.X, z2z2, M), u2 = mmul(q.X, z1z1, M);
+  U256 s1 = mmul(mmul(p.Y, q.Z, M), z2z2, M), s2 = mmul(mmul(q.Y, p.Z, M), z1z1, M);
+  U256 h = msub(u2, u1, M), r = msub(s2, s1, M);
+  if (h.is_zero()) return r.is_zero() ? hj_dbl(p) : hj_inf();
+  U256 hh = mmul(h, h, M), hhh = mmul(h, hh, M), v = mmul(u1, hh, M);
+  HJac o;
+  o.X = msub(msub(msub(mmul(r, r, M), hhh, M), v, M), v, M);
+  o.Y = msub(mmul(r, msub(v, o.X, M), M), mmul(s1, hhh, M), M);
+  o.Z = mmul(mmul(p.Z, q.Z, M), h, M);
+  return o;
+}
+inline HAff hj_to_aff(const HJac &p) {
+  const Mod &M = FQ();
+  if (p.inf()) return {U256::zero(), U256::zero()};
+  U256 zi = minv(p.Z, M), zi2 = mmul(zi, zi, M);
+  return {mmul(p.X, zi2, M), mmul(p.Y, mmul(zi2, zi, M), M)};
+}
+inline HJac hj_from_aff(const HAff &a) { return a.inf() ? hj_inf() : HJac{a.x, a.y, U256::one()}; }
+// XYZZ (x = X/ZZ, y = Y/ZZZ) -> Jacobian with Z = ZZZ/ZZ:  X_j = X*ZZ... simpler: go through
+// the identity  (X, Y, ZZ, ZZZ) ~ Jacobian (X*ZZ, Y*ZZZ, ZZ)?  check: x = X*ZZ/ZZ^2 = X/ZZ  ok;
+// y = Y*ZZZ/ZZ^3 = Y*ZZZ/ZZZ^2 = Y/ZZZ ok (ZZ^3 = ZZZ^2).
+inline HJac hj_from_xyzz(const U256 &X, const U256 &Y, const U256 &ZZ, const U256 &ZZZ) {
+  const Mod &M = FQ();
+  if (ZZ.is_zero()) return hj_inf();
+  return {mmul(X, ZZ, M), mmul(Y, ZZZ, M), ZZ};
+}
+
+// ---- signed multi-precision integers for rationalReduceScalar (5 limbs + sign)
+struct SInt {
+  static const int L = 5;
+  uint64_t m[L]; bool neg;
+  static SInt zero() { SInt r; memset(r.m, 0, sizeof r.m); r.neg = false; return r; }
+  bool is_zero() const { uint64_t o = 0; for (int i = 0; i < L; i++) o |= m[i]; return o == 0; }
+  int bits() const { for (int i = L - 1; i >= 0; i--) if (m[i]) return 64 * i + 64 - __builtin_clzll(m[i]); return 0; }
+};
+inline int mcmp(const uint64_t *a, const uint64_t *b) {
+  for (int i = SInt::L - 1; i >= 0; i--) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return 0;
+}
+inline void madd_mag(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+  u128 c = 0; for (int i = 0; i < SInt::L; i++) { c += (u128)a[i] + b[i]; o[i] = (uint64_t)c; c >>= 64; }
+}
+inline void msub_mag(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+  uint64_t br = 0;
+  for (int i = 0; i < SInt::L; i++) { u128 d = (u128)a[i] - b[i] - br; o[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+}
+inline SInt sadd(const SInt &a, const SInt &b) {
+  SInt r;
+  if (a.neg == b.neg) { madd_mag(r.m, a.m, b.m); r.neg = a.neg; }
+  else if (mcmp(a.m, b.m) >= 0) { msub_mag(r.m, a.m, b.m); r.neg = a.neg; }
+  else { msub_mag(r.m, b.m, a.m); r.neg = b.neg; }
+  if (r.is_zero()) r.neg = false;
+  return r;
+}
+inline SInt sneg(SInt a) { if (!a.is_zero()) a.neg = !a.neg; return a; }
+inline SInt smul(const SInt &a, const SInt &b) {
+  SInt r = SInt::zero();
+  for (int i = 0; i < SInt::L; i++) {
+    u128 c = 0;
+    for (int j = 0; i + j < SInt::L; j++) { c += (u128)a.m[i] * b.m[j] + r.m[i + j]; r.m[i + j] = (uint64_t)c; c >>= 64; }
+  }
+  r.neg = r.is_zero() ? false : (a.neg != b.neg);
+  return r;
+}
+// truncating division (Haskell `quot`, Commitment.hs:254)
+inline SInt squot(const SInt &a, const SInt &b) {
+  SInt q = SInt::zero();
+  uint64_t rem[SInt::L] = {0};
+  for (int i = a.bits() - 1; i >= 0; i--) {
+    uint64_t c = (a.m[i >> 6] >> (i & 63)) & 1;
+    for (int k = 0; k < SInt::L; k++) { uint64_t nc = rem[k] >> 63; rem[k] = (rem[k] << 1) | c; c = nc; }
+    if (mcmp(rem, b.m) >= 0) { msub_mag(rem, rem, b.m); q.m[i >> 6] |= 1ULL << (i & 63); }
+  }
+  q.neg = q.is_zero() ? false : (a.neg != b.neg);
+  return q;
+}
+
+// reduceScalar (Commitment.hs:276-279): signed representative in (-n/2, n/2]
+inline SInt reduce_scalar(const U256 &x) {
+  SInt r = SInt::zero();
+  U256 neg; sub_raw(neg, FR().m, x);
+  if (cmp(x, neg) > 0) { memcpy(r.m, neg.w, 32); r.neg = true; }
+  else { memcpy(r.m, x.w, 32); }
+  if (r.is_zero()) r.neg = false;
+  return r;
+}
+// extractScalar = fromInteger (Commitment.hs:274)
+inline U256 extract_scalar(const SInt &s) {
+  U256 v; memcpy(v.w, s.m, 32);   // |s| < 2^130 in every use
+  return s.neg ? mneg(v, FR()) : v;
+}
+// rationalReduceScalar (Commitment.hs:242-255): the egcd list starts at its second argument
+// (:252); the first (r, s) with r^2 <= 2n is returned (:247).
+inline std::pair<SInt, SInt> rational_reduce_scalar(const U256 &x) {
+  SInt pr = SInt::zero(), ps = SInt::zero(), cr = reduce_scalar(x), cs = SInt::zero();
+  memcpy(pr.m, FR().m.w, 32);
+  cs.m[0] = 1;
+  SInt two_n = SInt::zero(); memcpy(two_n.m, FR().m.w, 32); madd_mag(two_n.m, two_n.m, two_n.m);
+  for (;;) {
+    bool big = cr.bits() > 130;
+    if (!big) { SInt a = cr; a.neg = false; SInt sq = smul(a, a); big = mcmp(sq.m, two_n.m) > 0; }
+    if (!big) break;
+    SInt q = squot(pr, cr);
+    SInt nr = sadd(pr, sneg(smul(q, cr)));
+    SInt ns = sadd(ps, sneg(smul(q, cs)));
+    pr = cr; ps = cs; cr = nr; cs = ns;
+  }
+  return {cr, cs};
+}
+
+}  // namespace bppp_host

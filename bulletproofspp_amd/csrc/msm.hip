@@ -1,0 +1,498 @@
+// msm.hip — signed-digit Pippenger multi-scalar multiplication for gfx950.
+//
+// Replaces FastInnerProduct.innerProduct (src/Commitment.hs:325-335) reached through `commit`
+// (src/Commitment.hs:416-417).  The reference is a 256-row bit-serial Straus loop; this is a
+// different algorithm that yields the same group element:
+//
+//   1. k_digits      reduceScalar's sign fold (Commitment.hs:276-279, :366) + signed c-bit window
+//                    recode; coalesced 32-B scalar loads, u16 digits out.
+//   2. k_hist / k_scan* / k_scatter
+//                    counting sort of (window, |digit|) keys: the bucket histogram and cursors are
+//                    staged in LDS (<= 128 KiB per workgroup), so HBM sees only coalesced streams.
+//   3. k_acc_points / k_acc_records
+//                    load-balanced bucket accumulation: every lane owns exactly L consecutive
+//                    sorted entries (not one bucket), sums runs of equal key in an XYZZ register
+//                    accumulator with mixed adds, stores complete buckets and hands incomplete
+//                    head/tail runs to the next (L-times smaller) level.
+//   4. k_reduce1/2   sum_m m*B_m per window by per-lane running sums plus a wavefront suffix scan
+//                    (shuffles of whole points), then across wavefronts.
+//   5. window combine: Horner over <= 65 window sums — on the host for one MSM (a 256-doubling
+//                    dependency chain), in k_window_combine for batches.
+//
+// Integer / carry-chain work on the VALU; nothing here is a dense contraction, so no MFMA.
+#include <algorithm>
+#include <vector>
+#include "ctx.hpp"
+#include "ec.cuh"
+#include "hostmath.hpp"
+
+namespace bppp {
+
+static constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+static constexpr int L0 = 16;   // sorted entries per lane, level 0
+static constexpr int LR = 32;   // record slots per lane, levels >= 1
+
+struct RecodeK { uint32_t k[9]; };
+
+// ------------------------------------------------------------------------------------------------
+// 1. digits
+__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint64_t total, uint32_t n, int c,
+                                                int W, RecodeK K, uint16_t *__restrict__ dig,
+                                                unsigned long long *__restrict__ negmask) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = i < total;
+  bool neg = false;
+  if (valid) {
+    fe s = fe_load(scalars + 8 * i);
+    fe t, tmp;
+    raw_sub(t, fr_modulus(), s);               // n - s
+    neg = raw_sub(tmp, t, s) != 0;             // t < s  <=>  s > n - s   (reduceScalar, Commitment.hs:279)
+    uint32_t sp[9];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      cy += (uint64_t)(neg ? t.v[k] : s.v[k]) + K.k[k];
+      sp[k] = (uint32_t)cy; cy >>= 32;
+    }
+    sp[8] = (uint32_t)cy + K.k[8];
+    uint32_t inst = (uint32_t)(i / n), j = (uint32_t)(i % n);
+    uint32_t mask = (1u << c) - 1u;
+    size_t base = (size_t)inst * W * n + j;
+    for (int w = 0; w < W; w++) {
+      dig[base + (size_t)w * n] = (uint16_t)(sp[0] & mask);
+#pragma unroll
+      for (int k = 0; k < 8; k++) sp[k] = (sp[k] >> c) | (sp[k + 1] << (32 - c));
+      sp[8] >>= c;
+    }
+  }
+  unsigned long long m = __ballot(valid && neg);
+  if ((threadIdx.x & 63) == 0 && (i - (i & 63)) < total) negmask[i >> 6] = m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. counting sort by (instance, window, |digit|)
+__global__ void k_hist(const uint16_t *__restrict__ dig, uint32_t n, int c, int CH, uint32_t *__restrict__ blockhist) {
+  extern __shared__ uint32_t lh[];
+  const int M = 1 << (c - 1);
+  const uint32_t nbw = blockIdx.x, ch = blockIdx.y;
+  for (int t = threadIdx.x; t < M; t += blockDim.x) lh[t] = 0;
+  __syncthreads();
+  uint32_t per = (n + CH - 1) / CH, lo = ch * per, hi = min(n, lo + per);
+  const uint16_t *d = dig + (size_t)nbw * n;
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    int v = (int)d[j] - M;
+    if (v) atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t *out = blockhist + ((size_t)nbw * CH + ch) * M;
+  for (int t = threadIdx.x; t < M; t += blockDim.x) out[t] = lh[t];
+}
+
+// per flat bucket: exclusive prefix over the chunks (in place) and the bucket total
+__global__ void k_chunk_prefix(uint32_t *__restrict__ blockhist, int M, int CH, uint64_t FB, uint32_t *__restrict__ count) {
+  uint64_t fb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (fb >= FB) return;
+  uint64_t nbw = fb / M, mb = fb % M;
+  uint32_t run = 0;
+  for (int ch = 0; ch < CH; ch++) {
+    size_t at = ((size_t)nbw * CH + ch) * M + mb;
+    uint32_t t = blockhist[at];
+    blockhist[at] = run;
+    run += t;
+  }
+  count[fb] = run;
+}
+
+// three-kernel exclusive scan over `count` (tiles of 4096)
+static constexpr int SCAN_TILE = 4096;
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ tile_sums) {
+  __shared__ uint32_t ws[4];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+  uint32_t s = 0;
+  for (int k = 0; k < SCAN_TILE / 256; k++) {
+    uint64_t i = base + k * 256 + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_top(uint32_t *__restrict__ tile_sums, uint32_t ntiles, uint32_t *__restrict__ total_out) {
+  // single block: exclusive scan of tile sums in place
+  __shared__ uint32_t part[1024];
+  uint32_t per = (ntiles + 1023) / 1024, lo = threadIdx.x * per, hi = min(ntiles, lo + per);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += tile_sums[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = threadIdx.x >= (uint32_t)d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (uint32_t i = lo; i < hi; i++) { uint32_t t = tile_sums[i]; tile_sums[i] = run; run += t; }
+  if (threadIdx.x == 1023) *total_out = part[1023];
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint64_t n, const uint32_t *__restrict__ tile_off,
+                                                    uint32_t *__restrict__ out) {
+  // block-level exclusive scan of one tile (16 per thread), plus the tile offset
+  __shared__ uint32_t wsum[4];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+  uint32_t v[16], s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  uint32_t inc = s;
+  for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += t; }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
+  uint32_t run = tile_off[blockIdx.x] + woff + inc - s;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+__global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long long *__restrict__ negmask, uint32_t n, int c,
+                          int CH, int W, const uint32_t *__restrict__ blockhist, const uint32_t *__restrict__ start,
+                          unsigned long long *__restrict__ sorted) {
+  extern __shared__ uint32_t lh[];
+  const int M = 1 << (c - 1);
+  const uint32_t nbw = blockIdx.x, ch = blockIdx.y;
+  const uint32_t *bh = blockhist + ((size_t)nbw * CH + ch) * M;
+  const uint32_t *st = start + (size_t)nbw * M;
+  for (int t = threadIdx.x; t < M; t += blockDim.x) lh[t] = st[t] + bh[t];
+  __syncthreads();
+  uint32_t per = (n + CH - 1) / CH, lo = ch * per, hi = min(n, lo + per);
+  const uint16_t *d = dig + (size_t)nbw * n;
+  const uint32_t inst = nbw / W;
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    int v = (int)d[j] - M;
+    if (v) {
+      uint32_t mb = (v < 0 ? -v : v) - 1;
+      uint64_t flat = (uint64_t)inst * n + j;
+      uint32_t sneg = (uint32_t)((negmask[flat >> 6] >> (flat & 63)) & 1ull);
+      uint32_t sg = (v < 0 ? 1u : 0u) ^ sneg;
+      uint32_t pos = atomicAdd(&lh[mb], 1u);
+      uint32_t key = nbw * M + mb;
+      sorted[pos] = ((unsigned long long)key << 32) | ((unsigned long long)sg << 31) | j;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. load-balanced accumulation
+struct RunOut {
+  uint32_t *rec_key; uint32_t *rec_pt; uint32_t *buckets;
+  uint64_t g;
+  bool head_written, tail_written;
+  BPPP_DI void flush(uint32_t key, const xyzz &acc, bool hi, bool ti) {
+    if (!hi && !ti) { xyzz_store(buckets + (size_t)key * 32, acc); return; }
+    uint64_t slot = 2 * g + (hi ? 0 : 1);
+    rec_key[slot] = key;
+    xyzz_store(rec_pt + slot * 32, acc);
+    if (hi) head_written = true; else tail_written = true;
+  }
+  BPPP_DI void finish() {
+    if (!head_written) rec_key[2 * g] = KEY_EMPTY;
+    if (!tail_written) rec_key[2 * g + 1] = KEY_EMPTY;
+  }
+};
+
+__global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__restrict__ sorted, const uint32_t *__restrict__ total_p,
+                                                    const uint32_t *__restrict__ points, uint32_t n, uint32_t WM, int shared_pts,
+                                                    uint64_t G, uint32_t *__restrict__ buckets, uint32_t *__restrict__ rec_key,
+                                                    uint32_t *__restrict__ rec_pt) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t total = *total_p;
+  RunOut out{rec_key, rec_pt, buckets, g, false, false};
+  uint64_t pos0 = g * L0;
+  if (pos0 >= total) { out.finish(); return; }
+  uint64_t pos1 = min((uint64_t)total, pos0 + L0);
+  uint32_t prev_key = pos0 ? (uint32_t)(sorted[pos0 - 1] >> 32) : KEY_EMPTY;
+  uint32_t next_key = pos1 < total ? (uint32_t)(sorted[pos1] >> 32) : KEY_EMPTY;
+  unsigned long long e = sorted[pos0];
+  uint32_t cur = (uint32_t)(e >> 32);
+  bool first = true;
+  xyzz acc = xyzz_inf();
+  for (uint64_t p = pos0; p < pos1; p++) {
+    uint32_t k = (uint32_t)(e >> 32);
+    uint32_t idx = (uint32_t)e & 0x7FFFFFFFu;
+    bool sg = ((uint32_t)e >> 31) & 1u;
+    unsigned long long e_next = (p + 1 < pos1) ? sorted[p + 1] : 0ull;
+    if (k != cur) {
+      out.flush(cur, acc, first && cur == prev_key, false);
+      first = false; cur = k; acc = xyzz_inf();
+    }
+    size_t pidx = shared_pts ? (size_t)idx : (size_t)(k / WM) * n + idx;
+    aff P = aff_cneg(aff_load(points + pidx * 16), sg);
+    xyzz_madd(acc, P);
+    e = e_next;
+  }
+  out.flush(cur, acc, first && cur == prev_key, cur == next_key);
+  out.finish();
+}
+
+BPPP_DI uint32_t nearest_key_before(const uint32_t *keys, uint64_t b0) {
+  if (b0 >= 1 && keys[b0 - 1] != KEY_EMPTY) return keys[b0 - 1];
+  if (b0 >= 2) return keys[b0 - 2];
+  return KEY_EMPTY;
+}
+BPPP_DI uint32_t nearest_key_after(const uint32_t *keys, uint64_t b1, uint64_t S) {
+  if (b1 < S && keys[b1] != KEY_EMPTY) return keys[b1];
+  if (b1 + 1 < S) return keys[b1 + 1];
+  return KEY_EMPTY;
+}
+
+__global__ void __launch_bounds__(256) k_acc_records(const uint32_t *__restrict__ in_key, const uint32_t *__restrict__ in_pt, uint64_t S_in,
+                                                     uint64_t G, uint32_t *__restrict__ buckets, uint32_t *__restrict__ rec_key,
+                                                     uint32_t *__restrict__ rec_pt) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  RunOut out{rec_key, rec_pt, buckets, g, false, false};
+  uint64_t b0 = g * LR, b1 = min(S_in, b0 + LR);
+  uint32_t cur = KEY_EMPTY;
+  bool first = true;
+  xyzz acc = xyzz_inf();
+  uint32_t prev_key = nearest_key_before(in_key, b0);
+  uint32_t next_key = nearest_key_after(in_key, b1, S_in);
+  for (uint64_t s = b0; s < b1; s++) {
+    uint32_t k = in_key[s];
+    if (k == KEY_EMPTY) continue;
+    if (cur == KEY_EMPTY) cur = k;
+    if (k != cur) {
+      out.flush(cur, acc, first && cur == prev_key, false);
+      first = false; cur = k; acc = xyzz_inf();
+    }
+    xyzz P = xyzz_load(in_pt + s * 32);
+    xyzz_add(acc, P);
+  }
+  if (cur != KEY_EMPTY) out.flush(cur, acc, first && cur == prev_key, cur == next_key);
+  out.finish();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. bucket reduction: per window  sum_{m=1..M} m * B_m
+// One wavefront handles 64*Lw consecutive buckets: lane l takes buckets [ (wave*64+l)*Lw, +Lw ).
+__global__ void __launch_bounds__(64) k_reduce1(const uint32_t *__restrict__ buckets, int M, int Lw, int WPW, uint32_t *__restrict__ red) {
+  const uint32_t nbw = blockIdx.x, wave = blockIdx.y, lane = threadIdx.x;
+  uint32_t t = wave * 64 + lane;                 // lane index within the window
+  xyzz run = xyzz_inf(), acc = xyzz_inf();
+  if ((uint64_t)t * Lw < (uint64_t)M) {
+    const uint32_t *b = buckets + ((size_t)nbw * M + (size_t)t * Lw) * 32;
+    for (int k = Lw - 1; k >= 0; k--) {          // running sum from the top: acc = sum (k+1) * B_k
+      xyzz B = xyzz_load(b + (size_t)k * 32);
+      xyzz_add(run, B);
+      xyzz_add(acc, run);
+    }
+  }
+  // inclusive suffix scan of the lane sums S_l over the wavefront
+  xyzz suf = run;
+  for (int d = 1; d < 64; d <<= 1) {
+    xyzz o = xyzz_shfl_down(suf, d);
+    if ((int)lane + d < 64) xyzz_add(suf, o);
+  }
+  // V_l = acc_l + Lw * (l >= 1 ? suf_l : 0);  sum_l l*S_l = sum_{l>=1} suf_l
+  xyzz v = (lane >= 1) ? suf : xyzz_inf();
+  for (int k = Lw; k > 1; k >>= 1) v = xyzz_dbl(v);
+  xyzz_add(v, acc);
+  for (int d = 32; d >= 1; d >>= 1) {
+    xyzz o = xyzz_shfl_down(v, d);
+    if ((int)lane + d < 64) xyzz_add(v, o);
+  }
+  if (lane == 0) {
+    uint32_t *o = red + ((size_t)nbw * WPW + wave) * 64;
+    xyzz_store(o, v);          // A_wave
+    xyzz_store(o + 32, suf);   // S_wave (lane 0's inclusive suffix = whole-wave sum)
+  }
+}
+// across the wavefronts of a window: total = sum_j A_j + (64*Lw) * sum_{j>=1} suffix_j(S)
+__global__ void __launch_bounds__(64) k_reduce2(const uint32_t *__restrict__ red, int Lw, int WPW, uint32_t *__restrict__ winsum) {
+  const uint32_t nbw = blockIdx.x, lane = threadIdx.x;
+  xyzz A = xyzz_inf(), S = xyzz_inf();
+  if ((int)lane < WPW) {
+    const uint32_t *r = red + ((size_t)nbw * WPW + lane) * 64;
+    A = xyzz_load(r); S = xyzz_load(r + 32);
+  }
+  xyzz suf = S;
+  for (int d = 1; d < 64; d <<= 1) {
+    xyzz o = xyzz_shfl_down(suf, d);
+    if ((int)lane + d < 64) xyzz_add(suf, o);
+  }
+  xyzz v = (lane >= 1) ? suf : xyzz_inf();
+  for (int k = 64 * Lw; k > 1; k >>= 1) v = xyzz_dbl(v);
+  xyzz_add(v, A);
+  for (int d = 32; d >= 1; d >>= 1) {
+    xyzz o = xyzz_shfl_down(v, d);
+    if ((int)lane + d < 64) xyzz_add(v, o);
+  }
+  if (lane == 0) xyzz_store(winsum + (size_t)nbw * 32, v);
+}
+
+// 5. batched window combine: one lane per MSM instance
+__global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restrict__ winsum, int W, int c, uint32_t batch, uint32_t *__restrict__ out_aff) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  xyzz r = xyzz_inf();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) r = xyzz_dbl(r);
+    xyzz t = xyzz_load(winsum + ((size_t)b * W + w) * 32);
+    xyzz_add(r, t);
+  }
+  aff_store(out_aff + (size_t)b * 16, xyzz_to_aff(r));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+static int choose_window(size_t n) {
+  // cost model: W * (n madds + ~3 * 2^(c-1) bucket-reduce adds), W = floor(256/c)+1
+  double best = 1e300; int bc = 8;
+  for (int c = 4; c <= 16; c++) {
+    double W = 256 / c + 1;
+    double cost = W * ((double)n * 1.0 + 4.5 * (double)(1u << (c - 1)));
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+
+struct MsmPlan {
+  size_t n, batch; int c, W, M, CH, hist_threads, Lw, WPW;
+  uint64_t NB, FB, total_max;
+  std::vector<uint64_t> G, S;  // lanes / slots per level (G[0] = level-0 lanes)
+  int ntiles;
+};
+
+static MsmPlan make_plan(size_t n, size_t batch, int c) {
+  MsmPlan p;
+  p.n = n; p.batch = batch; p.c = c; p.W = 256 / c + 1; p.M = 1 << (c - 1);
+  p.NB = (uint64_t)batch * p.W; p.FB = p.NB * p.M; p.total_max = p.NB * n;
+  p.hist_threads = p.M >= 8192 ? 1024 : 256;
+  size_t per_block = (size_t)p.hist_threads * 64;
+  p.CH = (int)std::max<size_t>(1, std::min<size_t>(64, (n + per_block - 1) / per_block));
+  // bucket reduce geometry: lanes per window T = M / Lw, at most 64 wavefronts per window
+  if (p.M <= 64) { p.Lw = 1; p.WPW = 1; }
+  else {
+    p.Lw = 1;
+    while (p.M / p.Lw > 64 * 64) p.Lw <<= 1;     // cap at 4096 lanes per window
+    if (p.M / p.Lw >= 1024 && p.Lw < 4) p.Lw = std::min(4, p.M / 1024);  // amortise the wave scan
+    if (p.Lw < 1) p.Lw = 1;
+    p.WPW = p.M / p.Lw / 64;
+    if (p.WPW < 1) p.WPW = 1;
+  }
+  uint64_t g0 = (p.total_max + L0 - 1) / L0; if (!g0) g0 = 1;
+  p.G.push_back(g0); p.S.push_back(2 * g0);
+  while (p.G.back() > 1) {
+    uint64_t g = (p.S.back() + LR - 1) / LR;
+    p.G.push_back(g); p.S.push_back(2 * g);
+  }
+  p.ntiles = (int)((p.FB + SCAN_TILE - 1) / SCAN_TILE);
+  return p;
+}
+
+// sets K = sum_{w<W} 2^(c-1) * 2^(w*c) as 9 x 32-bit limbs
+static RecodeK make_recode_k(int c, int W) {
+  RecodeK K; memset(&K, 0, sizeof K);
+  for (int w = 0; w < W; w++) {
+    int bit = w * c + c - 1;
+    if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31);
+  }
+  return K;
+}
+
+int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points,
+            int window_bits, uint64_t *out_xy) {
+  using namespace bppp_host;
+  if (!out_xy) return fail(ctx, BPPP_ERR_ARG, "msm: null output");
+  if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
+  if (!d_scalars || !d_points) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
+  if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "msm: n must be < 2^31");
+  int c = window_bits ? window_bits : choose_window(n);
+  if (c < 2 || c > 16) return fail(ctx, BPPP_ERR_ARG, "msm: window_bits must be in [2,16]");
+  MsmPlan p = make_plan(n, batch, c);
+  if (p.FB >= (1ull << 32) - 1 || p.total_max >= (1ull << 32) - 1)
+    return fail(ctx, BPPP_ERR_ARG, "msm: batch*windows*buckets or batch*n*windows exceeds 2^32; split the batch");
+
+  // ---- carve the workspace
+  size_t need = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    Carver cv(pass ? ctx->ws : nullptr, ctx->ws_bytes);
+    uint16_t *dig = cv.take<uint16_t>(p.total_max);
+    unsigned long long *negmask = cv.take<unsigned long long>((batch * n + 63) / 64 + 1);
+    uint32_t *blockhist = cv.take<uint32_t>((size_t)p.NB * p.CH * p.M);
+    uint32_t *count = cv.take<uint32_t>(p.FB + 1);
+    uint32_t *start = cv.take<uint32_t>(p.FB + 1);
+    uint32_t *tiles = cv.take<uint32_t>(p.ntiles + 1);
+    unsigned long long *sorted = cv.take<unsigned long long>(p.total_max + 1);
+    uint32_t *buckets = cv.take<uint32_t>((size_t)p.FB * 32);
+    std::vector<uint32_t *> rkey(p.G.size()), rpt(p.G.size());
+    for (size_t l = 0; l < p.G.size(); l++) { rkey[l] = cv.take<uint32_t>(p.S[l]); rpt[l] = cv.take<uint32_t>((size_t)p.S[l] * 32); }
+    uint32_t *red = cv.take<uint32_t>((size_t)p.NB * p.WPW * 64);
+    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * 32);
+    uint32_t *out_aff = cv.take<uint32_t>((size_t)batch * 16);
+    if (!pass) { need = cv.off; int rc = ensure_workspace(ctx, need); if (rc) return rc; continue; }
+
+    hipStream_t st = ctx->stream;
+    const size_t lds = (size_t)p.M * 4;
+    if (lds > 64 * 1024) {
+      BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    prof_mark(ctx, 0);
+    // 1. digits
+    uint64_t total_sc = (uint64_t)batch * n;
+    k_digits<<<dim3((unsigned)((total_sc + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_scalars, total_sc, (uint32_t)n, c, p.W,
+                                                                            make_recode_k(c, p.W), dig, negmask);
+    prof_mark(ctx, 1);
+    // 2. sort
+    k_hist<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, (uint32_t)n, c, p.CH, blockhist);
+    k_chunk_prefix<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(blockhist, p.M, p.CH, p.FB, count);
+    k_scan_tile_sums<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles);
+    k_scan_top<<<dim3(1), dim3(1024), 0, st>>>(tiles, (uint32_t)p.ntiles, start + p.FB);
+    k_scan_apply<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles, start);
+    k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, c, p.CH, p.W, blockhist, start, sorted);
+    BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * 128, st));
+    prof_mark(ctx, 2);
+    // 3. accumulate
+    k_acc_points<<<dim3((unsigned)((p.G[0] + 255) / 256)), dim3(256), 0, st>>>(sorted, start + p.FB, (const uint32_t *)d_points, (uint32_t)n,
+                                                                              (uint32_t)(p.W * p.M), shared_points, p.G[0], buckets, rkey[0], rpt[0]);
+    for (size_t l = 1; l < p.G.size(); l++)
+      k_acc_records<<<dim3((unsigned)((p.G[l] + 255) / 256)), dim3(256), 0, st>>>(rkey[l - 1], rpt[l - 1], p.S[l - 1], p.G[l], buckets, rkey[l], rpt[l]);
+    prof_mark(ctx, 3);
+    // 4. bucket reduce
+    k_reduce1<<<dim3((unsigned)p.NB, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
+    k_reduce2<<<dim3((unsigned)p.NB), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
+    prof_mark(ctx, 4);
+    // 5. window combine
+    if (batch > 4) {
+      k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.W, c, (uint32_t)batch, out_aff);
+      BPPP_HIP(ctx, hipMemcpyAsync(out_xy, out_aff, batch * 64, hipMemcpyDeviceToHost, st));
+      prof_mark(ctx, 5);
+      BPPP_HIP(ctx, hipStreamSynchronize(st));
+    } else {
+      size_t bytes = (size_t)p.NB * 128;
+      int rc = ensure_pinned(ctx, bytes); if (rc) return rc;
+      BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
+      prof_mark(ctx, 5);
+      BPPP_HIP(ctx, hipStreamSynchronize(st));
+      const uint64_t *ws = (const uint64_t *)ctx->pinned;
+      for (size_t b = 0; b < batch; b++) {
+        HJac r = hj_inf();
+        for (int w = p.W - 1; w >= 0; w--) {
+          for (int k = 0; k < c; k++) r = hj_dbl(r);
+          const uint64_t *q = ws + ((size_t)b * p.W + w) * 16;
+          r = hj_add(r, hj_from_xyzz(U256::load(q), U256::load(q + 4), U256::load(q + 8), U256::load(q + 12)));
+        }
+        HAff a = hj_to_aff(r);
+        a.x.store(out_xy + 8 * b); a.y.store(out_xy + 8 * b + 4);
+      }
+    }
+    BPPP_HIP(ctx, hipGetLastError());
+    prof_collect(ctx, 6);
+  }
+  return BPPP_OK;
+}
+
+}  // namespace bppp

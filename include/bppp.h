@@ -1,0 +1,133 @@
+/*
+ * bppp.h — C ABI of libbppp_hip.so: the MI355X (gfx950) implementation of the Bulletproofs++
+ * hot path of Liam-Eagen/BulletproofsPP.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the Haskell `foreign import ccall` stubs that bind
+ * these symbols behind the reference's own typeclasses (FastInnerProduct / BPOpening).
+ *
+ * Data formats (all little-endian, limb 0 least significant):
+ *   scalar  Fr : 4 x uint64, canonical integer in [0, n)              (as FastPrime's 4 words,
+ *                src/Data/Field/Galois/FastPrime/Internal.hs:152-176; Encoding.hs:75-86)
+ *   point      : 8 x uint64 = affine x[4] ++ y[4], canonical in [0, p); infinity = all zero
+ *                (what `toA` yields, src/Commitment.hs:172-176; (0,0) is not on y^2 = x^3 + 7)
+ *   reduced scalar (ReducedScalar (Prime p) = Integer, Commitment.hs:270): sign flag + 3 x uint64
+ *                magnitude (< 2^130; rationalReducedScalarLength = 129, Commitment.hs:286)
+ *
+ * Buffers named d_* are DEVICE pointers (HBM-resident, 16-byte aligned); everything else is host
+ * memory.  All calls are synchronous with respect to the caller on return (outputs are valid),
+ * matching a Haskell `foreign import ccall safe`.  A context is bound to one GPU and one HIP
+ * stream and is not thread-safe; use one context per thread/GPU.
+ *
+ * Every function returns BPPP_OK (0) or a negative BPPP_ERR_* code; bppp_last_error() gives text.
+ */
+#ifndef BPPP_H
+#define BPPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPPP_OK 0
+#define BPPP_ERR_ARG (-1)      /* bad length / null pointer / unsupported parameter */
+#define BPPP_ERR_HIP (-2)      /* a HIP runtime call or kernel launch failed */
+#define BPPP_ERR_NODEVICE (-3) /* no gfx950 GPU visible */
+#define BPPP_ERR_POINT (-4)    /* validation requested and a point is not on the curve */
+
+typedef struct bppp_ctx bppp_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int bppp_ctx_create(int device, bppp_ctx **out);
+void bppp_ctx_destroy(bppp_ctx *ctx);
+/* run all work of this context on an existing hipStream_t (e.g. torch's current stream);
+ * NULL = the context's own stream. */
+int bppp_ctx_set_stream(bppp_ctx *ctx, void *hip_stream);
+const char *bppp_last_error(const bppp_ctx *ctx);
+const char *bppp_version(void);
+
+/* ---- a1: FastInnerProduct.innerProduct / commit --------------------------------------------
+ * Replaces `innerProduct :: [(Scalar v, v)] -> v` (src/Commitment.hs:325-335) as reached through
+ * `commit` (src/Commitment.hs:416-417): out = sum_i scalars[i] * points[i], as the canonical
+ * affine point.  Zero scalars and points at infinity are allowed (dotWith pads with both,
+ * Commitment.hs:423-424).  n = 0 returns infinity (the reference would crash on `head []`,
+ * Commitment.hs:328 — documented deviation).  Algorithm: signed-digit Pippenger bucket method
+ * (a different algorithm from the reference's 256-row Straus loop; same group element). */
+int bppp_msm(bppp_ctx *ctx, const uint64_t *scalars, const uint64_t *points_xy, size_t n, uint64_t out_xy[8]);
+/* same, inputs already resident in HBM; window_bits = 0 lets the library choose. */
+int bppp_msm_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, int window_bits,
+                    uint64_t out_xy[8]);
+/* `batch` independent MSMs of n terms each in one pass (one per proof: verifyBPM's single commit,
+ * src/Bulletproof.hs:377).  d_scalars is [batch][n]; d_points_xy is [batch][n] or, when
+ * shared_points != 0, one [n] basis used by every instance.  out_xy is [batch][8] on the host. */
+int bppp_msm_batch_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, size_t batch,
+                          int shared_points, int window_bits, uint64_t *out_xy);
+
+/* ---- a7: SplitScalar.rationalReduceScalar (host) ------------------------------------------
+ * Replaces rationalReduceScalar for `Prime p` (src/Commitment.hs:242-255, instance :269-288):
+ * returns (a, b) with x = a / b (mod n), following the reference's egcd step-for-step (its
+ * choice of (a, b) fixes the collapsed basis points, so it must match exactly). */
+int bppp_rational_reduce(const uint64_t x[4], uint64_t a_mag[3], int *a_neg, uint64_t b_mag[3], int *b_neg);
+
+/* ---- a8: projectivePairIP via collapsePoints, over a whole vector ---------------------------
+ * Replaces `collapsePoints b a gL gR = projectivePairIP (b, gL) (a, gR)` (src/Bulletproof.hs:213-214,
+ * src/Commitment.hs:343-353) mapped over adjacent pairs by mapHalves (src/Bulletproof.hs:88-90):
+ * out[j] = b * pts[2j] + a * pts[2j+1] for j < ceil(n/2); an odd tail pairs with infinity.
+ * The same (a, b) is used for every pair (one uniform add/double schedule per wavefront). */
+int bppp_fold_points(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
+                     const uint64_t *points_xy, size_t n, uint64_t *out_xy);
+int bppp_fold_points_device(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
+                            const void *d_points_xy, size_t n, void *d_out_xy);
+
+/* ---- a10/a11/a16: scalar halves of the Norm / Linear round (NL flavour) ---------------------
+ * makeScalarsComs scalar sums (src/Bulletproof/NormArgument.hs:113-118 via foldXR :20-29):
+ *   sx = sum_j q^(4j) xL_j xR_j,  sr = sum_j q^(4j) xR_j^2   over adjacent pairs (odd tail: xR = 0)
+ * The caller applies the 2 n^2 q^3 / n^2 q^4 factors (host glue, one multiplication each). */
+int bppp_norm_round_sums_device(bppp_ctx *ctx, const void *d_x, size_t n, const uint64_t q4[4], uint64_t sx[4],
+                                uint64_t sr[4]);
+/* Linear makeScalarsComs sums (NormArgument.hs:56-59): sx = sum cL xR + cR xL, sr = sum cR xR */
+int bppp_lin_round_sums_device(bppp_ctx *ctx, const void *d_c, const void *d_x, size_t n, uint64_t sx[4],
+                               uint64_t sr[4]);
+/* X / R opening scalars of the Norm round (NormArgument.hs:117): d_xw[2j] = q xR_j,
+ * d_xw[2j+1] = qinv xL_j (length 2*ceil(n/2)); d_rw[j] = xR_j (length ceil(n/2)). */
+int bppp_norm_round_openings_device(bppp_ctx *ctx, const void *d_x, size_t n, const uint64_t q[4],
+                                    const uint64_t qinv[4], void *d_xw, void *d_rw);
+/* Linear X / R opening scalars (NormArgument.hs:59): d_xw[2j] = xR_j, d_xw[2j+1] = xL_j; d_rw[j] = xR_j */
+int bppp_lin_round_openings_device(bppp_ctx *ctx, const void *d_x, size_t n, void *d_xw, void *d_rw);
+/* scalar vector fold of collapse (NormArgument.hs:129 / :71): out[j] = u * x[2j] + v * x[2j+1]
+ * with u = b0^-1, v = e q b0^-1 (norm) or e b0^-1 (linear x) or (u, v) = (b0, a0) (linear c). */
+int bppp_fold_scalars_device(bppp_ctx *ctx, const uint64_t u[4], const uint64_t v[4], const void *d_x, size_t n,
+                             void *d_out);
+
+/* ---- a15: tensor' (challenge expansion) -----------------------------------------------------
+ * Replaces the list instance of tensor' (src/Bulletproof.hs:94-95) as used by expandChallenges
+ * (NormArgument.hs:73-81, :131-145): out[i * 2^k + t] = bs[i] * prod over rounds of (q_r or e_r)
+ * selected by the bits of t.  es (k challenges, LAST ROUND FIRST as verifyBPM holds them,
+ * Bulletproof.hs:374) and qs (k weights, first round first) are host arrays of k scalars. */
+int bppp_tensor_device(bppp_ctx *ctx, const uint64_t *bs, size_t nb, const uint64_t *es, const uint64_t *qs,
+                       size_t k, void *d_out);
+
+/* ---- device memory helpers (so a non-HIP host language can keep vectors resident) ---------- */
+int bppp_device_alloc(bppp_ctx *ctx, size_t bytes, void **d_ptr);
+int bppp_device_free(bppp_ctx *ctx, void *d_ptr);
+int bppp_upload(bppp_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int bppp_download(bppp_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
+/* ---- measurement hooks ---------------------------------------------------------------------
+ * When enabled, each MSM call brackets its stages with hipEvents on the context's stream; the
+ * accumulated per-stage milliseconds and launch counts can be read back (bench.py's roofline). */
+#define BPPP_STAGE_DIGITS 0
+#define BPPP_STAGE_SORT 1
+#define BPPP_STAGE_ACCUMULATE 2
+#define BPPP_STAGE_REDUCE 3
+#define BPPP_STAGE_FINISH 4
+#define BPPP_NUM_STAGES 5
+int bppp_profile_enable(bppp_ctx *ctx, int on);
+int bppp_profile_read(bppp_ctx *ctx, double ms[BPPP_NUM_STAGES], uint64_t *calls, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPPP_H */

@@ -1,0 +1,27 @@
+/*
+ * bppp_test.h — test-only hooks exported by libbppp_hip.so so the parity tests can exercise the
+ * device field and group arithmetic directly (the device counterparts of mulField# / addField# /
+ * invField#, src/Data/Field/Galois/FastPrime/Internal.hs:909-988, and of nrmlAdd / dbl',
+ * src/Commitment.hs:111-144).  Not part of the drop-in boundary.
+ */
+#ifndef BPPP_TEST_H
+#define BPPP_TEST_H
+#include "bppp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define BPPP_FE_ADD 0
+#define BPPP_FE_SUB 1
+#define BPPP_FE_MUL 2
+#define BPPP_FE_SQR 3
+#define BPPP_FE_INV 4
+#define BPPP_FE_NEG 5
+/* out[i] = a[i] (op) b[i] in Fq (modulus = 0) or Fr (modulus = 1); host arrays of n x 4 uint64 */
+int bppp_test_fe_op(bppp_ctx *ctx, int op, int modulus, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
+/* out[i] = p[i] + q[i] (complete group law; op 0: mixed XYZZ+affine, op 1: XYZZ+XYZZ, op 2: 2*p[i]);
+ * host arrays of n x 8 uint64 affine points */
+int bppp_test_point_op(bppp_ctx *ctx, int op, const uint64_t *p, const uint64_t *q, size_t n, uint64_t *out);
+#ifdef __cplusplus
+}
+#endif
+#endif

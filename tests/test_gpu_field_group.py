@@ -1,0 +1,75 @@
+"""Device field / group arithmetic vs the oracle (bit-exact: integer work)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_scalars, array_to_point
+
+pytestmark = pytest.mark.gpu
+
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5}
+
+
+def _fe_op(gpu, op, mod, a, b):
+    A, B = scalars_to_array(a), scalars_to_array(b)
+    out = np.zeros_like(A)
+    lib = gpu.lib
+    lib.bppp_test_fe_op.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    rc = lib.bppp_test_fe_op(gpu.h, OPS[op], mod, A.ctypes.data, B.ctypes.data, len(a), out.ctypes.data)
+    assert rc == 0, gpu.lib.bppp_last_error(gpu.h)
+    return array_to_scalars(out)
+
+
+def _edge_values(m):
+    return [0, 1, 2, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2, 2**255 % m, 2**128, 2**128 - 1, 2**64, 2**32 + 977,
+            0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF, m - 2**32, m - 977, 3**160 % m, 2**224 - 1]
+
+
+@pytest.mark.parametrize("mod,m", [(0, O.P), (1, O.N)])
+def test_field_ops_match_python(gpu, mod, m):
+    rnd = random.Random(11 + mod)
+    edge = _edge_values(m)
+    a = edge + [rnd.randrange(m) for _ in range(2000)] + [e for e in edge for _ in edge]
+    b = edge[::-1] + [rnd.randrange(m) for _ in range(2000)] + [f for _ in edge for f in edge]
+    assert _fe_op(gpu, "add", mod, a, b) == [(x + y) % m for x, y in zip(a, b)]
+    assert _fe_op(gpu, "sub", mod, a, b) == [(x - y) % m for x, y in zip(a, b)]
+    assert _fe_op(gpu, "mul", mod, a, b) == [(x * y) % m for x, y in zip(a, b)]
+    assert _fe_op(gpu, "sqr", mod, a, b) == [(x * x) % m for x in a]
+    assert _fe_op(gpu, "neg", mod, a, b) == [(-x) % m for x in a]
+    small = a[:300]
+    assert _fe_op(gpu, "inv", mod, small, small) == [O.inv_mod(x, m) for x in small]
+
+
+def test_reference_constant_3_pow_160(gpu):
+    # "3^160" test value of FastPrime/Internal.hs:108-116 (verified in SURVEY.md App. C): square-and-multiply on device
+    acc = [1]
+    for _ in range(160):
+        acc = _fe_op(gpu, "mul", 1, acc, [3])
+    assert acc[0] == 3**160 % O.N
+
+
+def _pt_op(gpu, op, ps, qs):
+    A, B = points_to_array(ps), points_to_array(qs)
+    out = np.zeros_like(A)
+    lib = gpu.lib
+    lib.bppp_test_point_op.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    rc = lib.bppp_test_point_op(gpu.h, op, A.ctypes.data, B.ctypes.data, len(ps), out.ctypes.data)
+    assert rc == 0
+    return [array_to_point(out[i]) for i in range(len(ps))]
+
+
+def test_group_law_complete(gpu, oracle_lib):
+    py = O.PyEC()
+    pts = O.hash_points(b"grp", 40)
+    G = (O.GX, O.GY)
+    ps = pts[:20] + [G, G, None, G, None, pts[0]]
+    qs = pts[20:40] + [G, py.neg(G), G, None, None, py.neg(pts[0])]
+    want = [py.add(p, q) for p, q in zip(ps, qs)]
+    assert _pt_op(gpu, 0, ps, qs) == want          # XYZZ += affine, incl. P=Q, P=-Q, infinities
+    assert _pt_op(gpu, 1, ps, qs) == want          # XYZZ += XYZZ
+    assert _pt_op(gpu, 2, ps, qs) == [py.add(py.add(p, p), py.add(p, p)) for p in ps]
+    # lambda*G = (beta*Gx, Gy): the endomorphism constants of FastSECP256K1.hs:39,53
+    assert oracle_lib.mul(O.LAMBDA, G) == (O.BETA * O.GX % O.P, O.GY)

@@ -1,0 +1,84 @@
+"""Round kernels (point fold, scalar folds, round sums, tensor) vs the oracle's restatement of
+NormArgument.hs / Bulletproof.hs."""
+import random
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_point, array_to_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 65, 387])
+def test_fold_points_matches_pair_ip(gpu, oracle_lib, n):
+    rnd = random.Random(n)
+    pts = O.hash_points(b"fold%d" % n, n)
+    if n > 4:
+        pts[3] = None
+    e = rnd.randrange(O.N)
+    a1, b1 = O.rational_reduce_scalar(e)
+    assert gpu.rational_reduce(e) == (a1, b1)
+    got = gpu.fold_points(b1, a1, points_to_array(pts))
+    want = [oracle_lib.pair_ip(b1, pts[2 * j], a1, pts[2 * j + 1] if 2 * j + 1 < n else None) for j in range((n + 1) // 2)]
+    assert [array_to_point(got[j]) for j in range(len(want))] == want
+
+
+def test_rational_reduce_edges(gpu):
+    rnd = random.Random(3)
+    for x in [0, 1, 2, O.N - 1, O.N - 2, 2**128, 2**129, (O.N - 1) // 2, (O.N + 1) // 2] + [rnd.randrange(O.N) for _ in range(300)]:
+        assert gpu.rational_reduce(x) == O.rational_reduce_scalar(x)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 512, 261, 1000])
+def test_round_scalar_kernels(gpu, n):
+    rnd = random.Random(100 + n)
+    x = [rnd.randrange(O.N) for _ in range(n)]
+    c = [rnd.randrange(O.N) for _ in range(n)]
+    q = rnd.randrange(1, O.N)
+    qi = O.inv_mod(q, O.N)
+    dx, dc = gpu.to_device(scalars_to_array(x)), gpu.to_device(scalars_to_array(c))
+    npair = (n + 1) // 2
+    dxw, drw, dout = gpu.alloc(2 * npair * 32), gpu.alloc(npair * 32), gpu.alloc(npair * 32)
+    try:
+        # Norm.makeScalarsComs (NormArgument.hs:113-118)
+        st = O.Norm(q, qi, 1, [(v, None) for v in x])
+        sX, xw, sR, rw = st.make_scalars_coms()
+        q4 = pow(q, 4, O.N)
+        sx, sr = gpu.norm_round_sums(dx, n, q4)
+        assert 2 * pow(q, 3, O.N) * sx % O.N == sX and q4 * sr % O.N == sR
+        gpu.norm_round_openings(dx, n, q, qi, dxw, drw)
+        assert array_to_scalars(gpu.download(dxw, (2 * npair, 4))) == [v for v, _ in xw.body]
+        assert array_to_scalars(gpu.download(drw, (npair, 4))) == [v for v, _ in rw.body]
+        # Linear.makeScalarsComs (NormArgument.hs:56-59)
+        lt = O.Linear(1, [(cc, v, None) for cc, v in zip(c, x)])
+        lX, lxw, lR, lrw = lt.make_scalars_coms()
+        assert gpu.lin_round_sums(dc, dx, n) == (lX, lR)
+        gpu.lin_round_openings(dx, n, dxw, drw)
+        assert array_to_scalars(gpu.download(dxw, (2 * npair, 4))) == [v for _, v, _ in lxw.body]
+        assert array_to_scalars(gpu.download(drw, (npair, 4))) == [v for _, v, _ in lrw.body]
+        # collapse scalar parts (NormArgument.hs:129, :71)
+        u, v = rnd.randrange(O.N), rnd.randrange(O.N)
+        gpu.fold_scalars(u, v, dx, n, dout)
+        want = [(u * x[2 * j] + (v * x[2 * j + 1] if 2 * j + 1 < n else 0)) % O.N for j in range(npair)]
+        assert array_to_scalars(gpu.download(dout, (npair, 4))) == want
+    finally:
+        for p in (dx, dc, dxw, drw, dout):
+            gpu.free(p)
+
+
+@pytest.mark.parametrize("nb,k", [(1, 0), (2, 1), (3, 4), (2, 8), (1, 9)])
+def test_tensor_matches_list_instance(gpu, nb, k):
+    rnd = random.Random(nb * 31 + k)
+    bs = [rnd.randrange(O.N) for _ in range(nb)]
+    es = [rnd.randrange(O.N) for _ in range(k)]       # last round first
+    q = rnd.randrange(1, O.N)
+    qs = [pow(q, 2**r, O.N) for r in range(k)]        # iterate (^2) q
+    want = O.tensor(bs, es, lambda r: qs[r])
+    dout = gpu.alloc(max(1, nb << k) * 32)
+    try:
+        gpu.tensor(bs, es, qs, dout)
+        assert array_to_scalars(gpu.download(dout, (nb << k, 4))) == want
+    finally:
+        gpu.free(dout)
