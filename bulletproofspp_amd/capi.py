@@ -9,8 +9,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-NUM_STAGES = 5
-STAGE_NAMES = ["digits", "sort", "accumulate", "reduce", "finish"]
+NUM_STAGES = 6
+STAGE_NAMES = ["digits", "sort", "acc_points", "acc_records", "reduce", "finish"]
 
 # every symbol include/bppp.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -20,7 +20,7 @@ SYMBOLS = [
     "bppp_norm_round_sums_device", "bppp_lin_round_sums_device",
     "bppp_norm_round_openings_device", "bppp_lin_round_openings_device",
     "bppp_fold_scalars_device", "bppp_tensor_device",
-    "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
+    "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
     "bppp_profile_enable", "bppp_profile_read",
 ]
 
@@ -59,6 +59,7 @@ def load_library() -> C.CDLL:
     lib.bppp_lin_round_openings_device.argtypes = [vp, vp, sz, vp, vp]
     lib.bppp_fold_scalars_device.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.bppp_tensor_device.argtypes = [vp, vp, sz, vp, vp, sz, vp]
+    lib.bppp_lift_x_device.argtypes = [vp, vp, sz, vp]
     lib.bppp_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.bppp_device_free.argtypes = [vp, vp]
     lib.bppp_upload.argtypes = [vp, vp, vp, sz]
@@ -217,6 +218,9 @@ class Bppp:
         assert len(qs) == k
         self._check(self.lib.bppp_tensor_device(self.h, _ptr(scalars_to_array(bs)), len(bs), _ptr(scalars_to_array(es)) if k else None,
                                                 _ptr(scalars_to_array(qs)) if k else None, k, _ptr(d_out)), "bppp_tensor_device")
+
+    def lift_x(self, d_x: int, n: int, d_points: int):
+        self._check(self.lib.bppp_lift_x_device(self.h, _ptr(d_x), n, _ptr(d_points)), "bppp_lift_x_device")
 
     # ---- device memory
     def alloc(self, nbytes: int) -> int:

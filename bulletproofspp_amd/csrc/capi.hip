@@ -13,6 +13,7 @@ int lin_round_sums_run(bppp_ctx *, const void *, const void *, size_t, uint64_t 
 int round_openings_run(bppp_ctx *, const void *, size_t, int, const uint64_t *, const uint64_t *, void *, void *);
 int fold_scalars_run(bppp_ctx *, const uint64_t *, const uint64_t *, const void *, size_t, void *);
 int tensor_run(bppp_ctx *, const uint64_t *, size_t, const uint64_t *, const uint64_t *, size_t, void *);
+int lift_x_run(bppp_ctx *, const void *, size_t, void *);
 
 int ensure_workspace(bppp_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return BPPP_OK;
@@ -181,6 +182,11 @@ int bppp_fold_scalars_device(bppp_ctx *ctx, const uint64_t u[4], const uint64_t 
 int bppp_tensor_device(bppp_ctx *ctx, const uint64_t *bs, size_t nb, const uint64_t *es, const uint64_t *qs, size_t k, void *d_out) {
   CTX_ENTER(ctx);
   return tensor_run(ctx, bs, nb, es, qs, k, d_out);
+}
+
+int bppp_lift_x_device(bppp_ctx *ctx, const void *d_x, size_t n, void *d_points_xy) {
+  CTX_ENTER(ctx);
+  return lift_x_run(ctx, d_x, n, d_points_xy);
 }
 
 int bppp_device_alloc(bppp_ctx *ctx, size_t bytes, void **d_ptr) {

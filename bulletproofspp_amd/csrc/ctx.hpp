@@ -19,7 +19,7 @@ struct bppp_ctx {
   size_t pinned_bytes = 0;
   // profiling
   bool profile = false;
-  double stage_ms[BPPP_NUM_STAGES] = {0, 0, 0, 0, 0};
+  double stage_ms[BPPP_NUM_STAGES] = {0, 0, 0, 0, 0, 0};
   uint64_t calls = 0;
   hipEvent_t ev[BPPP_NUM_STAGES + 1] = {};
   bool ev_ready = false;

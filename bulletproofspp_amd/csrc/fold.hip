@@ -33,6 +33,40 @@ __global__ void __launch_bounds__(64) k_fold_points(const uint32_t *__restrict__
   aff_store(out + (size_t)j * 16, xyzz_to_aff(acc));
 }
 
+// pointX (app/Main.hs:68-72): y = sqrt(x^3 + 7) = (x^3+7)^((p+1)/4) since p = 3 mod 4; even root.
+__global__ void __launch_bounds__(64) k_lift_x(const uint32_t *__restrict__ xs, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x = fe_load(xs + (size_t)i * 8);
+  fe t;
+  bool ok = raw_sub(t, x, fp_modulus()) != 0;      // x < p
+  fe seven = fe_zero(); seven.v[0] = 7;
+  fe rhs = FPA(FPM(FPS(x), x), seven);
+  // exponent (p+1)/4 = 0x3FFFFFFF FFFFFFFF ... BFFFFF0C
+  fe e = fp_modulus();
+  e.v[0] += 1;                                      // p + 1 (low limb 0xFFFFFC2F + 1, no carry)
+#pragma unroll
+  for (int k = 0; k < 8; k++) e.v[k] = (e.v[k] >> 2) | (k < 7 ? e.v[k + 1] << 30 : 0u);
+  fe acc = fe_one(), base = rhs;
+  for (int b = 0; b < 254; b++) {
+    if ((e.v[b >> 5] >> (b & 31)) & 1u) acc = FPM(acc, base);
+    base = FPS(base);
+  }
+  ok = ok && fe_eq(FPS(acc), rhs);
+  if (acc.v[0] & 1u) acc = fe_neg<0>(acc);
+  aff r; r.x = x; r.y = acc;
+  if (!ok) r = aff_inf();
+  aff_store(out + (size_t)i * 16, r);
+}
+int lift_x_run(bppp_ctx *ctx, const void *d_x, size_t n, void *d_out) {
+  if (n == 0) return BPPP_OK;
+  if (!d_x || !d_out || n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "lift_x: bad input");
+  k_lift_x<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_x, (uint32_t)n, (uint32_t *)d_out);
+  BPPP_HIP(ctx, hipGetLastError());
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BPPP_OK;
+}
+
 int fold_points_run(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
                     const void *d_pts, size_t n, void *d_out) {
   if (n == 0) return BPPP_OK;

@@ -9,11 +9,12 @@
 //   2. k_hist / k_scan* / k_scatter
 //                    counting sort of (window, |digit|) keys: the bucket histogram and cursors are
 //                    staged in LDS (<= 128 KiB per workgroup), so HBM sees only coalesced streams.
-//   3. k_acc_points / k_acc_records
+//   3. k_acc_points / k_merge / k_merge_heavy
 //                    load-balanced bucket accumulation: every lane owns exactly L consecutive
 //                    sorted entries (not one bucket), sums runs of equal key in an XYZZ register
-//                    accumulator with mixed adds, stores complete buckets and hands incomplete
-//                    head/tail runs to the next (L-times smaller) level.
+//                    accumulator with mixed adds and stores complete buckets; a bucket that
+//                    straddles lanes is finished by k_merge (one lane per bucket) or, when it spans
+//                    many lanes (skewed scalars), by one wavefront in k_merge_heavy.
 //   4. k_reduce1/2   sum_m m*B_m per window by per-lane running sums plus a wavefront suffix scan
 //                    (shuffles of whole points), then across wavefronts.
 //   5. window combine: Horner over <= 65 window sums — on the host for one MSM (a 256-doubling
@@ -29,8 +30,6 @@
 namespace bppp {
 
 static constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
-static constexpr int L0 = 16;   // sorted entries per lane, level 0
-static constexpr int LR = 32;   // record slots per lane, levels >= 1
 
 struct RecodeK { uint32_t k[9]; };
 
@@ -184,34 +183,21 @@ __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long 
 
 // ------------------------------------------------------------------------------------------------
 // 3. load-balanced accumulation
-struct RunOut {
-  uint32_t *rec_key; uint32_t *rec_pt; uint32_t *buckets;
-  uint64_t g;
-  bool head_written, tail_written;
-  BPPP_DI void flush(uint32_t key, const xyzz &acc, bool hi, bool ti) {
-    if (!hi && !ti) { xyzz_store(buckets + (size_t)key * 32, acc); return; }
-    uint64_t slot = 2 * g + (hi ? 0 : 1);
-    rec_key[slot] = key;
-    xyzz_store(rec_pt + slot * 32, acc);
-    if (hi) head_written = true; else tail_written = true;
-  }
-  BPPP_DI void finish() {
-    if (!head_written) rec_key[2 * g] = KEY_EMPTY;
-    if (!tail_written) rec_key[2 * g + 1] = KEY_EMPTY;
-  }
-};
-
+// Lane g owns sorted positions [g*L, (g+1)*L).  A bucket b = [start[b], start[b]+count[b]) that lies
+// inside one lane is summed and stored there.  A bucket spanning lanes g0 < g1 leaves partial sums:
+//   lane g0 (run starts inside the lane)      -> tail slot 2*g0+1
+//   lanes g0 < g <= g1 (run continues from g-1) -> head slot 2*g
+// which k_merge (one lane per bucket, short spans) or k_merge_heavy (one wavefront per bucket)
+// add up.  Slots are addressed from start/count alone: no keys are stored, no compaction needed.
 __global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__restrict__ sorted, const uint32_t *__restrict__ total_p,
                                                     const uint32_t *__restrict__ points, uint32_t n, uint32_t WM, int shared_pts,
-                                                    uint64_t G, uint32_t *__restrict__ buckets, uint32_t *__restrict__ rec_key,
-                                                    uint32_t *__restrict__ rec_pt) {
+                                                    int L, uint64_t G, uint32_t *__restrict__ buckets, uint32_t *__restrict__ rec_pt) {
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const uint32_t total = *total_p;
-  RunOut out{rec_key, rec_pt, buckets, g, false, false};
-  uint64_t pos0 = g * L0;
-  if (pos0 >= total) { out.finish(); return; }
-  uint64_t pos1 = min((uint64_t)total, pos0 + L0);
+  uint64_t pos0 = g * (uint64_t)L;
+  if (pos0 >= total) return;
+  uint64_t pos1 = min((uint64_t)total, pos0 + L);
   uint32_t prev_key = pos0 ? (uint32_t)(sorted[pos0 - 1] >> 32) : KEY_EMPTY;
   uint32_t next_key = pos1 < total ? (uint32_t)(sorted[pos1] >> 32) : KEY_EMPTY;
   unsigned long long e = sorted[pos0];
@@ -224,7 +210,9 @@ __global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__
     bool sg = ((uint32_t)e >> 31) & 1u;
     unsigned long long e_next = (p + 1 < pos1) ? sorted[p + 1] : 0ull;
     if (k != cur) {
-      out.flush(cur, acc, first && cur == prev_key, false);
+      // the finished run ends inside this lane: head partial if it came from the previous lane, else complete
+      if (first && cur == prev_key) xyzz_store(rec_pt + (2 * g) * 32, acc);
+      else xyzz_store(buckets + (size_t)cur * 32, acc);
       first = false; cur = k; acc = xyzz_inf();
     }
     size_t pidx = shared_pts ? (size_t)idx : (size_t)(k / WM) * n + idx;
@@ -232,46 +220,91 @@ __global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__
     xyzz_madd(acc, P);
     e = e_next;
   }
-  out.flush(cur, acc, first && cur == prev_key, cur == next_key);
-  out.finish();
+  bool hi = first && cur == prev_key, ti = cur == next_key;
+  if (hi) xyzz_store(rec_pt + (2 * g) * 32, acc);
+  else if (ti) xyzz_store(rec_pt + (2 * g + 1) * 32, acc);
+  else xyzz_store(buckets + (size_t)cur * 32, acc);
 }
 
-BPPP_DI uint32_t nearest_key_before(const uint32_t *keys, uint64_t b0) {
-  if (b0 >= 1 && keys[b0 - 1] != KEY_EMPTY) return keys[b0 - 1];
-  if (b0 >= 2) return keys[b0 - 2];
-  return KEY_EMPTY;
-}
-BPPP_DI uint32_t nearest_key_after(const uint32_t *keys, uint64_t b1, uint64_t S) {
-  if (b1 < S && keys[b1] != KEY_EMPTY) return keys[b1];
-  if (b1 + 1 < S) return keys[b1 + 1];
-  return KEY_EMPTY;
+static constexpr int MERGE_SERIAL_MAX = 8;   // longer spans go to the wavefront-cooperative kernels
+static constexpr int HEAVY_CHUNK = 256;      // partial sums per wavefront in k_merge_heavy
+
+// partial t of a bucket whose first lane is g0: t = 0 is g0's tail slot, t >= 1 the head slot of lane g0+t
+BPPP_DI const uint32_t *partial_ptr(const uint32_t *rec_pt, uint64_t g0, uint64_t t) {
+  return rec_pt + (t == 0 ? 2 * g0 + 1 : 2 * (g0 + t)) * 32;
 }
 
-__global__ void __launch_bounds__(256) k_acc_records(const uint32_t *__restrict__ in_key, const uint32_t *__restrict__ in_pt, uint64_t S_in,
-                                                     uint64_t G, uint32_t *__restrict__ buckets, uint32_t *__restrict__ rec_key,
-                                                     uint32_t *__restrict__ rec_pt) {
-  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
-  RunOut out{rec_key, rec_pt, buckets, g, false, false};
-  uint64_t b0 = g * LR, b1 = min(S_in, b0 + LR);
-  uint32_t cur = KEY_EMPTY;
-  bool first = true;
-  xyzz acc = xyzz_inf();
-  uint32_t prev_key = nearest_key_before(in_key, b0);
-  uint32_t next_key = nearest_key_after(in_key, b1, S_in);
-  for (uint64_t s = b0; s < b1; s++) {
-    uint32_t k = in_key[s];
-    if (k == KEY_EMPTY) continue;
-    if (cur == KEY_EMPTY) cur = k;
-    if (k != cur) {
-      out.flush(cur, acc, first && cur == prev_key, false);
-      first = false; cur = k; acc = xyzz_inf();
-    }
-    xyzz P = xyzz_load(in_pt + s * 32);
-    xyzz_add(acc, P);
+__global__ void __launch_bounds__(256) k_merge(const uint32_t *__restrict__ start, const uint32_t *__restrict__ count, uint64_t FB, int L,
+                                               const uint32_t *__restrict__ rec_pt, uint32_t *__restrict__ buckets,
+                                               uint2 *__restrict__ heavy_items, uint4 *__restrict__ heavy_buckets, uint32_t *__restrict__ heavy_count) {
+  uint64_t fb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (fb >= FB) return;
+  uint32_t cnt = count[fb];
+  if (!cnt) return;
+  uint32_t s = start[fb];
+  uint64_t g0 = s / (uint32_t)L, g1 = (uint64_t)(s + cnt - 1) / (uint32_t)L;
+  if (g0 == g1) return;                       // summed and stored by its lane
+  uint32_t np = (uint32_t)(g1 - g0 + 1);      // number of partial sums
+  if (np > MERGE_SERIAL_MAX + 1) {
+    // skewed scalars / a narrow top window: hand the bucket to wavefronts, HEAVY_CHUNK partials each
+    uint32_t nch = (np + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+    uint32_t base = atomicAdd(&heavy_count[0], nch);
+    for (uint32_t j = 0; j < nch; j++) heavy_items[base + j] = make_uint2((uint32_t)fb, j);
+    if (nch > 1) heavy_buckets[atomicAdd(&heavy_count[1], 1u)] = make_uint4((uint32_t)fb, base, nch, 0u);
+    return;
   }
-  if (cur != KEY_EMPTY) out.flush(cur, acc, first && cur == prev_key, cur == next_key);
-  out.finish();
+  xyzz acc = xyzz_load(partial_ptr(rec_pt, g0, 0));
+  for (uint32_t t = 1; t < np; t++) {
+    xyzz p = xyzz_load(partial_ptr(rec_pt, g0, t));
+    xyzz_add(acc, p);
+  }
+  xyzz_store(buckets + fb * 32, acc);
+}
+
+// one wavefront per (heavy bucket, chunk): lanes stride over the chunk's partials, then a shuffle tree
+__global__ void __launch_bounds__(64) k_merge_heavy(const uint32_t *__restrict__ start, const uint32_t *__restrict__ count, int L,
+                                                    const uint32_t *__restrict__ rec_pt, uint32_t *__restrict__ buckets,
+                                                    const uint2 *__restrict__ heavy_items, const uint32_t *__restrict__ heavy_count,
+                                                    uint32_t *__restrict__ chunk_sums) {
+  const uint32_t nitems = heavy_count[0], lane = threadIdx.x;
+  for (uint32_t h = blockIdx.x; h < nitems; h += gridDim.x) {
+    uint2 it = heavy_items[h];
+    uint32_t fb = it.x, s = start[fb], cnt = count[fb];
+    uint64_t g0 = s / (uint32_t)L, g1 = (uint64_t)(s + cnt - 1) / (uint32_t)L;
+    uint32_t np = (uint32_t)(g1 - g0 + 1);
+    uint32_t t0 = it.y * HEAVY_CHUNK, t1 = min(np, t0 + HEAVY_CHUNK);
+    xyzz acc = xyzz_inf();
+    for (uint32_t t = t0 + lane; t < t1; t += 64) {
+      xyzz p = xyzz_load(partial_ptr(rec_pt, g0, t));
+      xyzz_add(acc, p);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      xyzz o = xyzz_shfl_down(acc, d);
+      if ((int)lane + d < 64) xyzz_add(acc, o);
+    }
+    if (lane == 0) {
+      if (np <= HEAVY_CHUNK) xyzz_store(buckets + (size_t)fb * 32, acc);
+      else xyzz_store(chunk_sums + (size_t)h * 32, acc);
+    }
+  }
+}
+// buckets with more than one chunk: one wavefront adds the chunk sums
+__global__ void __launch_bounds__(64) k_merge_heavy2(const uint4 *__restrict__ heavy_buckets, const uint32_t *__restrict__ heavy_count,
+                                                     const uint32_t *__restrict__ chunk_sums, uint32_t *__restrict__ buckets) {
+  const uint32_t nb = heavy_count[1], lane = threadIdx.x;
+  for (uint32_t h = blockIdx.x; h < nb; h += gridDim.x) {
+    uint4 hb = heavy_buckets[h];
+    xyzz acc = xyzz_inf();
+    for (uint32_t j = lane; j < hb.z; j += 64) {
+      xyzz p = xyzz_load(chunk_sums + (size_t)(hb.y + j) * 32);
+      xyzz_add(acc, p);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      xyzz o = xyzz_shfl_down(acc, d);
+      if ((int)lane + d < 64) xyzz_add(acc, o);
+    }
+    if (lane == 0) xyzz_store(buckets + (size_t)hb.x * 32, acc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,7 +394,7 @@ static int choose_window(size_t n) {
 struct MsmPlan {
   size_t n, batch; int c, W, M, CH, hist_threads, Lw, WPW;
   uint64_t NB, FB, total_max;
-  std::vector<uint64_t> G, S;  // lanes / slots per level (G[0] = level-0 lanes)
+  int L; uint64_t G;           // sorted entries per lane, number of lanes
   int ntiles;
 };
 
@@ -382,12 +415,10 @@ static MsmPlan make_plan(size_t n, size_t batch, int c) {
     p.WPW = p.M / p.Lw / 64;
     if (p.WPW < 1) p.WPW = 1;
   }
-  uint64_t g0 = (p.total_max + L0 - 1) / L0; if (!g0) g0 = 1;
-  p.G.push_back(g0); p.S.push_back(2 * g0);
-  while (p.G.back() > 1) {
-    uint64_t g = (p.S.back() + LR - 1) / LR;
-    p.G.push_back(g); p.S.push_back(2 * g);
-  }
+  // slice length: long enough that few buckets straddle lanes, short enough to keep >= ~64K lanes
+  p.L = 4;
+  while (p.L < 64 && p.total_max / (uint64_t)(2 * p.L) >= 65536) p.L <<= 1;
+  p.G = (p.total_max + p.L - 1) / p.L; if (!p.G) p.G = 1;
   p.ntiles = (int)((p.FB + SCAN_TILE - 1) / SCAN_TILE);
   return p;
 }
@@ -427,8 +458,13 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     uint32_t *tiles = cv.take<uint32_t>(p.ntiles + 1);
     unsigned long long *sorted = cv.take<unsigned long long>(p.total_max + 1);
     uint32_t *buckets = cv.take<uint32_t>((size_t)p.FB * 32);
-    std::vector<uint32_t *> rkey(p.G.size()), rpt(p.G.size());
-    for (size_t l = 0; l < p.G.size(); l++) { rkey[l] = cv.take<uint32_t>(p.S[l]); rpt[l] = cv.take<uint32_t>((size_t)p.S[l] * 32); }
+    uint32_t *rec_pt = cv.take<uint32_t>((size_t)p.G * 2 * 32);
+    // heavy buckets span > 9 lanes: at most G/9 of them, and at most G/256 + G/9 (bucket, chunk) items
+    size_t hmax = (size_t)(p.G / 8 + 2);
+    uint2 *heavy_items = cv.take<uint2>(hmax);
+    uint4 *heavy_buckets = cv.take<uint4>(hmax);
+    uint32_t *chunk_sums = cv.take<uint32_t>(hmax * 32);
+    uint32_t *heavy_count = cv.take<uint32_t>(4);
     uint32_t *red = cv.take<uint32_t>((size_t)p.NB * p.WPW * 64);
     uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * 32);
     uint32_t *out_aff = cv.take<uint32_t>((size_t)batch * 16);
@@ -454,28 +490,31 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     k_scan_apply<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles, start);
     k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, c, p.CH, p.W, blockhist, start, sorted);
     BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * 128, st));
+    BPPP_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     prof_mark(ctx, 2);
     // 3. accumulate
-    k_acc_points<<<dim3((unsigned)((p.G[0] + 255) / 256)), dim3(256), 0, st>>>(sorted, start + p.FB, (const uint32_t *)d_points, (uint32_t)n,
-                                                                              (uint32_t)(p.W * p.M), shared_points, p.G[0], buckets, rkey[0], rpt[0]);
-    for (size_t l = 1; l < p.G.size(); l++)
-      k_acc_records<<<dim3((unsigned)((p.G[l] + 255) / 256)), dim3(256), 0, st>>>(rkey[l - 1], rpt[l - 1], p.S[l - 1], p.G[l], buckets, rkey[l], rpt[l]);
+    k_acc_points<<<dim3((unsigned)((p.G + 255) / 256)), dim3(256), 0, st>>>(sorted, start + p.FB, (const uint32_t *)d_points, (uint32_t)n,
+                                                                           (uint32_t)(p.W * p.M), shared_points, p.L, p.G, buckets, rec_pt);
     prof_mark(ctx, 3);
+    k_merge<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(start, count, p.FB, p.L, rec_pt, buckets, heavy_items, heavy_buckets, heavy_count);
+    k_merge_heavy<<<dim3(2048), dim3(64), 0, st>>>(start, count, p.L, rec_pt, buckets, heavy_items, heavy_count, chunk_sums);
+    k_merge_heavy2<<<dim3(256), dim3(64), 0, st>>>(heavy_buckets, heavy_count, chunk_sums, buckets);
+    prof_mark(ctx, 4);
     // 4. bucket reduce
     k_reduce1<<<dim3((unsigned)p.NB, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
     k_reduce2<<<dim3((unsigned)p.NB), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
-    prof_mark(ctx, 4);
+    prof_mark(ctx, 5);
     // 5. window combine
     if (batch > 4) {
       k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.W, c, (uint32_t)batch, out_aff);
       BPPP_HIP(ctx, hipMemcpyAsync(out_xy, out_aff, batch * 64, hipMemcpyDeviceToHost, st));
-      prof_mark(ctx, 5);
+      prof_mark(ctx, 6);
       BPPP_HIP(ctx, hipStreamSynchronize(st));
     } else {
       size_t bytes = (size_t)p.NB * 128;
       int rc = ensure_pinned(ctx, bytes); if (rc) return rc;
       BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
-      prof_mark(ctx, 5);
+      prof_mark(ctx, 6);
       BPPP_HIP(ctx, hipStreamSynchronize(st));
       const uint64_t *ws = (const uint64_t *)ctx->pinned;
       for (size_t b = 0; b < batch; b++) {
@@ -490,7 +529,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
       }
     }
     BPPP_HIP(ctx, hipGetLastError());
-    prof_collect(ctx, 6);
+    prof_collect(ctx, 7);
   }
   return BPPP_OK;
 }

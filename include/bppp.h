@@ -109,6 +109,13 @@ int bppp_fold_scalars_device(bppp_ctx *ctx, const uint64_t u[4], const uint64_t 
 int bppp_tensor_device(bppp_ctx *ctx, const uint64_t *bs, size_t nb, const uint64_t *es, const uint64_t *qs,
                        size_t k, void *d_out);
 
+/* ---- harness utility: pointX of getPoints (app/Main.hs:68-72) -------------------------------
+ * For each candidate x (n x 4 uint64 in HBM) writes the affine point (x, y) with y the EVEN root of
+ * x^3 + 7, or the infinity encoding when x^3 + 7 is a non-residue or x >= p.  (Which root
+ * galois-field's `sr` returns cannot be confirmed offline — SURVEY.md 8c; even-y is this build's
+ * documented choice.)  Used to make synthetic bases on the GPU. */
+int bppp_lift_x_device(bppp_ctx *ctx, const void *d_x, size_t n, void *d_points_xy);
+
 /* ---- device memory helpers (so a non-HIP host language can keep vectors resident) ---------- */
 int bppp_device_alloc(bppp_ctx *ctx, size_t bytes, void **d_ptr);
 int bppp_device_free(bppp_ctx *ctx, void *d_ptr);
@@ -118,12 +125,13 @@ int bppp_download(bppp_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* ---- measurement hooks ---------------------------------------------------------------------
  * When enabled, each MSM call brackets its stages with hipEvents on the context's stream; the
  * accumulated per-stage milliseconds and launch counts can be read back (bench.py's roofline). */
-#define BPPP_STAGE_DIGITS 0
-#define BPPP_STAGE_SORT 1
-#define BPPP_STAGE_ACCUMULATE 2
-#define BPPP_STAGE_REDUCE 3
-#define BPPP_STAGE_FINISH 4
-#define BPPP_NUM_STAGES 5
+#define BPPP_STAGE_DIGITS 0      /* k_digits */
+#define BPPP_STAGE_SORT 1        /* k_hist .. k_scatter + bucket memset */
+#define BPPP_STAGE_ACC_POINTS 2  /* k_acc_points alone: the dominant kernel (roofline) */
+#define BPPP_STAGE_ACC_RECORDS 3 /* k_merge + k_merge_heavy (buckets that straddle lanes) */
+#define BPPP_STAGE_REDUCE 4      /* k_reduce1 + k_reduce2 */
+#define BPPP_STAGE_FINISH 5      /* window combine + copy-out */
+#define BPPP_NUM_STAGES 6
 int bppp_profile_enable(bppp_ctx *ctx, int on);
 int bppp_profile_read(bppp_ctx *ctx, double ms[BPPP_NUM_STAGES], uint64_t *calls, int reset);
 
