@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares; the host-only
+entry point (rationalReduceScalar) is exercised; device entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import bulletproofspp_amd as b
+from bulletproofspp_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bppp_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    for header in ("bppp.h", "bppp_test.h"):
+        names = _declared(header)
+        assert names, header
+        for name in names:
+            assert hasattr(lib, name), f"{name} declared in {header} but not exported"
+    assert sorted(capi.SYMBOLS) == _declared("bppp.h")
+    assert lib.bppp_version().startswith(b"bppp-hip")
+
+
+def test_rational_reduce_host_entry_point():
+    import pyoracle as O
+    lib = capi.load_library()
+    rnd = random.Random(1)
+    for x in [0, 1, O.N - 1, 2**128, (O.N + 1) // 2] + [rnd.randrange(O.N) for _ in range(300)]:
+        am, bm = np.zeros(3, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+        an, bn = C.c_int(0), C.c_int(0)
+        xs = capi.int_to_limbs(x)
+        assert lib.bppp_rational_reduce(xs.ctypes.data, am.ctypes.data, C.byref(an), bm.ctypes.data, C.byref(bn)) == 0
+        a = capi.limbs_to_int(am) * (-1 if an.value else 1)
+        bb = capi.limbs_to_int(bm) * (-1 if bn.value else 1)
+        assert (a, bb) == O.rational_reduce_scalar(x)
+    # not a canonical scalar -> argument error
+    bad = capi.int_to_limbs(O.N)
+    am, bm = np.zeros(3, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+    an, bn = C.c_int(0), C.c_int(0)
+    assert lib.bppp_rational_reduce(bad.ctypes.data, am.ctypes.data, C.byref(an), bm.ctypes.data, C.byref(bn)) == -1
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(b.BpppError):
+        b.Bppp(0)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under bulletproofspp_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "bulletproofspp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "lib" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "bppp_oracle" not in txt and "orc_" not in txt, f

@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: two gloo ranks shard one MSM by terms, all-gather one partial point each and add
+them locally (bulletproofspp_amd/dist.py).  On the GPU box the same code runs with backend nccl (RCCL);
+here the per-rank MSM and the point sum are the oracle's, so only the sharding / collective logic is under test."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import pyoracle as O
+    from bulletproofspp_amd import dist as bd
+    from bulletproofspp_amd.capi import points_to_array, array_to_point
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ec = O.CEC()
+    rnd = random.Random(42)
+    pts = O.hash_points(b"gloo", n)
+    sc = [rnd.randrange(O.N) for _ in range(n)]
+
+    def local_msm(lo, hi):
+        return points_to_array([ec.inner_product(list(zip(sc[lo:hi], pts[lo:hi])))])[0]
+
+    def sum_points(allp):
+        acc = None
+        for r in range(allp.shape[0]):
+            acc = ec.add(acc, array_to_point(allp[r]))
+        return points_to_array([acc])[0]
+
+    total = bd.sharded_msm(n, rank, world, local_msm, sum_points, dist)
+    want = ec.inner_product(list(zip(sc, pts)))
+    q.put((rank, array_to_point(total) == want, bd.shard_range(n, rank, world)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 64])
+def test_sharded_msm_world2_gloo(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+    (lo0, hi0), (lo1, hi1) = res[0][2], res[1][2]
+    assert lo0 == 0 and hi0 == lo1 and hi1 == n
+
+
+def test_shard_ranges_partition():
+    from bulletproofspp_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1 << 20, 344838):
+        for world in (1, 2, 4, 8):
+            rs = [shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
