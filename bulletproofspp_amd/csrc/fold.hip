@@ -37,24 +37,26 @@ __global__ void __launch_bounds__(64) k_fold_points(const uint32_t *__restrict__
 __global__ void __launch_bounds__(64) k_lift_x(const uint32_t *__restrict__ xs, uint32_t n, uint32_t *__restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe x = fe_load(xs + (size_t)i * 8);
+  fe xe = fe_load(xs + (size_t)i * 8);
   fe t;
-  bool ok = raw_sub(t, x, fp_modulus()) != 0;      // x < p
-  fe seven = fe_zero(); seven.v[0] = 7;
-  fe rhs = FPA(FPM(FPS(x), x), seven);
-  // exponent (p+1)/4 = 0x3FFFFFFF FFFFFFFF ... BFFFFF0C
+  bool ok = raw_sub(t, xe, fp_modulus()) != 0;      // x < p
+  fq x = fq_from_fe(xe);
+  fq seven = fq_zero(); seven.n[0] = 7;
+  fq rhs = fq_add(fq_mul(fq_sqr(x), x), seven);     // magnitude 2
+  // exponent (p+1)/4
   fe e = fp_modulus();
   e.v[0] += 1;                                      // p + 1 (low limb 0xFFFFFC2F + 1, no carry)
 #pragma unroll
   for (int k = 0; k < 8; k++) e.v[k] = (e.v[k] >> 2) | (k < 7 ? e.v[k + 1] << 30 : 0u);
-  fe acc = fe_one(), base = rhs;
+  fq acc = fq_one(), base = rhs;
   for (int b = 0; b < 254; b++) {
-    if ((e.v[b >> 5] >> (b & 31)) & 1u) acc = FPM(acc, base);
-    base = FPS(base);
+    if ((e.v[b >> 5] >> (b & 31)) & 1u) acc = fq_mul(acc, base);
+    base = fq_sqr(base);
   }
-  ok = ok && fe_eq(FPS(acc), rhs);
-  if (acc.v[0] & 1u) acc = fe_neg<0>(acc);
-  aff r; r.x = x; r.y = acc;
+  ok = ok && fq_normalizes_to_zero(fq_sub<2>(fq_sqr(acc), rhs));
+  fq y = fq_normalize(acc);
+  if (y.n[0] & 1u) y = fq_normalize(fq_neg<1>(y));
+  aff r; r.x = x; r.y = y;
   if (!ok) r = aff_inf();
   aff_store(out + (size_t)i * 16, r);
 }

@@ -95,6 +95,14 @@ inline U256 minv(const U256 &a, const Mod &M) {  // 0 -> 0 (BatchInverse.hs:18,2
   return mpow(a, e, M);
 }
 
+// a lazily-reduced device value: 10 limbs of radix 2^26 (csrc/fq26.cuh), any magnitude -> canonical mod p
+inline U256 from_limbs26(const uint32_t *n) {
+  const Mod &M = FQ();
+  U256 acc = U256::zero(), radix = U256::from_u64(1ull << 26);
+  for (int i = 9; i >= 0; i--) acc = madd(mmul(acc, radix, M), U256::from_u64(n[i]), M);
+  return acc;
+}
+
 // ---- curve, Jacobian on the host (only for the <= 33-point window combine and group glue)
 struct HAff { U256 x, y; bool inf() const { return x.is_zero() && y.is_zero(); } };
 struct HJac { U256 X, Y, Z; bool inf() const { return Z.is_zero(); } };

@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__
     unsigned long long e_next = (p + 1 < pos1) ? sorted[p + 1] : 0ull;
     if (k != cur) {
       // the finished run ends inside this lane: head partial if it came from the previous lane, else complete
-      if (first && cur == prev_key) xyzz_store(rec_pt + (2 * g) * 32, acc);
-      else xyzz_store(buckets + (size_t)cur * 32, acc);
+      if (first && cur == prev_key) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
+      else xyzz_store(buckets + (size_t)cur * XYZZ_WORDS, acc);
       first = false; cur = k; acc = xyzz_inf();
     }
     size_t pidx = shared_pts ? (size_t)idx : (size_t)(k / WM) * n + idx;
@@ -221,9 +221,9 @@ __global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__
     e = e_next;
   }
   bool hi = first && cur == prev_key, ti = cur == next_key;
-  if (hi) xyzz_store(rec_pt + (2 * g) * 32, acc);
-  else if (ti) xyzz_store(rec_pt + (2 * g + 1) * 32, acc);
-  else xyzz_store(buckets + (size_t)cur * 32, acc);
+  if (hi) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
+  else if (ti) xyzz_store(rec_pt + (2 * g + 1) * XYZZ_WORDS, acc);
+  else xyzz_store(buckets + (size_t)cur * XYZZ_WORDS, acc);
 }
 
 static constexpr int MERGE_SERIAL_MAX = 8;   // longer spans go to the wavefront-cooperative kernels
@@ -231,7 +231,7 @@ static constexpr int HEAVY_CHUNK = 256;      // partial sums per wavefront in k_
 
 // partial t of a bucket whose first lane is g0: t = 0 is g0's tail slot, t >= 1 the head slot of lane g0+t
 BPPP_DI const uint32_t *partial_ptr(const uint32_t *rec_pt, uint64_t g0, uint64_t t) {
-  return rec_pt + (t == 0 ? 2 * g0 + 1 : 2 * (g0 + t)) * 32;
+  return rec_pt + (t == 0 ? 2 * g0 + 1 : 2 * (g0 + t)) * XYZZ_WORDS;
 }
 
 __global__ void __launch_bounds__(256) k_merge(const uint32_t *__restrict__ start, const uint32_t *__restrict__ count, uint64_t FB, int L,
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) k_merge(const uint32_t *__restrict__ star
     xyzz p = xyzz_load(partial_ptr(rec_pt, g0, t));
     xyzz_add(acc, p);
   }
-  xyzz_store(buckets + fb * 32, acc);
+  xyzz_store(buckets + fb * XYZZ_WORDS, acc);
 }
 
 // one wavefront per (heavy bucket, chunk): lanes stride over the chunk's partials, then a shuffle tree
@@ -283,8 +283,8 @@ __global__ void __launch_bounds__(64) k_merge_heavy(const uint32_t *__restrict__
       if ((int)lane + d < 64) xyzz_add(acc, o);
     }
     if (lane == 0) {
-      if (np <= HEAVY_CHUNK) xyzz_store(buckets + (size_t)fb * 32, acc);
-      else xyzz_store(chunk_sums + (size_t)h * 32, acc);
+      if (np <= HEAVY_CHUNK) xyzz_store(buckets + (size_t)fb * XYZZ_WORDS, acc);
+      else xyzz_store(chunk_sums + (size_t)h * XYZZ_WORDS, acc);
     }
   }
 }
@@ -296,14 +296,14 @@ __global__ void __launch_bounds__(64) k_merge_heavy2(const uint4 *__restrict__ h
     uint4 hb = heavy_buckets[h];
     xyzz acc = xyzz_inf();
     for (uint32_t j = lane; j < hb.z; j += 64) {
-      xyzz p = xyzz_load(chunk_sums + (size_t)(hb.y + j) * 32);
+      xyzz p = xyzz_load(chunk_sums + (size_t)(hb.y + j) * XYZZ_WORDS);
       xyzz_add(acc, p);
     }
     for (int d = 32; d >= 1; d >>= 1) {
       xyzz o = xyzz_shfl_down(acc, d);
       if ((int)lane + d < 64) xyzz_add(acc, o);
     }
-    if (lane == 0) xyzz_store(buckets + (size_t)hb.x * 32, acc);
+    if (lane == 0) xyzz_store(buckets + (size_t)hb.x * XYZZ_WORDS, acc);
   }
 }
 
@@ -315,9 +315,9 @@ __global__ void __launch_bounds__(64) k_reduce1(const uint32_t *__restrict__ buc
   uint32_t t = wave * 64 + lane;                 // lane index within the window
   xyzz run = xyzz_inf(), acc = xyzz_inf();
   if ((uint64_t)t * Lw < (uint64_t)M) {
-    const uint32_t *b = buckets + ((size_t)nbw * M + (size_t)t * Lw) * 32;
+    const uint32_t *b = buckets + ((size_t)nbw * M + (size_t)t * Lw) * XYZZ_WORDS;
     for (int k = Lw - 1; k >= 0; k--) {          // running sum from the top: acc = sum (k+1) * B_k
-      xyzz B = xyzz_load(b + (size_t)k * 32);
+      xyzz B = xyzz_load(b + (size_t)k * XYZZ_WORDS);
       xyzz_add(run, B);
       xyzz_add(acc, run);
     }
@@ -337,9 +337,9 @@ __global__ void __launch_bounds__(64) k_reduce1(const uint32_t *__restrict__ buc
     if ((int)lane + d < 64) xyzz_add(v, o);
   }
   if (lane == 0) {
-    uint32_t *o = red + ((size_t)nbw * WPW + wave) * 64;
+    uint32_t *o = red + ((size_t)nbw * WPW + wave) * (2 * XYZZ_WORDS);
     xyzz_store(o, v);          // A_wave
-    xyzz_store(o + 32, suf);   // S_wave (lane 0's inclusive suffix = whole-wave sum)
+    xyzz_store(o + XYZZ_WORDS, suf);   // S_wave (lane 0's inclusive suffix = whole-wave sum)
   }
 }
 // across the wavefronts of a window: total = sum_j A_j + (64*Lw) * sum_{j>=1} suffix_j(S)
@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(64) k_reduce2(const uint32_t *__restrict__ red
   const uint32_t nbw = blockIdx.x, lane = threadIdx.x;
   xyzz A = xyzz_inf(), S = xyzz_inf();
   if ((int)lane < WPW) {
-    const uint32_t *r = red + ((size_t)nbw * WPW + lane) * 64;
-    A = xyzz_load(r); S = xyzz_load(r + 32);
+    const uint32_t *r = red + ((size_t)nbw * WPW + lane) * (2 * XYZZ_WORDS);
+    A = xyzz_load(r); S = xyzz_load(r + XYZZ_WORDS);
   }
   xyzz suf = S;
   for (int d = 1; d < 64; d <<= 1) {
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64) k_reduce2(const uint32_t *__restrict__ red
     xyzz o = xyzz_shfl_down(v, d);
     if ((int)lane + d < 64) xyzz_add(v, o);
   }
-  if (lane == 0) xyzz_store(winsum + (size_t)nbw * 32, v);
+  if (lane == 0) xyzz_store(winsum + (size_t)nbw * XYZZ_WORDS, v);
 }
 
 // 5. batched window combine: one lane per MSM instance
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restric
   xyzz r = xyzz_inf();
   for (int w = W - 1; w >= 0; w--) {
     for (int k = 0; k < c; k++) r = xyzz_dbl(r);
-    xyzz t = xyzz_load(winsum + ((size_t)b * W + w) * 32);
+    xyzz t = xyzz_load(winsum + ((size_t)b * W + w) * XYZZ_WORDS);
     xyzz_add(r, t);
   }
   aff_store(out_aff + (size_t)b * 16, xyzz_to_aff(r));
@@ -457,16 +457,16 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     uint32_t *start = cv.take<uint32_t>(p.FB + 1);
     uint32_t *tiles = cv.take<uint32_t>(p.ntiles + 1);
     unsigned long long *sorted = cv.take<unsigned long long>(p.total_max + 1);
-    uint32_t *buckets = cv.take<uint32_t>((size_t)p.FB * 32);
-    uint32_t *rec_pt = cv.take<uint32_t>((size_t)p.G * 2 * 32);
+    uint32_t *buckets = cv.take<uint32_t>((size_t)p.FB * XYZZ_WORDS);
+    uint32_t *rec_pt = cv.take<uint32_t>((size_t)p.G * 2 * XYZZ_WORDS);
     // heavy buckets span > 9 lanes: at most G/9 of them, and at most G/256 + G/9 (bucket, chunk) items
     size_t hmax = (size_t)(p.G / 8 + 2);
     uint2 *heavy_items = cv.take<uint2>(hmax);
     uint4 *heavy_buckets = cv.take<uint4>(hmax);
-    uint32_t *chunk_sums = cv.take<uint32_t>(hmax * 32);
+    uint32_t *chunk_sums = cv.take<uint32_t>(hmax * XYZZ_WORDS);
     uint32_t *heavy_count = cv.take<uint32_t>(4);
-    uint32_t *red = cv.take<uint32_t>((size_t)p.NB * p.WPW * 64);
-    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * 32);
+    uint32_t *red = cv.take<uint32_t>((size_t)p.NB * p.WPW * 2 * XYZZ_WORDS);
+    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * XYZZ_WORDS);
     uint32_t *out_aff = cv.take<uint32_t>((size_t)batch * 16);
     if (!pass) { need = cv.off; int rc = ensure_workspace(ctx, need); if (rc) return rc; continue; }
 
@@ -489,7 +489,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     k_scan_top<<<dim3(1), dim3(1024), 0, st>>>(tiles, (uint32_t)p.ntiles, start + p.FB);
     k_scan_apply<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles, start);
     k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, c, p.CH, p.W, blockhist, start, sorted);
-    BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * 128, st));
+    BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * XYZZ_WORDS * 4, st));
     BPPP_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     prof_mark(ctx, 2);
     // 3. accumulate
@@ -511,18 +511,18 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
       prof_mark(ctx, 6);
       BPPP_HIP(ctx, hipStreamSynchronize(st));
     } else {
-      size_t bytes = (size_t)p.NB * 128;
+      size_t bytes = (size_t)p.NB * XYZZ_WORDS * 4;
       int rc = ensure_pinned(ctx, bytes); if (rc) return rc;
       BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
       prof_mark(ctx, 6);
       BPPP_HIP(ctx, hipStreamSynchronize(st));
-      const uint64_t *ws = (const uint64_t *)ctx->pinned;
+      const uint32_t *ws = (const uint32_t *)ctx->pinned;
       for (size_t b = 0; b < batch; b++) {
         HJac r = hj_inf();
         for (int w = p.W - 1; w >= 0; w--) {
           for (int k = 0; k < c; k++) r = hj_dbl(r);
-          const uint64_t *q = ws + ((size_t)b * p.W + w) * 16;
-          r = hj_add(r, hj_from_xyzz(U256::load(q), U256::load(q + 4), U256::load(q + 8), U256::load(q + 12)));
+          const uint32_t *q = ws + ((size_t)b * p.W + w) * XYZZ_WORDS;
+          r = hj_add(r, hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)));
         }
         HAff a = hj_to_aff(r);
         a.x.store(out_xy + 8 * b); a.y.store(out_xy + 8 * b + 4);

@@ -14,11 +14,33 @@ template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
     default: return fe_neg<MOD>(a);
   }
 }
+// Fq through the production representation (10 x 26-bit limbs, csrc/fq26.cuh)
+BPPP_DI fe apply_op_fq(int op, const fe &a, const fe &b) {
+  fq x = fq_from_fe(a), y = fq_from_fe(b);
+  switch (op) {
+    case BPPP_FE_ADD: return fq_to_fe(fq_add(x, y));
+    case BPPP_FE_SUB: return fq_to_fe(fq_sub<1>(x, y));
+    case BPPP_FE_MUL: return fq_to_fe(fq_mul(x, y));
+    case BPPP_FE_SQR: return fq_to_fe(fq_sqr(x));
+    case BPPP_FE_INV: return fq_to_fe(fq_inv(x));
+    default: return fq_to_fe(fq_neg<1>(x));
+  }
+}
+// worst-case magnitudes: (8a) * (8b) with both operands built by repeated lazy additions
+BPPP_DI fe apply_mag8_mul(const fe &a, const fe &b) {
+  fq x = fq_from_fe(a), y = fq_from_fe(b);
+  fq x8 = fq_mul_int(x, 8), y8 = fq_neg<7>(fq_mul_int(y, 7));   // magnitudes 8 and 8
+  return fq_to_fe(fq_mul(x8, y8));                               // = -56 a b
+}
 __global__ void k_test_fe(int op, int mod, const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t *out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe x = fe_load(a + (size_t)i * 8), y = fe_load(b + (size_t)i * 8);
-  fe r = mod ? apply_op<1>(op, x, y) : apply_op<0>(op, x, y);
+  fe r;
+  if (mod == 1) r = apply_op<1>(op, x, y);            // Fr, 8 x 32
+  else if (mod == 2) r = apply_op<0>(op, x, y);       // Fq, legacy 8 x 32 code path (cross-check)
+  else if (op == 6) r = apply_mag8_mul(x, y);
+  else r = apply_op_fq(op, x, y);                     // Fq, production 10 x 26
   fe_store(out + (size_t)i * 8, r);
 }
 __global__ void k_test_point(int op, const uint32_t *p, const uint32_t *q, uint32_t n, uint32_t *out) {

@@ -10,7 +10,8 @@ from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_
 
 pytestmark = pytest.mark.gpu
 
-OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5}
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5, "mag8mul": 6}
+# modulus selector of bppp_test_fe_op: 0 = Fq via the production 10x26 limbs, 1 = Fr (8x32), 2 = Fq via the 8x32 code path
 
 
 def _fe_op(gpu, op, mod, a, b):
@@ -28,7 +29,7 @@ def _edge_values(m):
             0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF, m - 2**32, m - 977, 3**160 % m, 2**224 - 1]
 
 
-@pytest.mark.parametrize("mod,m", [(0, O.P), (1, O.N)])
+@pytest.mark.parametrize("mod,m", [(0, O.P), (1, O.N), (2, O.P)])
 def test_field_ops_match_python(gpu, mod, m):
     rnd = random.Random(11 + mod)
     edge = _edge_values(m)
@@ -41,6 +42,16 @@ def test_field_ops_match_python(gpu, mod, m):
     assert _fe_op(gpu, "neg", mod, a, b) == [(-x) % m for x in a]
     small = a[:300]
     assert _fe_op(gpu, "inv", mod, small, small) == [O.inv_mod(x, m) for x in small]
+
+
+def test_fq26_worst_case_magnitudes(gpu):
+    """lazy reduction: (8a) * (-7b + 8p') with every limb near its magnitude-8 bound must still be exact"""
+    rnd = random.Random(5)
+    edge = _edge_values(O.P) + [O.P - 1] * 4 + [2**256 - 2**32 - 978, 2**255, (1 << 256) - 1 - 2**32 - 977 - 1]
+    edge = [e % O.P for e in edge]
+    a = edge + [rnd.randrange(O.P) for _ in range(3000)] + [e for e in edge for _ in edge]
+    b = edge[::-1] + [rnd.randrange(O.P) for _ in range(3000)] + [f for _ in edge for f in edge]
+    assert _fe_op(gpu, "mag8mul", 0, a, b) == [(-56 * x * y) % O.P for x, y in zip(a, b)]
 
 
 def test_reference_constant_3_pow_160(gpu):
