@@ -412,6 +412,7 @@ static MsmPlan make_plan(size_t n, size_t batch, int c) {
     while (p.M / p.Lw > 64 * 64) p.Lw <<= 1;     // cap at 4096 lanes per window
     if (p.M / p.Lw >= 1024 && p.Lw < 4) p.Lw = std::min(4, p.M / 1024);  // amortise the wave scan
     if (p.Lw < 1) p.Lw = 1;
+    if (const char *e = getenv("BPPP_LW")) { int v = atoi(e); if (v >= 1 && (v & (v - 1)) == 0 && p.M / v >= 64 && p.M / v <= 4096) p.Lw = v; }
     p.WPW = p.M / p.Lw / 64;
     if (p.WPW < 1) p.WPW = 1;
   }
