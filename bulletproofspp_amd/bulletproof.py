@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference's Bulletproof interface for the norm-linear argument, over the C ABI.
+
+Names follow the reference (src/Bulletproof.hs, src/Bulletproof/NormArgument.hs) so the parity tests read like
+the reference's own call sites: makeNormLinearBP / makeScalarsComs / collapse / getWitness / proveRoundM /
+proveBPM / verifyBPM.  The vectors and bases live in HBM (`bppp_nl`); the injected oracle (src/ZKP.hs:73-77)
+runs on the host, exactly one call per round."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .capi import (Bppp, BpppError, _ptr, array_to_point, array_to_scalars, int_to_limbs, limbs_to_int, points_to_array,
+                   scalars_to_array)
+
+N_ORDER = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+Point = Optional[Tuple[int, int]]
+
+
+class NormLinearBP:
+    """PedersenScalarVector (NormLinear []) on the device: scalar s on g + norm (x, G) + linear (c, x, H)."""
+
+    def __init__(self, gpu: Bppp, s: int, g: Point, q: int, cs: Sequence[int], nss: Sequence[int], ngs: Sequence[Point],
+                 lss: Sequence[int], lgs: Sequence[Point]):
+        # zipWithDef'' padding of makeNorm / makeLinear (NormArgument.hs:47-48, :98-99): shorter side padded with 0 / zeroV
+        nlen, llen = max(len(nss), len(ngs)), max(len(cs), len(lss), len(lgs))
+        pad = lambda xs, n, z: list(xs) + [z] * (n - len(xs))
+        self.gpu, self.g = gpu, g
+        h = C.c_void_p()
+        rc = gpu.lib.bppp_nl_create(gpu.h, _ptr(int_to_limbs(s % N_ORDER)), _ptr(points_to_array([g])), _ptr(int_to_limbs(q % N_ORDER)),
+                                    _ptr(scalars_to_array(pad(nss, nlen, 0))), _ptr(points_to_array(pad(ngs, nlen, None))), nlen,
+                                    _ptr(scalars_to_array(pad(cs, llen, 0))), _ptr(scalars_to_array(pad(lss, llen, 0))),
+                                    _ptr(points_to_array(pad(lgs, llen, None))), llen, C.byref(h))
+        gpu._check(rc, "bppp_nl_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.gpu.lib.bppp_nl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lengths(self) -> Tuple[int, int]:
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.gpu._check(self.gpu.lib.bppp_nl_lengths(self.h, C.byref(a), C.byref(b)), "bppp_nl_lengths")
+        return int(a.value), int(b.value)
+
+    def makeScalarsComs(self) -> Tuple[int, Point, int, Point]:
+        """(sX, commit(sX·g + X-opening), sR, commit(sR·g + R-opening))  — Bulletproof.hs:348-350"""
+        sX, sR = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        X, R = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_nl_round_commit(self.h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nl_round_commit")
+        return limbs_to_int(sX), array_to_point(X), limbs_to_int(sR), array_to_point(R)
+
+    def collapse(self, e: int):
+        self.gpu._check(self.gpu.lib.bppp_nl_round_collapse(self.h, _ptr(int_to_limbs(e % N_ORDER))), "bppp_nl_round_collapse")
+
+    def getWitness(self) -> Tuple[List[int], List[int]]:
+        n, l = self.lengths()
+        nw, lw = np.zeros((max(n, 1), 4), dtype=np.uint64), np.zeros((max(l, 1), 4), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_nl_get_witness(self.h, _ptr(nw), _ptr(lw)), "bppp_nl_get_witness")
+        return array_to_scalars(nw)[:n], array_to_scalars(lw)[:l]
+
+    def download(self) -> dict:
+        n, l = self.lengths()
+        nx, lc, lx = (np.zeros((max(k, 1), 4), dtype=np.uint64) for k in (n, l, l))
+        ng, lh = np.zeros((max(n, 1), 8), dtype=np.uint64), np.zeros((max(l, 1), 8), dtype=np.uint64)
+        s, q, nn, ln = (np.zeros(4, dtype=np.uint64) for _ in range(4))
+        self.gpu._check(self.gpu.lib.bppp_nl_download(self.h, _ptr(nx), _ptr(ng), _ptr(lc), _ptr(lx), _ptr(lh), _ptr(s), _ptr(q), _ptr(nn), _ptr(ln)),
+                        "bppp_nl_download")
+        return {"norm_x": array_to_scalars(nx)[:n], "norm_g": [array_to_point(ng[i]) for i in range(n)], "lin_c": array_to_scalars(lc)[:l],
+                "lin_x": array_to_scalars(lx)[:l], "lin_h": [array_to_point(lh[i]) for i in range(l)], "s": limbs_to_int(s), "q": limbs_to_int(q),
+                "norm_n": limbs_to_int(nn), "lin_n": limbs_to_int(ln)}
+
+
+OracleFn = Callable[[List[Point]], int]
+
+
+def proveRoundM(com: NormLinearBP, oracle: OracleFn) -> Tuple[Tuple[Point, Point], int]:
+    """src/Bulletproof.hs:346-355: commit X and R on the GPU, hash on the host, collapse on the GPU."""
+    _, ac, _, bc = com.makeScalarsComs()
+    e = oracle([ac, bc]) % N_ORDER
+    com.collapse(e)
+    return (ac, bc), e
+
+
+def proveBPM(n_rounds: int, com: NormLinearBP, oracle: OracleFn):
+    """src/Bulletproof.hs:357-359: responses (and the challenges) come out LAST ROUND FIRST."""
+    resps, es = [], []
+    for _ in range(n_rounds):
+        r, e = proveRoundM(com, oracle)
+        resps.insert(0, r)
+        es.insert(0, e)
+    return resps, es
+
+
+def verifyBPM(gpu: Bppp, q: int, sp: int, g: Point, pub_norm: Sequence[int], ngs: Sequence[Point], pub_lin_c: Sequence[int],
+              pub_lin_x: Sequence[int], lgs: Sequence[Point], es: Sequence[int], responses: Sequence[Tuple[Point, Point]],
+              wit_norm: Sequence[int], wit_lin: Sequence[int], init_terms: Sequence[Tuple[int, Point]]) -> bool:
+    """src/Bulletproof.hs:370-378 with the challenges already derived (es, last round first): zeroV == commit(...)"""
+    k = len(es)
+    assert len(responses) == k
+    out = np.zeros(8, dtype=np.uint64)
+    flat = [p for xr in responses for p in xr]
+    rc = gpu.lib.bppp_nl_verify(
+        gpu.h, _ptr(int_to_limbs(q % N_ORDER)), _ptr(int_to_limbs(sp % N_ORDER)), _ptr(points_to_array([g])),
+        _ptr(scalars_to_array(pub_norm)) if len(pub_norm) else None, _ptr(points_to_array(ngs)) if len(ngs) else None, len(ngs),
+        _ptr(scalars_to_array(pub_lin_c)) if len(lgs) else None, _ptr(scalars_to_array(pub_lin_x)) if len(lgs) else None,
+        _ptr(points_to_array(lgs)) if len(lgs) else None, len(lgs),
+        _ptr(scalars_to_array(es)) if k else None, k, _ptr(scalars_to_array(wit_norm)) if len(wit_norm) else None, len(wit_norm),
+        _ptr(scalars_to_array(wit_lin)) if len(wit_lin) else None, len(wit_lin),
+        _ptr(scalars_to_array([s for s, _ in init_terms])) if init_terms else None,
+        _ptr(points_to_array([p for _, p in init_terms])) if init_terms else None, len(init_terms),
+        _ptr(points_to_array(flat)) if k else None, _ptr(out))
+    gpu._check(rc, "bppp_nl_verify")
+    return array_to_point(out) is None

@@ -109,6 +109,40 @@ int bppp_fold_scalars_device(bppp_ctx *ctx, const uint64_t u[4], const uint64_t 
 int bppp_tensor_device(bppp_ctx *ctx, const uint64_t *bs, size_t nb, const uint64_t *es, const uint64_t *qs,
                        size_t k, void *d_out);
 
+/* ---- a10-a14: the norm-linear argument with device-resident state (BPOpening / BPCollection) ---
+ * `bppp_nl` is the device counterpart of `PedersenScalarVector (NormLinear f) v s`
+ * (src/Commitment.hs:487-501, src/Bulletproof/NormArgument.hs:153-162): the norm vector x with basis G,
+ * the linear vector (c, x) with basis H, the scalar s on g, and the deferred normalisations
+ * (BPFrame''.nrmlz'', src/Bulletproof.hs:167).  The Fiat-Shamir oracle stays with the caller
+ * (injected in the reference too, src/ZKP.hs:73-77). */
+typedef struct bppp_nl bppp_nl;
+/* makeNormLinearBP' 1 q cs nss ngs lss lgs (NormArgument.hs:162) inside makePSV s g (Commitment.hs:490-491) */
+int bppp_nl_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], const uint64_t q[4], const uint64_t *norm_x,
+                   const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy,
+                   size_t llen, bppp_nl **out);
+void bppp_nl_destroy(bppp_nl *nl);
+int bppp_nl_lengths(const bppp_nl *nl, size_t *nlen, size_t *llen);
+/* first half of proveRoundM (src/Bulletproof.hs:346-350): makeScalarsComs (NormArgument.hs:113-118, :56-59,
+ * Bulletproof.hs:258-261) and ac = commit(sX, X-opening), bc = commit(sR, R-opening) as one batched MSM. */
+int bppp_nl_round_commit(bppp_nl *nl, uint64_t sX[4], uint64_t X_xy[8], uint64_t sR[4], uint64_t R_xy[8]);
+/* second half of proveRoundM (Bulletproof.hs:352-354): (e0, e1) = makeEs e = (e, e^2 - 1); s += e0 sX + e1 sR;
+ * collapse e (NormArgument.hs:123-129, :64-71): scalar folds, basis folds by collapsePoints, q <- q^2. */
+int bppp_nl_round_collapse(bppp_nl *nl, const uint64_t e[4]);
+/* getWitness (NormArgument.hs:121, :62; Bulletproof.hs:264): normalisation applied; lengths from bppp_nl_lengths */
+int bppp_nl_get_witness(bppp_nl *nl, uint64_t *norm_w, uint64_t *lin_w);
+/* raw current state (vectors NOT multiplied by the normalisations) for parity checks; any pointer may be NULL */
+int bppp_nl_download(bppp_nl *nl, uint64_t *norm_x, uint64_t *norm_g_xy, uint64_t *lin_c, uint64_t *lin_x, uint64_t *lin_h_xy,
+                     uint64_t s[4], uint64_t q[4], uint64_t norm_nrmlz[4], uint64_t lin_nrmlz[4]);
+/* verifyBPM (src/Bulletproof.hs:370-378) after the challenges are known: expandChallenges
+ * (NormArgument.hs:73-81, :131-145; Bulletproof.hs:268-269) on the device, then the single commit over
+ * verifyWith's term list (Bulletproof.hs:362-368): wit' ++ initCom ++ [e0 X_j, e1 R_j].  `es` and
+ * `responses_xy` (k pairs X, R) are LAST ROUND FIRST as the reference holds them (Bulletproof.hs:359, :374).
+ * out_xy is the committed point; the proof verifies iff it is infinity (all zero). */
+int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q[4], const uint64_t sp[4], const uint64_t g_xy[8], const uint64_t *pub_norm,
+                   const uint64_t *norm_g_xy, size_t nlen, const uint64_t *pub_lin_c, const uint64_t *pub_lin_x, const uint64_t *lin_h_xy,
+                   size_t llen, const uint64_t *es, size_t k, const uint64_t *wit_norm, size_t fn, const uint64_t *wit_lin, size_t fl,
+                   const uint64_t *init_scalars, const uint64_t *init_points_xy, size_t ninit, const uint64_t *responses_xy, uint64_t out_xy[8]);
+
 /* ---- harness utility: pointX of getPoints (app/Main.hs:68-72) -------------------------------
  * For each candidate x (n x 4 uint64 in HBM) writes the affine point (x, y) with y the EVEN root of
  * x^3 + 7, or the infinity encoding when x^3 + 7 is a non-residue or x >= p.  (Which root

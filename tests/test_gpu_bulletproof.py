@@ -1,0 +1,121 @@
+"""proveBPM / verifyBPM with device-resident vectors (bppp_nl_*) vs the oracle's restatement of
+src/Bulletproof.hs:346-378 and src/Bulletproof/NormArgument.hs, round by round: bit-exact scalars and points."""
+import json
+import os
+import random
+
+import pytest
+
+import pyoracle as O
+from bulletproofspp_amd.bulletproof import NormLinearBP, proveBPM, verifyBPM
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+pt = lambda v: None if v is None else (int(v[0], 16), int(v[1], 16))
+
+
+def test_golden_transcript_round_by_round(gpu):
+    d = json.load(open(os.path.join(G, "bp_transcript.json")))
+    h = lambda k: [int(v, 16) for v in d[k]]
+    gs, hs = [pt(p) for p in d["gs"]], [pt(p) for p in d["hs"]]
+    com = NormLinearBP(gpu, int(d["s"], 16), pt(d["g"]), int(d["q"], 16), h("cs"), h("xs"), gs, h("ls"), hs)
+    for r in d["rounds"]:
+        sX, X, sR, R = com.makeScalarsComs()
+        assert (hex(sX), hex(sR)) == (r["sX"], r["sR"])
+        assert X == pt(r["X"]) and R == pt(r["R"])
+        com.collapse(int(r["e"], 16))
+        st = com.download()
+        assert [hex(v) for v in st["norm_x"]] == r["norm_x"] and st["norm_g"] == [pt(p) for p in r["norm_g"]]
+        assert [hex(v) for v in st["lin_c"]] == r["lin_c"] and [hex(v) for v in st["lin_x"]] == r["lin_x"]
+        assert st["lin_h"] == [pt(p) for p in r["lin_h"]]
+        assert hex(st["s"]) == r["s_next"] and hex(st["norm_n"]) == r["norm_n"] and hex(st["norm_q"] if "norm_q" in st else st["q"]) == r["norm_q"]
+        assert hex(st["lin_n"]) == r["lin_n"]
+    nw, lw = com.getWitness()
+    assert [hex(v) for v in nw] == d["final_norm_witness"] and [hex(v) for v in lw] == d["final_lin_witness"]
+    com.close()
+
+
+def _instance(nl, ll, seed):
+    rnd = random.Random(seed)
+    g, *rest = O.hash_points(b"gpubp%d" % seed, 1 + nl + ll)
+    return g, rest[:nl], rest[nl:], [rnd.randrange(O.N) for _ in range(nl)], [rnd.randrange(O.N) for _ in range(ll)], \
+        [rnd.randrange(O.N) for _ in range(ll)], rnd.randrange(1, O.N)
+
+
+@pytest.mark.parametrize("nl,ll", [(5, 1), (8, 5), (7, 3), (33, 6), (64, 7), (1, 1), (0, 6), (9, 0)])
+def test_prove_on_gpu_equals_oracle_and_verifies(gpu, oracle_lib, nl, ll):
+    g, gs, hs, xs, ls, cs, q = _instance(nl, ll, 31 * nl + ll)
+    body = O.NormLinear.make(1, q, cs, xs, gs, ls, hs)
+    wit = O.PSV(body.eval_scalar(), g, body)
+    C = O.commit(wit.open_terms(), oracle_lib)
+    rounds, (fn, fl) = O.optimal_witness_size_nl(nl, ll)
+    rounds = max(rounds, 1)
+    fin, resps_o, es_o = O.prove_bp(rounds, wit, O.Transcript(O.sha_oracle_fn()), oracle_lib)
+    # GPU prover with the same injected oracle
+    com = NormLinearBP(gpu, wit.sc, g, q, cs, xs, gs, ls, hs)
+    tr = O.Transcript(O.sha_oracle_fn())
+    resps, es = proveBPM(rounds, com, tr.oracle)
+    assert resps == resps_o and es == es_o
+    nw, lw = com.getWitness()
+    assert nw == fin.body.norm.get_witness() and lw == fin.body.lin.get_witness()
+    assert com.download()["s"] == fin.sc
+    com.close()
+    # GPU verifier: expandChallenges + the single MSM
+    zeros_n, zeros_l = [0] * nl, [0] * ll
+    ok = verifyBPM(gpu, q, 0, g, zeros_n, gs, cs, zeros_l, hs, es, resps, nw, lw, [(1, C)])
+    assert ok
+    # the verifier's term list equals the oracle's (scalars bit-for-bit), checked through the result of a perturbed run
+    if nw:
+        bad = [(nw[0] + 1) % O.N] + nw[1:]
+        assert not verifyBPM(gpu, q, 0, g, zeros_n, gs, cs, zeros_l, hs, es, resps, bad, lw, [(1, C)])
+    assert not verifyBPM(gpu, q, 1, g, zeros_n, gs, cs, zeros_l, hs, es, resps, nw, lw, [(1, C)])
+    if len(resps) > 1:
+        swapped = [resps[1], resps[0]] + resps[2:]
+        assert not verifyBPM(gpu, q, 0, g, zeros_n, gs, cs, zeros_l, hs, es, swapped, nw, lw, [(1, C)])
+
+
+def test_verify_with_nonzero_public_vectors(gpu, oracle_lib):
+    """pub (publicCs) non-zero as the range proofs use it (TypedReciprocal.hs:356-357): witness = pub + hidden part."""
+    nl, ll = 12, 5
+    g, gs, hs, xs, ls, cs, q = _instance(nl, ll, 77)
+    rnd = random.Random(5)
+    pub_n = [rnd.randrange(O.N) for _ in range(nl)]
+    pub_l = [rnd.randrange(O.N) for _ in range(ll)]
+    body = O.NormLinear.make(1, q, cs, xs, gs, ls, hs)
+    wit = O.PSV(body.eval_scalar(), g, body)
+    # initCom commits to the hidden part: total - pub on every basis element, and s on g minus sp
+    sp = rnd.randrange(O.N)
+    hidden = [((x - p) % O.N, G_) for x, p, G_ in zip(xs, pub_n, gs)] + [((x - p) % O.N, H_) for x, p, H_ in zip(ls, pub_l, hs)] + [((wit.sc - sp) % O.N, g)]
+    C = O.commit(hidden, oracle_lib)
+    rounds, _ = O.optimal_witness_size_nl(nl, ll)
+    com = NormLinearBP(gpu, wit.sc, g, q, cs, xs, gs, ls, hs)
+    tr = O.Transcript(O.sha_oracle_fn())
+    resps, es = proveBPM(rounds, com, tr.oracle)
+    nw, lw = com.getWitness()
+    com.close()
+    assert verifyBPM(gpu, q, sp, g, pub_n, gs, cs, pub_l, hs, es, resps, nw, lw, [(1, C)])
+    # same through the oracle's verifier
+    basis = O.PSV(0, g, O.NormLinear.make(1, q, [0] * ll, [0] * nl, gs, [0] * ll, hs))
+    pub = O.PSV(sp, g, O.NormLinear.make(1, q, cs, pub_n, [None] * nl, pub_l, [None] * ll))
+    witb = O.NormLinear.make(1, 1, [], nw, [], lw, [])
+    assert O.commit(O.verify_terms([(1, C)], es, resps, pub, basis, witb), oracle_lib) is None
+
+
+def test_examples_64by64_shape(gpu, oracle_lib):
+    """BASELINE config 3 shape: nrmLen 512, linLen 261, 8 rounds — prover rounds on the GPU,
+    final opening and every response equal to the oracle's."""
+    nl, ll = 512, 261
+    g, gs, hs, xs, ls, cs, q = _instance(nl, ll, 6464)
+    body = O.NormLinear.make(1, q, cs, xs, gs, ls, hs)
+    wit = O.PSV(body.eval_scalar(), g, body)
+    rounds, (fn, fl) = O.optimal_witness_size_nl(nl, ll)
+    assert (rounds, fn, fl) == (8, 2, 2)
+    fin, resps_o, es_o = O.prove_bp(rounds, wit, O.Transcript(O.sha_oracle_fn()), oracle_lib)
+    com = NormLinearBP(gpu, wit.sc, g, q, cs, xs, gs, ls, hs)
+    resps, es = proveBPM(rounds, com, O.Transcript(O.sha_oracle_fn()).oracle)
+    assert resps == resps_o and es == es_o
+    nw, lw = com.getWitness()
+    assert (nw, lw) == (fin.body.norm.get_witness(), fin.body.lin.get_witness())
+    com.close()
+    C = O.commit(wit.open_terms(), oracle_lib)
+    assert verifyBPM(gpu, q, 0, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, nw, lw, [(1, C)])
