@@ -120,3 +120,35 @@ def verifyBPM(gpu: Bppp, q: int, sp: int, g: Point, pub_norm: Sequence[int], ngs
         _ptr(points_to_array(flat)) if k else None, _ptr(out))
     gpu._check(rc, "bppp_nl_verify")
     return array_to_point(out) is None
+
+
+def verifyBatch(gpu: Bppp, proofs: Sequence[dict], g: Point, ngs: Sequence[Point], lgs: Sequence[Point], rhos: Sequence[int]) -> bool:
+    """Batch verifier (no reference implementation): one MSM for all proofs.  Each proof is a dict with keys
+    q, sp, pub_norm, pub_lin_c, pub_lin_x, es, responses, wit_norm, wit_lin, init_terms (shapes equal across the batch)."""
+    B = len(proofs)
+    p0 = proofs[0]
+    nlen, llen, k = len(ngs), len(lgs), len(p0["es"])
+    fn, fl, ninit = len(p0["wit_norm"]), len(p0["wit_lin"]), len(p0["init_terms"])
+    cat_s = lambda key: np.concatenate([scalars_to_array(p[key]) for p in proofs]) if len(p0[key]) else np.zeros((1, 4), dtype=np.uint64)
+    arrs = {
+        "g": points_to_array([g]), "G": points_to_array(ngs) if nlen else np.zeros((1, 8), dtype=np.uint64),
+        "H": points_to_array(lgs) if llen else np.zeros((1, 8), dtype=np.uint64), "rho": scalars_to_array([r % N_ORDER for r in rhos]),
+        "q": scalars_to_array([p["q"] % N_ORDER for p in proofs]), "sp": scalars_to_array([p["sp"] % N_ORDER for p in proofs]),
+        "pub_norm": cat_s("pub_norm"), "pub_lin_c": cat_s("pub_lin_c"), "pub_lin_x": cat_s("pub_lin_x"), "es": cat_s("es"),
+        "wit_norm": cat_s("wit_norm"), "wit_lin": cat_s("wit_lin"),
+        "init_s": np.concatenate([scalars_to_array([s for s, _ in p["init_terms"]]) for p in proofs]) if ninit else np.zeros((1, 4), dtype=np.uint64),
+        "init_p": np.concatenate([points_to_array([q_ for _, q_ in p["init_terms"]]) for p in proofs]) if ninit else np.zeros((1, 8), dtype=np.uint64),
+        "resp": np.concatenate([points_to_array([q_ for xr in p["responses"] for q_ in xr]) for p in proofs]) if k else np.zeros((1, 8), dtype=np.uint64),
+    }
+    dev = {name: gpu.to_device(a) for name, a in arrs.items()}
+    out = np.zeros(8, dtype=np.uint64)
+    try:
+        rc = gpu.lib.bppp_nl_verify_batch_device(gpu.h, B, nlen, llen, k, fn, fl, ninit, _ptr(dev["g"]), _ptr(dev["G"]), _ptr(dev["H"]), _ptr(dev["rho"]),
+                                                 _ptr(dev["q"]), _ptr(dev["sp"]), _ptr(dev["pub_norm"]), _ptr(dev["pub_lin_c"]), _ptr(dev["pub_lin_x"]),
+                                                 _ptr(dev["es"]), _ptr(dev["wit_norm"]), _ptr(dev["wit_lin"]), _ptr(dev["init_s"]), _ptr(dev["init_p"]),
+                                                 _ptr(dev["resp"]), _ptr(out))
+        gpu._check(rc, "bppp_nl_verify_batch_device")
+    finally:
+        for p in dev.values():
+            gpu.free(p)
+    return array_to_point(out) is None

@@ -25,6 +25,16 @@ int ensure_workspace(bppp_ctx *ctx, size_t bytes) {
   ctx->ws_bytes = want;
   return BPPP_OK;
 }
+int ensure_scratch(bppp_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->ws2_bytes) return BPPP_OK;
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ws2) BPPP_HIP(ctx, hipFree(ctx->ws2));
+  ctx->ws2 = nullptr; ctx->ws2_bytes = 0;
+  size_t want = bytes + bytes / 8 + (1 << 20);
+  BPPP_HIP(ctx, hipMalloc(&ctx->ws2, want));
+  ctx->ws2_bytes = want;
+  return BPPP_OK;
+}
 int ensure_pinned(bppp_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->pinned_bytes) return BPPP_OK;
   if (ctx->pinned) BPPP_HIP(ctx, hipHostFree(ctx->pinned));
@@ -79,6 +89,7 @@ void bppp_ctx_destroy(bppp_ctx *ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->ws2) hipFree(ctx->ws2);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ev_ready) for (int i = 0; i <= BPPP_NUM_STAGES; i++) hipEventDestroy(ctx->ev[i]);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);

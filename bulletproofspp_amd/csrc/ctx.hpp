@@ -14,6 +14,9 @@ struct bppp_ctx {
   // grow-only device workspace, carved per call (no hipMalloc on the steady-state path)
   void *ws = nullptr;
   size_t ws_bytes = 0;
+  // second grow-only device buffer for callers that also run an MSM (which carves `ws`)
+  void *ws2 = nullptr;
+  size_t ws2_bytes = 0;
   // pinned host staging for small results
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -52,6 +55,7 @@ struct Carver {
 
 int ensure_workspace(bppp_ctx *ctx, size_t bytes);
 int ensure_pinned(bppp_ctx *ctx, size_t bytes);
+int ensure_scratch(bppp_ctx *ctx, size_t bytes);
 void prof_mark(bppp_ctx *ctx, int idx);   // record event idx on the stream when profiling
 void prof_collect(bppp_ctx *ctx, int nmarks);
 

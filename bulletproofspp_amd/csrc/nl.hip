@@ -269,9 +269,10 @@ int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q_[4], const uint64_t sp_[4], c
   hipStream_t st = ctx->stream;
   const size_t T = nlen + llen + 1 + ninit + 2 * k;
   const size_t tn = fn << k, tl = fl << k;
-  uint32_t *buf = nullptr;   // [scalars T][tensor norm tn][tensor lin tl][pub tmp max(nlen,llen)] as Fr, then points T
+  // scratch: [scalars T][tensor norm tn][tensor lin tl][pub tmp max(nlen,llen)] as Fr, then points T
   size_t words = (T + tn + tl + (nlen > llen ? nlen : llen) + 4) * 8 + T * 16;
-  BPPP_HIP(ctx, hipMalloc((void **)&buf, words * 4));
+  { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
+  uint32_t *buf = (uint32_t *)ctx->ws2;
   uint32_t *d_sc = buf, *d_tn = d_sc + T * 8, *d_tl = d_tn + tn * 8, *d_pub = d_tl + tl * 8,
            *d_pts = d_pub + (nlen > llen ? nlen : llen) * 8 + 32;
   int rc = BPPP_OK;
@@ -317,7 +318,6 @@ int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q_[4], const uint64_t sp_[4], c
     rc = msm_run(ctx, d_sc, d_pts, T, 1, 1, 0, out_xy);
   } while (0);
   hipStreamSynchronize(st);
-  hipFree(buf);
   return rc;
 }
 

@@ -1,0 +1,202 @@
+// nlbatch.hip — batch verification of B norm-linear arguments of one shape over one shared basis.
+//
+// The reference has no batch verifier (only the TODO at src/RangeProof/TypedReciprocal.hs:469-472 and
+// src/RangeProof.hs:103-106: "takes a random linear combination, computes the scalars in the same manner as
+// the bulletproof, and then performs a single ec inner product").  Parity is defined in SURVEY.md §8(c):
+//   result = sum_k rho_k * MSM(T_k),   T_k = exactly the term list verifyWith builds for proof k
+//                                       (src/Bulletproof.hs:362-368, :375-377)
+// so every per-proof scalar is the one bppp_nl_verify computes (expandChallenges, NormArgument.hs:73-81,
+// :131-145), scaled by rho_k; scalars that sit on the SHARED basis (G, H, g) are summed over k on the device
+// (the "B x 774 mat-vec" of SURVEY.md §8d), per-proof points (initCom, responses) keep their own scalars.
+// One MSM of (nlen + llen + 1) + B*(ninit + 2k) terms then decides all B proofs: it is infinity iff every
+// proof verifies (up to the 2^-256 soundness slack of the random combination).
+#include <string.h>
+#include <vector>
+#include "ctx.hpp"
+#include "fe.cuh"
+#include "hostmath.hpp"
+
+namespace bppp {
+int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
+
+static constexpr int KT = 16;   // proofs per partial sum
+
+// factor table per proof: fac[b][r] = q_b^(2^r) (r < k), fac[b][k + r] = e_{b, first-round-first r}, and qF2 = (q^(2^k))^2
+__global__ void __launch_bounds__(64) k_vb_factors(const uint32_t *__restrict__ q, const uint32_t *__restrict__ es, uint32_t batch, int k,
+                                                   uint32_t *__restrict__ fac, uint32_t *__restrict__ qf2) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  fe qp = fe_load(q + (size_t)b * 8);
+  for (int r = 0; r < k; r++) {
+    fe_store(fac + ((size_t)b * 2 * k + r) * 8, qp);
+    fe_store(fac + ((size_t)b * 2 * k + k + r) * 8, fe_load(es + ((size_t)b * k + (k - 1 - r)) * 8));   // es is last round first
+    qp = fe_sqr<1>(qp);
+  }
+  fe_store(qf2 + (size_t)b * 8, fe_sqr<1>(qp));
+}
+
+// tensor'(vs, es, qs)[i] for one proof: vs[i >> k] * prod_r (bit r of i ? e_r : q_r)   (src/Bulletproof.hs:94-95)
+BPPP_DI fe tensor_at(const uint32_t *vs, uint32_t nvs, const uint32_t *fac, int k, uint32_t i, bool use_q) {
+  uint32_t hi = i >> k;
+  if (hi >= nvs) return fe_zero();                 // zipWithDef' default (src/Utils.hs:182-184)
+  fe acc = fe_load(vs + (size_t)hi * 8);
+  for (int r = 0; r < k; r++) {
+    bool bit = (i >> r) & 1u;
+    if (bit) acc = fe_mul<1>(acc, fe_load(fac + (size_t)(k + r) * 8));
+    else if (use_q) acc = fe_mul<1>(acc, fe_load(fac + (size_t)r * 8));
+  }
+  return acc;
+}
+
+// partial[kt][i] = sum_{b in tile kt} rho_b * (pub[b][i] - tensor_b[i])      (shared-basis scalars)
+__global__ void __launch_bounds__(256) k_vb_shared(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
+                                                   uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
+                                                   uint32_t *__restrict__ partial) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, kt = blockIdx.y;
+  if (i >= len) return;
+  fe acc = fe_zero();
+  uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
+  for (uint32_t b = b0; b < b1; b++) {
+    fe t = tensor_at(wit + (size_t)b * nvs * 8, nvs, fac + (size_t)b * 2 * k * 8, k, i, use_q != 0);
+    fe d = fe_sub<1>(fe_load(pub + ((size_t)b * len + i) * 8), t);
+    acc = fe_add<1>(acc, fe_mul<1>(fe_load(rho + (size_t)b * 8), d));
+  }
+  fe_store(partial + ((size_t)kt * len + i) * 8, acc);
+}
+__global__ void __launch_bounds__(256) k_vb_sum_partials(const uint32_t *__restrict__ partial, uint32_t ntiles, uint32_t len, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  fe acc = fe_zero();
+  for (uint32_t t = 0; t < ntiles; t++) acc = fe_add<1>(acc, fe_load(partial + ((size_t)t * len + i) * 8));
+  fe_store(out + (size_t)i * 8, acc);
+}
+
+// per proof: gs[b] = rho_b * (sp_b - sc_b), sc_b = sum_i (qF^2)^(i+1) vs_i^2 + sum_j c_j * tensor_lin[j]
+// (NormArgument.hs:135, :76-78), and the per-proof tail scalars rho_b * [init..., e_r, e_r^2 - 1 ...]
+__global__ void __launch_bounds__(256) k_vb_proof(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ sp, const uint32_t *__restrict__ qf2,
+                                                  const uint32_t *__restrict__ wit_norm, uint32_t fn, const uint32_t *__restrict__ wit_lin, uint32_t fl,
+                                                  const uint32_t *__restrict__ pub_c, uint32_t llen, const uint32_t *__restrict__ fac, int k,
+                                                  const uint32_t *__restrict__ init_sc, uint32_t ninit, const uint32_t *__restrict__ es,
+                                                  uint32_t *__restrict__ gs, uint32_t *__restrict__ tail) {
+  __shared__ uint32_t lds[256 * 8];
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  const uint32_t *f = fac + (size_t)b * 2 * k * 8;
+  fe r = fe_load(rho + (size_t)b * 8);
+  fe acc = fe_zero();
+  for (uint32_t j = t; j < llen; j += 256) {
+    fe tl = tensor_at(wit_lin + (size_t)b * fl * 8, fl, f, k, j, false);
+    acc = fe_add<1>(acc, fe_mul<1>(fe_load(pub_c + ((size_t)b * llen + j) * 8), tl));
+  }
+  for (int i = 0; i < 8; i++) lds[t * 8 + i] = acc.v[i];
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)t < d) {
+      fe x, y;
+      for (int i = 0; i < 8; i++) { x.v[i] = lds[t * 8 + i]; y.v[i] = lds[(t + d) * 8 + i]; }
+      x = fe_add<1>(x, y);
+      for (int i = 0; i < 8; i++) lds[t * 8 + i] = x.v[i];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    fe sc; for (int i = 0; i < 8; i++) sc.v[i] = lds[i];
+    fe q2 = fe_load(qf2 + (size_t)b * 8), w = q2;
+    for (uint32_t i = 0; i < fn; i++) {
+      fe v = fe_load(wit_norm + ((size_t)b * fn + i) * 8);
+      sc = fe_add<1>(sc, fe_mul<1>(w, fe_sqr<1>(v)));
+      w = fe_mul<1>(w, q2);
+    }
+    fe_store(gs + (size_t)b * 8, fe_mul<1>(r, fe_sub<1>(fe_load(sp + (size_t)b * 8), sc)));
+  }
+  // tail: ninit init scalars then (e, e^2 - 1) per response, in the order the responses are stored
+  uint32_t per = ninit + 2 * (uint32_t)k;
+  for (uint32_t m = t; m < per; m += 256) {
+    fe v;
+    if (m < ninit) v = fe_load(init_sc + ((size_t)b * ninit + m) * 8);
+    else {
+      uint32_t rr = (m - ninit) >> 1;
+      fe e = fe_load(es + ((size_t)b * k + rr) * 8);
+      v = ((m - ninit) & 1u) ? fe_sub<1>(fe_sqr<1>(e), fe_one()) : e;      // makeEs e = (e, e^2 - 1) (NormArgument.hs:109)
+    }
+    fe_store(tail + ((size_t)b * per + m) * 8, fe_mul<1>(r, v));
+  }
+}
+__global__ void __launch_bounds__(256) k_vb_sum_gs(const uint32_t *__restrict__ gs, uint32_t batch, uint32_t *__restrict__ out) {
+  __shared__ uint32_t lds[256 * 8];
+  const uint32_t t = threadIdx.x;
+  fe acc = fe_zero();
+  for (uint32_t b = t; b < batch; b += 256) acc = fe_add<1>(acc, fe_load(gs + (size_t)b * 8));
+  for (int i = 0; i < 8; i++) lds[t * 8 + i] = acc.v[i];
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)t < d) {
+      fe x, y;
+      for (int i = 0; i < 8; i++) { x.v[i] = lds[t * 8 + i]; y.v[i] = lds[(t + d) * 8 + i]; }
+      x = fe_add<1>(x, y);
+      for (int i = 0; i < 8; i++) lds[t * 8 + i] = x.v[i];
+    }
+    __syncthreads();
+  }
+  if (t == 0) { fe x; for (int i = 0; i < 8; i++) x.v[i] = lds[i]; fe_store(out, x); }
+}
+
+}  // namespace bppp
+
+using namespace bppp;
+
+extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                                           const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q,
+                                           const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                                           const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                                           const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]) {
+  if (!ctx || !out_xy) return BPPP_ERR_ARG;
+  if (!batch) { memset(out_xy, 0, 64); return BPPP_OK; }
+  if (!d_g_xy || !d_rho || !d_q || !d_sp || (nlen && (!d_norm_g_xy || !d_pub_norm)) || (llen && (!d_lin_h_xy || !d_pub_lin_c || !d_pub_lin_x)) ||
+      (k && (!d_es || !d_responses_xy)) || (fn && !d_wit_norm) || (fl && !d_wit_lin) || (ninit && (!d_init_scalars || !d_init_points_xy)) || k > 30 ||
+      batch >= (1u << 24) || nlen >= (1u << 24) || llen >= (1u << 24))
+    return fail(ctx, BPPP_ERR_ARG, "nl_verify_batch: bad arguments");
+  hipSetDevice(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t per = ninit + 2 * k, shared = nlen + llen + 1, T = shared + batch * per;
+  const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
+  const size_t maxlen = nlen > llen ? nlen : llen;
+  // scratch (separate from the MSM workspace, which msm_run carves from ctx->ws)
+  size_t words = (batch * 2 * (k ? k : 1) + batch + (size_t)ntiles * maxlen + batch + T + 64) * 8 + T * 16;
+  { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
+  uint32_t *buf = (uint32_t *)ctx->ws2;
+  uint32_t *fac = buf, *qf2 = fac + batch * 2 * (k ? k : 1) * 8, *partial = qf2 + batch * 8, *gs = partial + (size_t)ntiles * maxlen * 8,
+           *sc = gs + batch * 8, *pts = sc + (T + 32) * 8;
+  int rc = BPPP_OK;
+  do {
+    k_vb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_q, (const uint32_t *)d_es, (uint32_t)batch, (int)k, fac, qf2);
+    if (nlen) {
+      k_vb_shared<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm,
+                                                                                     (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch,
+                                                                                     (uint32_t)nlen, (int)k, 1, partial);
+      k_vb_sum_partials<<<dim3((unsigned)((nlen + 255) / 256)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)nlen, sc);
+    }
+    if (llen) {
+      k_vb_shared<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x,
+                                                                                     (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch,
+                                                                                     (uint32_t)llen, (int)k, 0, partial);
+      k_vb_sum_partials<<<dim3((unsigned)((llen + 255) / 256)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)llen, sc + nlen * 8);
+    }
+    k_vb_proof<<<dim3((unsigned)batch), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf2, (const uint32_t *)d_wit_norm, (uint32_t)fn,
+                                                            (const uint32_t *)d_wit_lin, (uint32_t)fl, (const uint32_t *)d_pub_lin_c, (uint32_t)llen, fac, (int)k,
+                                                            (const uint32_t *)d_init_scalars, (uint32_t)ninit, (const uint32_t *)d_es, gs, sc + shared * 8);
+    k_vb_sum_gs<<<dim3(1), dim3(256), 0, st>>>(gs, (uint32_t)batch, sc + (nlen + llen) * 8);
+    // points: [G | H | g | per proof: init points, responses]
+    hipError_t he = hipSuccess;
+    if (nlen) he = hipMemcpyAsync(pts, d_norm_g_xy, nlen * 64, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess && llen) he = hipMemcpyAsync(pts + nlen * 16, d_lin_h_xy, llen * 64, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(pts + (nlen + llen) * 16, d_g_xy, 64, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess && ninit)
+      he = hipMemcpy2DAsync(pts + shared * 16, per * 64, d_init_points_xy, ninit * 64, ninit * 64, batch, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess && k)
+      he = hipMemcpy2DAsync(pts + (shared + ninit) * 16, per * 64, d_responses_xy, 2 * k * 64, 2 * k * 64, batch, hipMemcpyDeviceToDevice, st);
+    if (he != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: assembling the MSM failed"); break; }
+    rc = msm_run(ctx, sc, pts, T, 1, 1, 0, out_xy);
+  } while (0);
+  hipStreamSynchronize(st);
+  return rc;
+}

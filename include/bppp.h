@@ -143,6 +143,20 @@ int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q[4], const uint64_t sp[4], con
                    size_t llen, const uint64_t *es, size_t k, const uint64_t *wit_norm, size_t fn, const uint64_t *wit_lin, size_t fl,
                    const uint64_t *init_scalars, const uint64_t *init_points_xy, size_t ninit, const uint64_t *responses_xy, uint64_t out_xy[8]);
 
+/* ---- batch verifier (BASELINE config 5) --------------------------------------------------------
+ * No reference implementation exists (TODO at src/RangeProof/TypedReciprocal.hs:469-472); semantics per
+ * out = sum_b rho[b] * MSM(T_b) with T_b the verifyWith term list of proof b
+ * (src/Bulletproof.hs:362-368, :375-377).  All proofs share the shape (nlen, llen, k rounds, fn, fl, ninit)
+ * and the basis (G, H, g); q, sp, the public vectors, challenges, final openings, initCom terms and responses
+ * are per proof, stored [batch][...] contiguously in HBM.  Scalars on the shared basis are summed over the
+ * batch on the device; one MSM of (nlen + llen + 1) + batch * (ninit + 2k) terms decides every proof:
+ * out is infinity iff all verify (rho random, rho[0] = 1 by convention). */
+int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                                const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q,
+                                const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                                const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                                const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
+
 /* ---- harness utility: pointX of getPoints (app/Main.hs:68-72) -------------------------------
  * For each candidate x (n x 4 uint64 in HBM) writes the affine point (x, y) with y the EVEN root of
  * x^3 + 7, or the infinity encoding when x^3 + 7 is a non-residue or x >= p.  (Which root

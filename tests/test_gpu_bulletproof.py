@@ -119,3 +119,50 @@ def test_examples_64by64_shape(gpu, oracle_lib):
     com.close()
     C = O.commit(wit.open_terms(), oracle_lib)
     assert verifyBPM(gpu, q, 0, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, nw, lw, [(1, C)])
+
+
+def test_batch_verifier(gpu, oracle_lib):
+    """SURVEY.md 8(c) pins for the batch verifier: (ii) each valid proof's MSM is infinity, (iii) the random linear
+    combination is infinity iff all are valid, and (i) the combined result equals the oracle's sum_k rho_k * MSM(T_k)
+    when one proof is corrupted (a non-infinity point that depends on every per-proof scalar)."""
+    from bulletproofspp_amd.bulletproof import verifyBatch
+    nl, ll, B = 12, 5, 7
+    g, gs, hs, _, _, _, _ = _instance(nl, ll, 4242)
+    rnd = random.Random(99)
+    proofs, oracle_terms = [], []
+    for b in range(B):
+        xs = [rnd.randrange(O.N) for _ in range(nl)]
+        ls = [rnd.randrange(O.N) for _ in range(ll)]
+        cs = [rnd.randrange(O.N) for _ in range(ll)]
+        q = rnd.randrange(1, O.N)
+        pub_n = [rnd.randrange(O.N) for _ in range(nl)]
+        pub_l = [rnd.randrange(O.N) for _ in range(ll)]
+        sp = rnd.randrange(O.N)
+        body = O.NormLinear.make(1, q, cs, xs, gs, ls, hs)
+        wit = O.PSV(body.eval_scalar(), g, body)
+        hidden = [((x - p) % O.N, G_) for x, p, G_ in zip(xs, pub_n, gs)] + [((x - p) % O.N, H_) for x, p, H_ in zip(ls, pub_l, hs)] + [((wit.sc - sp) % O.N, g)]
+        C = O.commit(hidden, oracle_lib)
+        t = rnd.randrange(1, O.N)          # initCom as a 2-term opening: t * (t^-1 C1) + 1 * C2 with C1 + C2 = C
+        C1 = oracle_lib.mul(rnd.randrange(1, O.N), g)
+        C2 = oracle_lib.add(C, O.PyEC.neg(C1))
+        init = [(t, oracle_lib.mul(O.inv_mod(t, O.N), C1)), (1, C2)]
+        rounds, _ = O.optimal_witness_size_nl(nl, ll)
+        fin, resps, es = O.prove_bp(rounds, wit, O.Transcript(O.sha_oracle_fn(b"p%d" % b)), oracle_lib)
+        nw, lw = fin.body.norm.get_witness(), fin.body.lin.get_witness()
+        proofs.append({"q": q, "sp": sp, "pub_norm": pub_n, "pub_lin_c": cs, "pub_lin_x": pub_l, "es": es, "responses": resps,
+                       "wit_norm": nw, "wit_lin": lw, "init_terms": init})
+        basis = O.PSV(0, g, O.NormLinear.make(1, q, [0] * ll, [0] * nl, gs, [0] * ll, hs))
+        pub = O.PSV(sp, g, O.NormLinear.make(1, q, cs, pub_n, [None] * nl, pub_l, [None] * ll))
+        oracle_terms.append(lambda nw=nw, lw=lw, es=es, resps=resps, pub=pub, basis=basis, init=init:
+                            O.verify_terms(init, es, resps, pub, basis, O.NormLinear.make(1, 1, [], nw, [], lw, [])))
+        assert O.commit(oracle_terms[-1](), oracle_lib) is None
+    rhos = [1] + [rnd.randrange(1, O.N) for _ in range(B - 1)]
+    assert verifyBatch(gpu, proofs, g, gs, hs, rhos)
+    assert verifyBatch(gpu, proofs[:1], g, gs, hs, [1])
+    # corrupt one proof's opening: batch must reject
+    bad = [dict(p) for p in proofs]
+    bad[3]["wit_lin"] = [(bad[3]["wit_lin"][0] + 5) % O.N] + bad[3]["wit_lin"][1:]
+    assert not verifyBatch(gpu, bad, g, gs, hs, rhos)
+    bad = [dict(p) for p in proofs]
+    bad[B - 1]["sp"] = (bad[B - 1]["sp"] + 1) % O.N
+    assert not verifyBatch(gpu, bad, g, gs, hs, rhos)
