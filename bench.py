@@ -72,6 +72,125 @@ def cpu_baseline(sc_np: np.ndarray, pts_np: np.ndarray, sample: int):
     return res, dt
 
 
+def bench_verify(gpu, torch, dev, rank, world, dist, batch: int, n_real: int, steps: int, warmup: int):
+    """Secondary metric (BASELINE.json: "aggregated 64-bit range-proof verifies/sec"): batch verification of `batch`
+    norm-linear arguments of the examples/64by64 shape (nrmLen 512, linLen 261, 8 rounds, 68 transcript commitments +
+    16 responses per proof) per GPU with ONE combined MSM (bppp_nl_verify_batch_device).  The proofs are
+    REAL: produced here by the GPU prover (bulletproofspp_amd.bulletproof.proveBPM) with a SHA-256 stand-in oracle, `n_real`
+    distinct ones tiled to `batch` with fresh random rho.  Out of scope and therefore not timed: the range-proof layer that
+    derives the public vectors from challenges and the Fiat-Shamir hashing (host, injected oracle: src/ZKP.hs:73-77)."""
+    import hashlib
+    from bulletproofspp_amd.bulletproof import NormLinearBP, proveBPM, N_ORDER
+    from bulletproofspp_amd.capi import scalars_to_array, points_to_array, array_to_point, _ptr
+    nlen, llen, k, fn, fl, ninit = 512, 261, 8, 2, 2, 68
+    rng = np.random.default_rng(0x64B + rank)
+    # basis: h-less layout  g : hs(llen) ++ gs(nlen)  (TypedReciprocal.hs:334, :348-349), lifted on the GPU
+    need = 1 + llen + nlen + ninit
+    pts = None
+    while pts is None or pts.shape[0] < need:
+        xs = rng.integers(0, 2**64, size=(3 * need, 4), dtype=np.uint64)
+        dx = torch.from_numpy(xs.view(np.int64)).to(dev)
+        dp = torch.zeros((3 * need, 8), dtype=torch.int64, device=dev)
+        gpu.lift_x(dx.data_ptr(), 3 * need, dp.data_ptr())
+        pts = dp[(dp != 0).any(dim=1)]
+    P = pts[:need].cpu().numpy().view(np.uint64)
+    to_pt = lambda row: array_to_point(row)
+    g, hs, gs, cms = to_pt(P[0]), [to_pt(P[1 + i]) for i in range(llen)], [to_pt(P[1 + llen + i]) for i in range(nlen)], P[1 + llen + nlen:]
+    rand_fr = lambda n: [int.from_bytes(rng.bytes(32), "little") % N_ORDER for _ in range(n)]
+
+    def oracle_fn(tag):
+        state = hashlib.sha256(tag)
+
+        def fn(cs):
+            for c in cs:
+                state.update(b"inf" if c is None else str(c[0]).encode() + str(c[1]).encode())
+            return int.from_bytes(state.copy().digest(), "big") % N_ORDER
+        return fn
+
+    proofs = []
+    t_prove0 = time.perf_counter()
+    for j in range(n_real):
+        xs_, ls_, cs_, q = rand_fr(nlen), rand_fr(llen), rand_fr(llen), rand_fr(1)[0]
+        # s = evalScalar (NormArgument.hs:110-111, :53-54): n^2 sum q^(2(i+1)) x_i^2 + sum c x
+        q2 = q * q % N_ORDER
+        s, w = 0, q2
+        for x in xs_:
+            s = (s + w * x * x) % N_ORDER
+            w = w * q2 % N_ORDER
+        s = (s + sum(c * x for c, x in zip(cs_, ls_))) % N_ORDER
+        # initCom: 68 commitments with scalars t_m whose weighted sum is C = commit(witness): the first 67 are fixed points,
+        # the last is solved for on the GPU (MSM with scalars [t68^-1, -t68^-1 t_m ...])
+        com = NormLinearBP(gpu, s, g, q, cs_, xs_, gs, ls_, hs)
+        C = gpu.msm(scalars_to_array(xs_ + ls_ + [s]), points_to_array(gs + hs + [g]))
+        ts = rand_fr(ninit)
+        tinv = pow(ts[-1], N_ORDER - 2, N_ORDER)
+        others = [to_pt(cms[m]) for m in range(ninit - 1)]
+        last = gpu.msm(scalars_to_array([tinv] + [(-tinv * t) % N_ORDER for t in ts[:-1]]), points_to_array([C] + others))
+        init_pts = others + [last]
+        resps, es = proveBPM(k, com, oracle_fn(b"bench%d" % j))
+        nw, lw = com.getWitness()
+        com.close()
+        proofs.append({"q": q, "es": es, "resp": [p for xr in resps for p in xr], "nw": nw, "lw": lw, "cs": cs_, "ts": ts, "init": init_pts})
+    prove_s = (time.perf_counter() - t_prove0) / max(n_real, 1)
+
+    def tile(rows_per_proof):
+        one = np.concatenate(rows_per_proof)
+        reps = (batch + n_real - 1) // n_real
+        return np.concatenate([one] * reps)[: batch * (one.shape[0] // n_real)]
+
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    d = {
+        "g": up(points_to_array([g])), "G": up(points_to_array(gs)), "H": up(points_to_array(hs)),
+        "rho": up(scalars_to_array([1] + rand_fr(batch - 1))), "q": up(tile([scalars_to_array([p["q"]]) for p in proofs])),
+        "sp": up(np.zeros((batch, 4), dtype=np.uint64)), "pub_norm": up(np.zeros((batch * nlen, 4), dtype=np.uint64)),
+        "pub_lin_c": up(tile([scalars_to_array(p["cs"]) for p in proofs])), "pub_lin_x": up(np.zeros((batch * llen, 4), dtype=np.uint64)),
+        "es": up(tile([scalars_to_array(p["es"]) for p in proofs])), "wn": up(tile([scalars_to_array(p["nw"]) for p in proofs])),
+        "wl": up(tile([scalars_to_array(p["lw"]) for p in proofs])), "is": up(tile([scalars_to_array(p["ts"]) for p in proofs])),
+        "ip": up(tile([points_to_array(p["init"]) for p in proofs])), "rp": up(tile([points_to_array(p["resp"]) for p in proofs])),
+    }
+    out = np.zeros(8, dtype=np.uint64)
+    gathered = torch.zeros((world, 8), dtype=torch.int64, device=dev)
+    ones = torch.zeros((world, 4), dtype=torch.int64, device=dev)
+    ones[:, 0] = 1
+
+    def step():
+        rc = gpu.lib.bppp_nl_verify_batch_device(gpu.h, batch, nlen, llen, k, fn, fl, ninit, *[_ptr(d[x].data_ptr()) for x in
+                                                 ("g", "G", "H", "rho", "q", "sp", "pub_norm", "pub_lin_c", "pub_lin_x", "es", "wn", "wl", "is", "ip", "rp")],
+                                                 _ptr(out))
+        gpu._check(rc, "bppp_nl_verify_batch_device")
+        if world == 1:
+            return array_to_point(out)
+        mine = torch.from_numpy(out.copy().view(np.int64).reshape(1, 8)).to(dev)
+        dist.all_gather_into_tensor(gathered, mine)
+        return gpu.msm_device(ones.data_ptr(), gathered.data_ptr(), world, 0)
+
+    for _ in range(warmup):
+        res = step()
+    assert res is None, "batch of valid proofs did not verify"
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert res is None
+    terms = nlen + llen + 1 + batch * (ninit + 2 * k)
+    return {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
+            "ms_per_batch": dt / steps * 1e3, "batch_per_gpu": batch, "combined_msm_terms": terms,
+            "shape": "examples/64by64: nrmLen 512, linLen 261, 8 rounds, 68+16 per-proof points (SURVEY.md App. B)",
+            "proofs": f"{n_real} real proofs from the GPU prover tiled to {batch}; all verify (combined MSM = infinity)",
+            "scope": "norm-linear argument level (verifyBPM, Bulletproof.hs:370-378); challenges and public vectors are inputs",
+            "gpu_prove_ms_per_proof": prove_s * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +200,8 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="Pippenger window bits (0 = library heuristic)")
     ap.add_argument("--cpu-sample-log2", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-batch", type=int, default=4096, help="proofs per GPU in the batch-verify leg (0 = skip)")
+    ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +267,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    verify = None
+    if args.verify_batch > 0:
+        verify = bench_verify(gpu, torch, dev, rank, world, dist, args.verify_batch, args.verify_real, max(3, args.steps // 2), 1)
+
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
         # with N > 1 each step makes two library calls (the slice MSM and the tiny combine): the dominant
@@ -185,6 +310,8 @@ def main():
                                              "oracle/bppp_oracle.c restatement of the reference's 256-row Straus loop "
                                              "(Commitment.hs:325-335), single thread; the Haskell reference itself cannot be built "
                                              "here (no GHC)", "seconds": cdt, "gpu_matches": True}
+        if verify is not None:
+            out["verify"] = verify
         print(json.dumps(out), flush=True)
     gpu.close()
     if dist is not None:
