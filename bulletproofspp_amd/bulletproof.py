@@ -152,3 +152,69 @@ def verifyBatch(gpu: Bppp, proofs: Sequence[dict], g: Point, ngs: Sequence[Point
         for p in dev.values():
             gpu.free(p)
     return array_to_point(out) is None
+
+
+# ----------------------------------------------------------------------------- inner-product flavour
+class NormLinearIP:
+    """IP-flavour NormLinear (src/Bulletproof/InnerProductArgument.hs:239-267) on the device; `r` as in makeNorm (:194)."""
+
+    def __init__(self, gpu: Bppp, s: int, g: Point, r: int, cs: Sequence[int], nss: Sequence[int], ngs: Sequence[Point],
+                 lss: Sequence[int], lgs: Sequence[Point]):
+        nlen, llen = max(len(nss), len(ngs)), max(len(cs), len(lss), len(lgs))
+        pad = lambda xs, n, z: list(xs) + [z] * (n - len(xs))
+        self.gpu = gpu
+        h = C.c_void_p()
+        rc = gpu.lib.bppp_ip_create(gpu.h, _ptr(int_to_limbs(s % N_ORDER)), _ptr(points_to_array([g])), _ptr(int_to_limbs(r % N_ORDER)),
+                                    _ptr(scalars_to_array(pad(nss, nlen, 0))) if nlen else None, _ptr(points_to_array(pad(ngs, nlen, None))) if nlen else None, nlen,
+                                    _ptr(scalars_to_array(pad(cs, llen, 0))) if llen else None, _ptr(scalars_to_array(pad(lss, llen, 0))) if llen else None,
+                                    _ptr(points_to_array(pad(lgs, llen, None))) if llen else None, llen, C.byref(h))
+        gpu._check(rc, "bppp_ip_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.gpu.lib.bppp_ip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lengths(self) -> Tuple[int, int]:
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.gpu._check(self.gpu.lib.bppp_ip_lengths(self.h, C.byref(a), C.byref(b)), "bppp_ip_lengths")
+        return int(a.value), int(b.value)
+
+    def makeScalarsComs(self) -> Tuple[int, Point, int, Point]:
+        sL, sR = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        L, R = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_ip_round_commit(self.h, _ptr(sL), _ptr(L), _ptr(sR), _ptr(R)), "bppp_ip_round_commit")
+        return limbs_to_int(sL), array_to_point(L), limbs_to_int(sR), array_to_point(R)
+
+    def collapse(self, e: int):
+        self.gpu._check(self.gpu.lib.bppp_ip_round_collapse(self.h, _ptr(int_to_limbs(e % N_ORDER))), "bppp_ip_round_collapse")
+
+    def getWitness(self) -> Tuple[List[int], List[int], int]:
+        m, l = self.lengths()
+        nw, lw = np.zeros((max(2 * m, 1), 4), dtype=np.uint64), np.zeros((max(l, 1), 4), dtype=np.uint64)
+        s = np.zeros(4, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_ip_get_witness(self.h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_ip_get_witness")
+        return array_to_scalars(nw)[:2 * m], array_to_scalars(lw)[:l], limbs_to_int(s)
+
+
+def verifyBPM_IP(gpu: Bppp, r: int, sp: int, g: Point, pub_norm: Sequence[int], ngs: Sequence[Point], pub_lin_c: Sequence[int],
+                 pub_lin_x: Sequence[int], lgs: Sequence[Point], es: Sequence[int], responses: Sequence[Tuple[Point, Point]],
+                 wit_norm: Sequence[int], wit_lin: Sequence[int], init_terms: Sequence[Tuple[int, Point]]) -> bool:
+    k = len(es)
+    out = np.zeros(8, dtype=np.uint64)
+    flat = [p for xr in responses for p in xr]
+    opt_s = lambda xs: _ptr(scalars_to_array(xs)) if len(xs) else None
+    opt_p = lambda ps: _ptr(points_to_array(ps)) if len(ps) else None
+    rc = gpu.lib.bppp_ip_verify(gpu.h, _ptr(int_to_limbs(r % N_ORDER)), _ptr(int_to_limbs(sp % N_ORDER)), _ptr(points_to_array([g])),
+                                opt_s(pub_norm), opt_p(ngs), len(ngs), opt_s(pub_lin_c), opt_s(pub_lin_x), opt_p(lgs), len(lgs),
+                                opt_s(es), k, opt_s(wit_norm), len(wit_norm), opt_s(wit_lin), len(wit_lin),
+                                opt_s([s for s, _ in init_terms]), opt_p([p for _, p in init_terms]), len(init_terms), opt_p(flat), _ptr(out))
+    gpu._check(rc, "bppp_ip_verify")
+    return array_to_point(out) is None

@@ -143,6 +143,28 @@ int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q[4], const uint64_t sp[4], con
                    size_t llen, const uint64_t *es, size_t k, const uint64_t *wit_norm, size_t fn, const uint64_t *wit_lin, size_t fl,
                    const uint64_t *init_scalars, const uint64_t *init_points_xy, size_t ninit, const uint64_t *responses_xy, uint64_t out_xy[8]);
 
+/* ---- a12: the inner-product flavour (src/Bulletproof/InnerProductArgument.hs; the CLI's default, app/Parse.hs:100)
+ * Same contract as bppp_nl_*.  `r` is the argument of makeNorm (:194-206; q = r^4): the norm vector (nlen scalars on nlen
+ * points) is re-expressed as ceil(nlen/2) inner-product pairs with the basis change g' = g1 + r g0, h' = g1 - r g0 done
+ * on the device (one full scalar multiplication per pair, :204).  makeEs e = (1/e, e) (:68). */
+typedef struct bppp_ip bppp_ip;
+int bppp_ip_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], const uint64_t r[4], const uint64_t *norm_s,
+                   const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy,
+                   size_t llen, bppp_ip **out);
+void bppp_ip_destroy(bppp_ip *ip);
+int bppp_ip_lengths(const bppp_ip *ip, size_t *ip_len, size_t *llen);   /* ip_len = number of (x, y) pairs */
+/* makeScalarsComs (:70-81, :155-158 via foldLR :17-26) + the two commits of proveRoundM (src/Bulletproof.hs:348-350) */
+int bppp_ip_round_commit(bppp_ip *ip, uint64_t sL[4], uint64_t L_xy[8], uint64_t sR[4], uint64_t R_xy[8]);
+/* s += e^-1 sL + e sR; collapse (:86-101, :162-170) */
+int bppp_ip_round_collapse(bppp_ip *ip, const uint64_t e[4]);
+/* getWitness: norm_w holds 2*ip_len scalars (nx x - ny y, nx x + ny y) (:222-223); lin_w llen scalars; s the PSV scalar */
+int bppp_ip_get_witness(bppp_ip *ip, uint64_t *norm_w, uint64_t *lin_w, uint64_t s[4]);
+/* verifyBPM for this flavour: basis change, expandChallenges (:103-124, :172-181), one MSM; out must be infinity */
+int bppp_ip_verify(bppp_ctx *ctx, const uint64_t r[4], const uint64_t sp[4], const uint64_t g_xy[8], const uint64_t *pub_norm,
+                   const uint64_t *norm_g_xy, size_t nlen, const uint64_t *pub_lin_c, const uint64_t *pub_lin_x, const uint64_t *lin_h_xy,
+                   size_t llen, const uint64_t *es, size_t k, const uint64_t *wit_norm, size_t fn, const uint64_t *wit_lin, size_t fl,
+                   const uint64_t *init_scalars, const uint64_t *init_points_xy, size_t ninit, const uint64_t *responses_xy, uint64_t out_xy[8]);
+
 /* ---- batch verifier (BASELINE config 5) --------------------------------------------------------
  * No reference implementation exists (TODO at src/RangeProof/TypedReciprocal.hs:469-472); semantics per
  * out = sum_b rho[b] * MSM(T_b) with T_b the verifyWith term list of proof b

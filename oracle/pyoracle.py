@@ -657,3 +657,241 @@ def hash_points(seed: bytes, count: int, ec: Optional[CEC] = None) -> List[Point
             y = P - y
         out.append((x, y))
     return out
+
+
+# ============================================================================= inner-product flavour
+# Restatement of src/Bulletproof/InnerProductArgument.hs (the default argument of the CLI, app/Parse.hs:100).
+def number_rounds_reduce1(n: int) -> Tuple[int, int]:
+    """numberRoundsReduce' (src/Bulletproof.hs:305-307): reduce to less than 3."""
+    r, n1 = number_rounds_reduce(n)
+    return (r + 1, round_reduce(n1)) if n1 > 2 else (r, n1)
+
+
+def optimal_witness_size_ip(n_len: int, l_len: int) -> Tuple[int, Tuple[int, int]]:
+    """IP-flavour NormLinear optimalWitnessSize (InnerProductArgument.hs:253-267)."""
+    n_even = (n_len + (n_len % 2)) // 2
+    nR, n1 = number_rounds_reduce1(n_even)
+    lR, l1 = number_rounds_reduce(l_len)
+    r = max(nR, lR)
+    n2 = round_reduce_by(n1, r - nR)
+    l2 = round_reduce_by(l1, r - lR)
+    if 2 * n2 + l2 > 5:
+        return r + 1, (2 * round_reduce(n2), round_reduce(l2))
+    return r, (2 * n2, l2)
+
+
+@dataclass
+class InnerProduct:
+    """data InnerProduct = IP s nrmlzY q qInv (BPF'' nrmlzX [IPF x g y h]) (InnerProductArgument.hs:32-49)."""
+    s: int
+    ny: int
+    q: int
+    q_inv: int
+    nx: int
+    body: List[Tuple[int, Point, int, Point]]
+
+    @staticmethod
+    def make(s, q, ss0, gs0, ss1, gs1) -> "InnerProduct":
+        """makeIP (:47-49)."""
+        n = max(len(ss0), len(gs0), len(ss1), len(gs1))
+        g = lambda xs, i, z: xs[i] if i < len(xs) else z
+        body = [(g(ss0, i, 0) % N, g(gs0, i, None), g(ss1, i, 0) % N, g(gs1, i, None)) for i in range(n)]
+        return InnerProduct(s % N, 1, q % N, inv_mod(q, N), 1, body)
+
+    def open_terms(self):
+        """openWith (IPF x g y h) = x·g + y·h (:37-38); normalisation is not part of the commitment."""
+        out = []
+        for x, g, y, h in self.body:
+            out += [(x, g), (y, h)]
+        return out
+
+    def eval_scalar(self) -> int:
+        """evalScalar (:63-66)."""
+        scs = [x * y % N for x, _, y, _ in self.body]
+        return self.s * self.nx % N * self.ny % N * dot_zip(scs, powers1(self.q, len(scs))) % N
+
+    @staticmethod
+    def make_es(e: int) -> Tuple[int, int]:
+        """makeEs (:68)."""
+        return inv_mod(e, N), e % N
+
+    def make_scalars_coms(self):
+        """makeScalarsComs (:70-81) via foldLR (:17-26)."""
+        q, qi = self.q, self.q_inv
+        q2 = q * q % N
+        s, sl, sr = 1, 0, 0
+        wl, wr = [], []
+        zero = (0, None, 0, None)
+        for (xl, gl, yl, hl), (xr, gr, yr, hr) in _halves(self.body, zero):
+            sl = (sl + s * xl * yr) % N
+            sr = (sr + s * xr * yl) % N
+            wl.append((qi * xl % N, gr, yr, hl))
+            wr.append((q * xr % N, gl, yl, hr))
+            s = s * q2 % N
+        k = self.s * self.nx % N * self.ny % N
+        sL = k * q % N * sl % N
+        sR = k * q2 % N * sr % N
+        mk = lambda t, b: InnerProduct(self.s, self.ny, q2, qi * qi % N, t * self.nx % N, b)
+        return sL, mk(1, wl), sR, mk(qi, wr)
+
+    def get_witness(self) -> List[int]:
+        """getWitness (:83-84)."""
+        out = []
+        for x, _, y, _ in self.body:
+            out += [self.nx * x % N, self.ny * y % N]
+        return out
+
+    def collapse(self, e: int, ec) -> "InnerProduct":
+        """collapse (:86-101)."""
+        q, qi = self.q, self.q_inv
+        ei = inv_mod(e, N)
+        a1, b1 = rational_reduce_scalar(qi * ei % N)
+        b0 = b1 % N
+        b0i = inv_mod(b0, N)
+        c1, d1 = rational_reduce_scalar(e)
+        d0 = d1 % N
+        d0i = inv_mod(d0, N)
+        body = []
+        zero = (0, None, 0, None)
+        for (xl, gl, yl, hl), (xr, gr, yr, hr) in _halves(self.body, zero):
+            body.append((b0i * (xl + e * q % N * xr) % N, ec.pair_ip(b1, gl, a1, gr), d0i * (yl + ei * yr) % N, ec.pair_ip(d1, hl, c1, hr)))
+        return InnerProduct(self.s, self.ny * d0 % N, q * q % N, qi * qi % N, self.nx * b0 % N * qi % N, body)
+
+    @staticmethod
+    def expand_challenges(es_y, wit: "InnerProduct", pub: "InnerProduct", basis: "InnerProduct"):
+        """expandChallenges (:103-124)."""
+        s, q = pub.s, pub.q
+        qF = q
+        for _ in range(len(es_y)):
+            qF = qF * qF % N
+        es_x = [inv_mod(e, N) for e in es_y]
+        vx = [wit.nx * x % N for x, _, _, _ in wit.body]
+        vy = [wit.ny * y % N for _, _, y, _ in wit.body]
+        sc = s * weighted_dot_zip(powers1(qF, len(vx)), vx, vy) % N
+        tx = tensor(vx, es_x, lambda k: pow(q, 2**k, N))
+        ty = tensor(vy, es_y, lambda k: 1)
+        pairs = list(zip(pub.body, basis.body))
+        ts = list(zip(tx, ty))
+        body = zip_with_def1(lambda pg, e_: ((pg[0][0] - e_[0]) % N, pg[1][1], (pg[0][2] - e_[1]) % N, pg[1][3]), (0, 0), pairs, ts)
+        return sc, InnerProduct(s, 1, qF, inv_mod(qF, N), 1, body)
+
+
+@dataclass
+class LinearIP:
+    """Linear of the IP flavour (InnerProductArgument.hs:132-181)."""
+    n: int
+    body: List[Tuple[int, int, Point]]
+
+    @staticmethod
+    def make(cs, ss, gs) -> "LinearIP":
+        l = Linear.make(cs, ss, gs)
+        return LinearIP(l.n, l.body)
+
+    def open_terms(self):
+        return [(x, g) for _, x, g in self.body]
+
+    def eval_scalar(self) -> int:
+        return sum(c * x for c, x, _ in self.body) % N
+
+    def make_scalars_coms(self):
+        """makeScalarsComs (:155-158): half-length openings."""
+        sl, sr = 0, 0
+        wl, wr = [], []
+        for (cl, xl, gl), (cr, xr, gr) in _halves(self.body, (0, 0, None)):
+            sl = (sl + cr * xl) % N
+            sr = (sr + cl * xr) % N
+            wl.append((cr, xl, gr))
+            wr.append((cl, xr, gl))
+        return sl, LinearIP(self.n, wl), sr, LinearIP(self.n, wr)
+
+    def get_witness(self) -> List[int]:
+        return [self.n * x % N for _, x, _ in self.body]
+
+    def collapse(self, e: int, ec) -> "LinearIP":
+        """collapse (:162-170): rationalReduceScalar of 1/e."""
+        a1, b1 = rational_reduce_scalar(inv_mod(e, N))
+        a0, b0 = a1 % N, b1 % N
+        b0i = inv_mod(b0, N)
+        body = []
+        for (cl, xl, gl), (cr, xr, gr) in _halves(self.body, (0, 0, None)):
+            body.append(((b0 * cl + a0 * cr) % N, (b0i * xl + e * b0i % N * xr) % N, ec.pair_ip(b1, gl, a1, gr)))
+        return LinearIP(self.n * b0 % N, body)
+
+    @staticmethod
+    def expand_challenges(es1, wit: "LinearIP", pub: "LinearIP", basis: "LinearIP"):
+        """expandChallenges (:172-181): challenges inverted first."""
+        es = [inv_mod(e, N) for e in es1]
+        sc, l = Linear.expand_challenges(es, Linear(wit.n, wit.body), Linear(pub.n, pub.body), Linear(basis.n, basis.body))
+        return sc, LinearIP(l.n, l.body)
+
+
+def ip_make_norm(r: int, ss: Sequence[int], gs: Sequence[Point], ec) -> InnerProduct:
+    """makeNorm of the IP flavour (:194-206): pairs (s0,g0),(s1,g1) -> IPF x' g' y' h' with the basis change
+    g' = g1 + r·g0, h' = g1 - r·g0; state IP 4 1 q q^-1 with q = r^4."""
+    r %= N
+    q = pow(r, 4, N)
+    half, r2i = inv_mod(2, N), inv_mod(2 * r, N)
+    items = zip_with_def2(lambda s, g: (s % N, g), 0, None, list(ss), list(gs))
+    body = []
+    for (s0, g0), (s1, g1) in _halves(items, (0, None)):
+        p = ec.mul(r, g0)                                   # commit (CP r g0) (:204)
+        body.append(((r2i * s0 + half * s1) % N, ec.add(g1, p), (-r2i * s0 + half * s1) % N, ec.add(g1, ec.neg(p))))
+    return InnerProduct(4, 1, q, inv_mod(q, N), 1, body)
+
+
+def ip_norm_get_witness(ip: InnerProduct) -> List[int]:
+    """Norm.getWitness of the IP flavour (:222-223)."""
+    out = []
+    for x, _, y, _ in ip.body:
+        out += [(ip.nx * x - ip.ny * y) % N, (ip.nx * x + ip.ny * y) % N]
+    return out
+
+
+@dataclass
+class NormLinearIP:
+    """NormLinear of the IP flavour (:239-267): BPCompose (Norm f) (Linear f)."""
+    s: int
+    norm: InnerProduct
+    lin: LinearIP
+
+    @staticmethod
+    def make(s, r, cs, nss, ngs, lss, lgs, ec) -> "NormLinearIP":
+        return NormLinearIP(s % N, ip_make_norm(r, nss, ngs, ec), LinearIP.make(cs, lss, lgs))
+
+    def open_terms(self):
+        return self.norm.open_terms() + self.lin.open_terms()
+
+    @staticmethod
+    def make_es(e: int):
+        return InnerProduct.make_es(e)
+
+    def eval_scalar(self) -> int:
+        return self.s * (self.norm.eval_scalar() + self.lin.eval_scalar()) % N
+
+    def make_scalars_coms(self):
+        a = self.norm.make_scalars_coms()
+        b = self.lin.make_scalars_coms()
+        return (a[0] + b[0]) % N, NormLinearIP(self.s, a[1], b[1]), (a[2] + b[2]) % N, NormLinearIP(self.s, a[3], b[3])
+
+    def get_witness(self) -> List[int]:
+        return [self.s * w % N for w in ip_norm_get_witness(self.norm) + self.lin.get_witness()]
+
+    def collapse(self, e: int, ec) -> "NormLinearIP":
+        return NormLinearIP(self.s, self.norm.collapse(e, ec), self.lin.collapse(e, ec))
+
+    @staticmethod
+    def expand_challenges(es, wit: "NormLinearIP", pub: "NormLinearIP", basis: "NormLinearIP"):
+        sa, na = InnerProduct.expand_challenges(es, wit.norm, pub.norm, basis.norm)
+        sb, lb = LinearIP.expand_challenges(es, wit.lin, pub.lin, basis.lin)
+        return (sa + sb) % N, NormLinearIP(pub.s, na, lb)
+
+
+def verify_terms_generic(cls, init_terms, es, rs, pub: PSV, basis: PSV, wit_body):
+    """verifyBPM's term list (Bulletproof.hs:375-377, :362-368) for any BPOpening class with expand_challenges / make_es."""
+    sc, chs = cls.expand_challenges(es, wit_body, pub.body, basis.body)
+    wit1 = PSV((pub.sc - sc) % N, basis.g, chs)
+    terms = wit1.open_terms() + list(init_terms)
+    for e, (x, r) in zip(es, rs):
+        e0, e1 = cls.make_es(e)
+        terms += [(e0, x), (e1, r)]
+    return terms

@@ -166,3 +166,42 @@ def test_batch_verifier(gpu, oracle_lib):
     bad = [dict(p) for p in proofs]
     bad[B - 1]["sp"] = (bad[B - 1]["sp"] + 1) % O.N
     assert not verifyBatch(gpu, bad, g, gs, hs, rhos)
+
+
+# ----------------------------------------------------------------------------- inner-product flavour (a12)
+@pytest.mark.parametrize("nl,ll", [(11, 6), (16, 6), (8, 5), (62, 24), (10, 3), (5, 0), (0, 7)])
+def test_ip_flavour_prove_and_verify(gpu, oracle_lib, nl, ll):
+    """src/Bulletproof/InnerProductArgument.hs on the GPU vs the oracle's restatement, round by round.
+    Shapes include examples/32bit (11, 6), examples/64bit (16, 6) and examples/rec_test (62, 24)."""
+    from bulletproofspp_amd.bulletproof import NormLinearIP, verifyBPM_IP
+    ec = oracle_lib
+    g, gs, hs, xs, ls, cs, r = _instance(nl, ll, 500 + 31 * nl + ll)
+    body = O.NormLinearIP.make(1, r, cs, xs, gs, ls, hs, ec)
+    s = body.eval_scalar()
+    com_o = O.PSV(s, g, body)
+    C = O.commit(com_o.open_terms(), ec)
+    rounds, (fn, fl) = O.optimal_witness_size_ip(nl, ll)
+    rounds = max(rounds, 1)
+    dev = NormLinearIP(gpu, s, g, r, cs, xs, gs, ls, hs)
+    tr = O.Transcript(O.sha_oracle_fn())
+    resps, es = [], []
+    for _ in range(rounds):
+        c = com_o.body
+        sL, a, sR, b = c.make_scalars_coms()
+        ac = O.commit(O.PSV(sL, g, a).open_terms(), ec)
+        bc = O.commit(O.PSV(sR, g, b).open_terms(), ec)
+        dsL, dL, dsR, dR = dev.makeScalarsComs()
+        assert (dsL, dL, dsR, dR) == (sL, ac, sR, bc)
+        e = tr.oracle([ac, bc])
+        e0, e1 = c.make_es(e)
+        com_o = O.PSV((com_o.sc + e0 * sL + e1 * sR) % O.N, g, c.collapse(e, ec))
+        dev.collapse(e)
+        resps.insert(0, (ac, bc)); es.insert(0, e)
+        nw_d, lw_d, s_d = dev.getWitness()
+        assert nw_d == O.ip_norm_get_witness(com_o.body.norm) and lw_d == com_o.body.lin.get_witness() and s_d == com_o.sc
+    nw, lw, _ = dev.getWitness()
+    dev.close()
+    assert verifyBPM_IP(gpu, r, 0, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, nw, lw, [(1, C)])
+    if nw:
+        assert not verifyBPM_IP(gpu, r, 0, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, [(nw[0] + 1) % O.N] + nw[1:], lw, [(1, C)])
+    assert not verifyBPM_IP(gpu, r, 3, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, nw, lw, [(1, C)])

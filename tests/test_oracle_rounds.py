@@ -98,3 +98,56 @@ def test_batch_inverse_zero_maps_to_zero():
     inv = O.batch_inverse(xs, O.N)
     assert inv[1] == 0 and inv[4] == 0
     assert all(x * y % O.N == 1 for x, y in zip(xs, inv) if x)
+
+
+# ----------------------------------------------------------------------------- inner-product flavour
+def _ip_prove_verify(nl, ll, seed, ec, tamper=False):
+    rnd = random.Random(seed)
+    g, *rest = O.hash_points(b"ipo%d" % seed, 1 + nl + ll)
+    gs, hs = rest[:nl], rest[nl:]
+    xs = [rnd.randrange(O.N) for _ in range(nl)]
+    ls = [rnd.randrange(O.N) for _ in range(ll)]
+    cs = [rnd.randrange(O.N) for _ in range(ll)]
+    r = rnd.randrange(1, O.N)
+    body = O.NormLinearIP.make(1, r, cs, xs, gs, ls, hs, ec)
+    s = body.eval_scalar()
+    # the weights the range proofs rely on: qPowers' _ q = powers' (negate q^2) (InnerProductArgument.hs:230-231)
+    w = O.powers1((-r * r) % O.N, nl)
+    assert s == (sum(wi * x * x for wi, x in zip(w, xs)) + sum(c * l for c, l in zip(cs, ls))) % O.N
+    com = O.PSV(s, g, body)
+    C = O.commit(com.open_terms(), ec)
+    assert C == O.commit(list(zip(xs, gs)) + list(zip(ls, hs)) + [(s, g)], ec)      # the basis change preserves the commitment
+    rounds, (fn, fl) = O.optimal_witness_size_ip(nl, ll)
+    tr = O.Transcript(O.sha_oracle_fn())
+    resps, es = [], []
+    for _ in range(rounds):
+        c = com.body
+        sL, a, sR, b = c.make_scalars_coms()
+        ac, bc = O.commit(O.PSV(sL, g, a).open_terms(), ec), O.commit(O.PSV(sR, g, b).open_terms(), ec)
+        e = tr.oracle([ac, bc])
+        e0, e1 = c.make_es(e)
+        com = O.PSV((com.sc + e0 * sL + e1 * sR) % O.N, g, c.collapse(e, ec))
+        assert com.sc == com.body.eval_scalar()
+        resps.insert(0, (ac, bc)); es.insert(0, e)
+    nw, lw = O.ip_norm_get_witness(com.body.norm), com.body.lin.get_witness()
+    assert (len(nw), len(lw)) == (fn, fl)
+    if tamper:
+        lw = [(lw[0] + 1) % O.N] + lw[1:] if lw else lw
+        nw = nw if lw else [(nw[0] + 1) % O.N] + nw[1:]
+    basis = O.PSV(0, g, O.NormLinearIP.make(1, r, [0] * ll, [0] * nl, gs, [0] * ll, hs, ec))
+    pub = O.PSV(0, g, O.NormLinearIP.make(1, r, cs, [0] * nl, [None] * nl, [0] * ll, [None] * ll, ec))
+    witb = O.NormLinearIP.make(1, 1, [], nw, [], lw, [], ec)      # decodeProof' (RangeProof.hs:81)
+    return O.commit(O.verify_terms_generic(O.NormLinearIP, [(1, C)], es, resps, pub, basis, witb), ec) is None
+
+
+@pytest.mark.parametrize("nl,ll", [(11, 6), (16, 6), (8, 5), (62, 24), (10, 3)])
+def test_ip_flavour_closes(oracle_lib, nl, ll):
+    assert _ip_prove_verify(nl, ll, nl * 7 + ll, oracle_lib)
+    assert not _ip_prove_verify(nl, ll, nl * 7 + ll, oracle_lib, tamper=True)
+
+
+def test_ip_round_counts_match_reference_shapes():
+    # examples/32bit, 64bit, rec_test (argument = IP by default, app/Parse.hs:100)
+    assert O.optimal_witness_size_ip(11, 6) == (3, (2, 1))
+    assert O.optimal_witness_size_ip(16, 6) == (3, (2, 1))
+    assert O.optimal_witness_size_ip(62, 24) == (5, (2, 1))
