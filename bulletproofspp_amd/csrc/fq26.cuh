@@ -36,6 +36,11 @@ BPPP_DI bool fq_all_zero(const fq &a) {        // exact all-limbs-zero test (the
 }
 
 // ---- multiplication: 100 carry-free v_mad_u64_u32 + 20 for the 2^260 fold
+// Measured codegen (hipcc 7.2, gfx950): 224 instructions per fq_mul — 113 v_mad_u64_u32, 28 v_lshl_add_u64, 22
+// v_lshrrev_b64, 23 v_and, 9 v_lshlrev_b64, ~10 v_mov: the compiler starts every column from zero (independent chains, good
+// ILP) and adds the previous column's carry with one 64-bit add.  Pinning a single dependent chain per column (empty-asm
+// barriers) removes those adds but back-to-back dependent v_mad_u64_u32 need a wait state on this target (hipcc pads
+// with s_nop 0): 254-272 instructions, slower.  The plain C below is therefore the production form.
 #define FQ_COL(acc, k)                                                                 \
   _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); i <= ((k) < 9 ? (k) : 9); i++) \
       acc += (uint64_t)a.n[i] * b.n[(k)-i];
