@@ -72,7 +72,7 @@ def cpu_baseline(sc_np: np.ndarray, pts_np: np.ndarray, sample: int):
     return res, dt
 
 
-def bench_verify(gpu, torch, dev, rank, world, dist, batch: int, n_real: int, steps: int, warmup: int):
+def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real: int, steps: int, warmup: int):
     """Secondary metric (BASELINE.json: "aggregated 64-bit range-proof verifies/sec"): batch verification of `batch`
     norm-linear arguments of the examples/64by64 shape (nrmLen 512, linLen 261, 8 rounds, 68 transcript commitments +
     16 responses per proof) per GPU with ONE combined MSM (bppp_nl_verify_batch_device).  The proofs are
@@ -149,20 +149,14 @@ def bench_verify(gpu, torch, dev, rank, world, dist, batch: int, n_real: int, st
         "ip": up(tile([points_to_array(p["init"]) for p in proofs])), "rp": up(tile([points_to_array(p["resp"]) for p in proofs])),
     }
     out = np.zeros(8, dtype=np.uint64)
-    gathered = torch.zeros((world, 8), dtype=torch.int64, device=dev)
-    ones = torch.zeros((world, 4), dtype=torch.int64, device=dev)
-    ones[:, 0] = 1
 
     def step():
         rc = gpu.lib.bppp_nl_verify_batch_device(gpu.h, batch, nlen, llen, k, fn, fl, ninit, *[_ptr(d[x].data_ptr()) for x in
                                                  ("g", "G", "H", "rho", "q", "sp", "pub_norm", "pub_lin_c", "pub_lin_x", "es", "wn", "wl", "is", "ip", "rp")],
                                                  _ptr(out))
         gpu._check(rc, "bppp_nl_verify_batch_device")
-        if world == 1:
-            return array_to_point(out)
-        mine = torch.from_numpy(out.copy().view(np.int64).reshape(1, 8)).to(dev)
-        dist.all_gather_into_tensor(gathered, mine)
-        return gpu.msm_device(ones.data_ptr(), gathered.data_ptr(), world, 0)
+        part = array_to_point(out)
+        return part if world == 1 else combine(part)
 
     for _ in range(warmup):
         res = step()
@@ -178,7 +172,7 @@ def bench_verify(gpu, torch, dev, rank, world, dist, batch: int, n_real: int, st
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert res is None
@@ -202,6 +196,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=4096, help="proofs per GPU in the batch-verify leg (0 = skip)")
     ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -214,13 +210,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    coll_dev = dev if args.backend == "nccl" else None      # gloo rehearsal gathers through host tensors
+    from bulletproofspp_amd.dist import all_gather_points
 
     n = 1 << args.log2n
     gpu = b.Bppp(local)
@@ -229,17 +232,17 @@ def main():
     torch.cuda.set_stream(work_stream)
     gpu.set_stream(work_stream.cuda_stream)
     dsc, dpts = make_inputs(gpu, torch, dev, n, seed=0xB9B9 + rank)
-    ones = torch.zeros((world, 4), dtype=torch.int64, device=dev)
-    ones[:, 0] = 1
-    gathered = torch.zeros((world, 8), dtype=torch.int64, device=dev)
+    ones_np = np.zeros((world, 4), dtype=np.uint64)
+    ones_np[:, 0] = 1
+
+    def combine(part):
+        """all-gather one 64-B partial point per rank (RCCL has no mod-p reduction) and add them with the library"""
+        allp = all_gather_points(points_to_array([part])[0], dist, coll_dev)
+        return gpu.msm(ones_np, np.ascontiguousarray(allp))
 
     def step():
         part = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), n, args.window)
-        if world == 1:
-            return part
-        mine = torch.from_numpy(points_to_array([part]).view(np.int64)).to(dev)
-        dist.all_gather_into_tensor(gathered, mine)          # 64 B per rank over xGMI; no mod-p reduce exists in RCCL
-        return gpu.msm_device(ones.data_ptr(), gathered.data_ptr(), world, 0)
+        return part if world == 1 else combine(part)
 
     for _ in range(args.warmup):
         res = step()
@@ -263,13 +266,13 @@ def main():
     stages, calls = gpu.profile_read(reset=True)
     gpu.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     verify = None
     if args.verify_batch > 0:
-        verify = bench_verify(gpu, torch, dev, rank, world, dist, args.verify_batch, args.verify_real, max(3, args.steps // 2), 1)
+        verify = bench_verify(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, args.verify_real, max(3, args.steps // 2), 1)
 
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
@@ -280,7 +283,7 @@ def main():
         achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.log2n == 20:    # the PMC passes were taken on the 2^20 workload
             try:
                 traffic = json.load(open(tpath)).get("k_acc_points_bytes_per_launch")
             except Exception:
