@@ -35,7 +35,7 @@ struct RecodeK { uint32_t k[9]; };
 
 // ------------------------------------------------------------------------------------------------
 // 1. digits
-__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint64_t total, uint32_t n, int c,
+__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint64_t total, uint32_t n, uint32_t stride, int c,
                                                 int W, RecodeK K, uint16_t *__restrict__ dig,
                                                 unsigned long long *__restrict__ negmask) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,9 +56,9 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
     sp[8] = (uint32_t)cy + K.k[8];
     uint32_t inst = (uint32_t)(i / n), j = (uint32_t)(i % n);
     uint32_t mask = (1u << c) - 1u;
-    size_t base = (size_t)inst * W * n + j;
+    size_t base = (size_t)inst * W * stride + j;
     for (int w = 0; w < W; w++) {
-      dig[base + (size_t)w * n] = (uint16_t)(sp[0] & mask);
+      dig[base + (size_t)w * stride] = (uint16_t)(sp[0] & mask);
 #pragma unroll
       for (int k = 0; k < 8; k++) sp[k] = (sp[k] >> c) | (sp[k + 1] << (32 - c));
       sp[8] >>= c;
@@ -70,17 +70,25 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
 
 // ------------------------------------------------------------------------------------------------
 // 2. counting sort by (instance, window, |digit|)
-__global__ void k_hist(const uint16_t *__restrict__ dig, uint32_t n, int c, int CH, uint32_t *__restrict__ blockhist) {
+// Both sort kernels read 8 consecutive u16 digits per lane with ONE 16-byte load (n is padded to a multiple of 8 in the
+// digit buffer's row stride), so each lane has 8 independent LDS atomics / stores in flight instead of a dependent
+// load -> atomic -> store chain per entry (the scattered stores are latency-, not bandwidth-bound).
+__global__ void k_hist(const uint16_t *__restrict__ dig, uint32_t n, uint32_t stride, int c, int CH, uint32_t *__restrict__ blockhist) {
   extern __shared__ uint32_t lh[];
   const int M = 1 << (c - 1);
   const uint32_t nbw = blockIdx.x, ch = blockIdx.y;
   for (int t = threadIdx.x; t < M; t += blockDim.x) lh[t] = 0;
   __syncthreads();
-  uint32_t per = (n + CH - 1) / CH, lo = ch * per, hi = min(n, lo + per);
-  const uint16_t *d = dig + (size_t)nbw * n;
-  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    int v = (int)d[j] - M;
-    if (v) atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+  uint32_t per = (((n + CH - 1) / CH) + 7u) & ~7u, lo = ch * per, hi = min(n, lo + per);
+  const uint16_t *d = dig + (size_t)nbw * stride;
+  for (uint32_t j0 = lo + threadIdx.x * 8; j0 < hi; j0 += blockDim.x * 8) {
+    uint4 pk = *reinterpret_cast<const uint4 *>(d + j0);
+    uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int v = (int)((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - M;
+      if (j0 + k < hi && v) atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+    }
   }
   __syncthreads();
   uint32_t *out = blockhist + ((size_t)nbw * CH + ch) * M;
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
   for (int k = 0; k < 16; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
-__global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long long *__restrict__ negmask, uint32_t n, int c,
+__global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long long *__restrict__ negmask, uint32_t n, uint32_t stride, int c,
                           int CH, int W, const uint32_t *__restrict__ blockhist, const uint32_t *__restrict__ start,
                           unsigned long long *__restrict__ sorted) {
   extern __shared__ uint32_t lh[];
@@ -164,19 +172,28 @@ __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long 
   const uint32_t *st = start + (size_t)nbw * M;
   for (int t = threadIdx.x; t < M; t += blockDim.x) lh[t] = st[t] + bh[t];
   __syncthreads();
-  uint32_t per = (n + CH - 1) / CH, lo = ch * per, hi = min(n, lo + per);
-  const uint16_t *d = dig + (size_t)nbw * n;
+  uint32_t per = (((n + CH - 1) / CH) + 7u) & ~7u, lo = ch * per, hi = min(n, lo + per);
+  const uint16_t *d = dig + (size_t)nbw * stride;
   const uint32_t inst = nbw / W;
-  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    int v = (int)d[j] - M;
-    if (v) {
-      uint32_t mb = (v < 0 ? -v : v) - 1;
-      uint64_t flat = (uint64_t)inst * n + j;
-      uint32_t sneg = (uint32_t)((negmask[flat >> 6] >> (flat & 63)) & 1ull);
-      uint32_t sg = (v < 0 ? 1u : 0u) ^ sneg;
-      uint32_t pos = atomicAdd(&lh[mb], 1u);
-      uint32_t key = nbw * M + mb;
-      sorted[pos] = ((unsigned long long)key << 32) | ((unsigned long long)sg << 31) | j;
+  for (uint32_t j0 = lo + threadIdx.x * 8; j0 < hi; j0 += blockDim.x * 8) {
+    uint4 pk = *reinterpret_cast<const uint4 *>(d + j0);
+    uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+    uint64_t flat0 = (uint64_t)inst * n + j0;
+    // sign bits of the 8 scalars: they may straddle two 64-bit words when inst*n is not a multiple of 8
+    unsigned long long m0 = negmask[flat0 >> 6], m1 = negmask[(flat0 + 7) >> 6];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int v = (int)((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - M;
+      if (j0 + k < hi && v) {
+        uint32_t mb = (v < 0 ? -v : v) - 1;
+        uint64_t flat = flat0 + k;
+        unsigned long long mw = ((flat >> 6) == (flat0 >> 6)) ? m0 : m1;
+        uint32_t sneg = (uint32_t)((mw >> (flat & 63)) & 1ull);
+        uint32_t sg = (v < 0 ? 1u : 0u) ^ sneg;
+        uint32_t pos = atomicAdd(&lh[mb], 1u);
+        uint32_t key = nbw * M + mb;
+        sorted[pos] = ((unsigned long long)key << 32) | ((unsigned long long)sg << 31) | (j0 + k);
+      }
     }
   }
 }
@@ -451,7 +468,8 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
   size_t need = 0;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv(pass ? ctx->ws : nullptr, ctx->ws_bytes);
-    uint16_t *dig = cv.take<uint16_t>(p.total_max);
+    const uint32_t stride = (uint32_t)((n + 7) & ~(size_t)7);     // digit rows are 16-byte aligned
+    uint16_t *dig = cv.take<uint16_t>((size_t)p.NB * stride + 8);
     unsigned long long *negmask = cv.take<unsigned long long>((batch * n + 63) / 64 + 1);
     uint32_t *blockhist = cv.take<uint32_t>((size_t)p.NB * p.CH * p.M);
     uint32_t *count = cv.take<uint32_t>(p.FB + 1);
@@ -480,16 +498,16 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     prof_mark(ctx, 0);
     // 1. digits
     uint64_t total_sc = (uint64_t)batch * n;
-    k_digits<<<dim3((unsigned)((total_sc + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_scalars, total_sc, (uint32_t)n, c, p.W,
+    k_digits<<<dim3((unsigned)((total_sc + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_scalars, total_sc, (uint32_t)n, stride, c, p.W,
                                                                             make_recode_k(c, p.W), dig, negmask);
     prof_mark(ctx, 1);
     // 2. sort
-    k_hist<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, (uint32_t)n, c, p.CH, blockhist);
+    k_hist<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, (uint32_t)n, stride, c, p.CH, blockhist);
     k_chunk_prefix<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(blockhist, p.M, p.CH, p.FB, count);
     k_scan_tile_sums<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles);
     k_scan_top<<<dim3(1), dim3(1024), 0, st>>>(tiles, (uint32_t)p.ntiles, start + p.FB);
     k_scan_apply<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles, start);
-    k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, c, p.CH, p.W, blockhist, start, sorted);
+    k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, stride, c, p.CH, p.W, blockhist, start, sorted);
     BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * XYZZ_WORDS * 4, st));
     BPPP_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     prof_mark(ctx, 2);
