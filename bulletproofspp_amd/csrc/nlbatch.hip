@@ -19,7 +19,8 @@
 namespace bppp {
 int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
 
-static constexpr int KT = 16;   // proofs per partial sum
+static constexpr int KT = 4;    // proofs per partial sum
+BPPP_DI fe frm(const fe &a, const fe &b) { return fe_mul<1>(a, b); }
 
 // factor table per proof: fac[b][r] = q_b^(2^r) (r < k), fac[b][k + r] = e_{b, first-round-first r}, and qF2 = (q^(2^k))^2
 __global__ void __launch_bounds__(64) k_vb_factors(const uint32_t *__restrict__ q, const uint32_t *__restrict__ es, uint32_t batch, int k,
@@ -48,10 +49,10 @@ BPPP_DI fe tensor_at(const uint32_t *vs, uint32_t nvs, const uint32_t *fac, int 
   return acc;
 }
 
-// partial[kt][i] = sum_{b in tile kt} rho_b * (pub[b][i] - tensor_b[i])      (shared-basis scalars)
-__global__ void __launch_bounds__(256) k_vb_shared(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
-                                                   uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
-                                                   uint32_t *__restrict__ partial) {
+// partial[kt][i] = sum_{b in tile kt} rho_b * (pub[b][i] - tensor_b[i])      (shared-basis scalars), one position per lane
+__global__ void __launch_bounds__(256) k_vb_shared1(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
+                                                    uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
+                                                    uint32_t *__restrict__ partial) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, kt = blockIdx.y;
   if (i >= len) return;
   fe acc = fe_zero();
@@ -63,12 +64,73 @@ __global__ void __launch_bounds__(256) k_vb_shared(const uint32_t *__restrict__ 
   }
   fe_store(partial + ((size_t)kt * len + i) * 8, acc);
 }
+// Same sums with 8 consecutive basis positions i0..i0+7 per lane (k >= 3): they share the tensor factors of rounds >= 3,
+// so the lane multiplies those once and expands the three low rounds by doubling in registers (2.4 multiplications per
+// output instead of k); rho is folded into the base value.
+#define VB_LVL(R, N)                                                   \
+  {                                                                    \
+    fe eq = fe_load(f + (size_t)(k + (R)) * 8), qq = fe_load(f + (size_t)(R) * 8); \
+    _Pragma("unroll") for (int j = 0; j < (N); j++) {                  \
+      t[j + (N)] = frm(eq, t[j]);                                      \
+      if (use_q) t[j] = frm(qq, t[j]);                                 \
+    }                                                                  \
+  }
+__global__ void __launch_bounds__(64) k_vb_shared8(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
+                                                   uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
+                                                   uint32_t *__restrict__ partial) {
+  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8, kt = blockIdx.y;
+  if (i0 >= len) return;
+  fe acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; o++) acc[o] = fe_zero();
+  uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
+  for (uint32_t b = b0; b < b1; b++) {
+    const uint32_t *f = fac + (size_t)b * 2 * k * 8;
+    const fe r = fe_load(rho + (size_t)b * 8);
+    fe t[8];
+    uint32_t hi = i0 >> k;
+    bool live = hi < nvs;                                  // zipWithDef' default 0 beyond the tensor (src/Utils.hs:182-184)
+#pragma unroll
+    for (int o = 0; o < 8; o++) t[o] = fe_zero();
+    if (live) {
+      fe base = frm(r, fe_load(wit + ((size_t)b * nvs + hi) * 8));
+      for (int rr = 3; rr < k; rr++) {
+        bool bit = (i0 >> rr) & 1u;
+        if (bit) base = frm(base, fe_load(f + (size_t)(k + rr) * 8));
+        else if (use_q) base = frm(base, fe_load(f + (size_t)rr * 8));
+      }
+      t[0] = base;
+      VB_LVL(0, 1)
+      VB_LVL(1, 2)
+      VB_LVL(2, 4)
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      if (i0 + o < len) {
+        fe d = frm(r, fe_load(pub + ((size_t)b * len + i0 + o) * 8));
+        acc[o] = fe_add<1>(acc[o], fe_sub<1>(d, t[o]));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 8; o++)
+    if (i0 + o < len) fe_store(partial + ((size_t)kt * len + i0 + o) * 8, acc[o]);
+}
+
+// column sums of partial[ntiles][len]: blockIdx.y strides over the tiles, the 4 wavefronts of a block take every 4th tile
 __global__ void __launch_bounds__(256) k_vb_sum_partials(const uint32_t *__restrict__ partial, uint32_t ntiles, uint32_t len, uint32_t *__restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len) return;
+  __shared__ uint32_t lds[256 * 8];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t i = blockIdx.x * 64 + lane;
   fe acc = fe_zero();
-  for (uint32_t t = 0; t < ntiles; t++) acc = fe_add<1>(acc, fe_load(partial + ((size_t)t * len + i) * 8));
-  fe_store(out + (size_t)i * 8, acc);
+  if (i < len)
+    for (uint32_t t = wv; t < ntiles; t += 4) acc = fe_add<1>(acc, fe_load(partial + ((size_t)t * len + i) * 8));
+  for (int q = 0; q < 8; q++) lds[threadIdx.x * 8 + q] = acc.v[q];
+  __syncthreads();
+  if (wv == 0 && i < len) {
+    for (int w = 1; w < 4; w++) { fe o; for (int q = 0; q < 8; q++) o.v[q] = lds[(w * 64 + lane) * 8 + q]; acc = fe_add<1>(acc, o); }
+    fe_store(out + (size_t)i * 8, acc);
+  }
 }
 
 // per proof: gs[b] = rho_b * (sp_b - sc_b), sc_b = sum_i (qF^2)^(i+1) vs_i^2 + sum_j c_j * tensor_lin[j]
@@ -170,16 +232,14 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
   do {
     k_vb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_q, (const uint32_t *)d_es, (uint32_t)batch, (int)k, fac, qf2);
     if (nlen) {
-      k_vb_shared<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm,
-                                                                                     (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch,
-                                                                                     (uint32_t)nlen, (int)k, 1, partial);
-      k_vb_sum_partials<<<dim3((unsigned)((nlen + 255) / 256)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)nlen, sc);
+      if (k >= 3) k_vb_shared8<<<dim3((unsigned)((nlen + 511) / 512), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
+      else k_vb_shared1<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
+      k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)nlen, sc);
     }
     if (llen) {
-      k_vb_shared<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x,
-                                                                                     (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch,
-                                                                                     (uint32_t)llen, (int)k, 0, partial);
-      k_vb_sum_partials<<<dim3((unsigned)((llen + 255) / 256)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)llen, sc + nlen * 8);
+      if (k >= 3) k_vb_shared8<<<dim3((unsigned)((llen + 511) / 512), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)llen, sc + nlen * 8);
     }
     k_vb_proof<<<dim3((unsigned)batch), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf2, (const uint32_t *)d_wit_norm, (uint32_t)fn,
                                                             (const uint32_t *)d_wit_lin, (uint32_t)fl, (const uint32_t *)d_pub_lin_c, (uint32_t)llen, fac, (int)k,
