@@ -401,16 +401,16 @@ static int choose_window(size_t n) {
   // Cost model in units of one mixed addition (~68 ps chip-wide, measured at 2^20; profiles/):
   //   accumulate: one addition per (scalar, window that holds real bits): ceil(255/c) windows (+ half a window when
   //               c divides 255: the top digit then wraps for half the scalars and a carry window appears);
-  //   reduce:     ~7 per bucket (the wave-prefix bucket reduction is latency-bound; fitted at c = 13..16);
+  //   reduce:     ~10 per bucket (the wave-prefix bucket reduction is latency-bound; fitted at c = 13..16);
   //   heavy top:  when the top window has few real bits its buckets hold n / 2^r entries each and go through the
-  //               wave-cooperative merge tree: a flat ~3e6 (0.2 ms) once they span many lanes.
+  //               wave-cooperative merge tree: a flat ~1.5e6 (0.1 ms) once they span many lanes.
   double best = 1e300; int bc = 8;
   for (int c = 4; c <= 16; c++) {
     int W = 256 / c + 1, full = 254 / c, r = 255 - c * full;       // r = real bits in the top window (1..c)
     double weff = full + 1 + (r == c ? 0.5 : 0.0);
-    double cost = weff * (double)n + 7.0 * W * (double)(1u << (c - 1));
+    double cost = weff * (double)n + 10.0 * W * (double)(1u << (c - 1));
     double top_bucket = r == c ? n / 2.0 : (double)n / (double)(1u << (r < 20 ? r : 20));
-    if ((r == c || r < c - 1) && top_bucket > 1024.0) cost += 3.0e6;
+    if ((r == c || r < c - 1) && top_bucket > 1024.0) cost += 1.5e6;
     if (cost < best) { best = cost; bc = c; }
   }
   return bc;
