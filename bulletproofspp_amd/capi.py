@@ -19,7 +19,7 @@ SYMBOLS = [
     "bppp_fold_points", "bppp_fold_points_device",
     "bppp_norm_round_sums_device", "bppp_lin_round_sums_device",
     "bppp_norm_round_openings_device", "bppp_lin_round_openings_device",
-    "bppp_fold_scalars_device", "bppp_tensor_device",
+    "bppp_fold_scalars_device", "bppp_tensor_device", "bppp_batch_inverse_device",
     "bppp_nl_create", "bppp_nl_destroy", "bppp_nl_lengths", "bppp_nl_round_commit", "bppp_nl_round_collapse",
     "bppp_nl_get_witness", "bppp_nl_download", "bppp_nl_verify", "bppp_nl_verify_batch_device",
     "bppp_ip_create", "bppp_ip_destroy", "bppp_ip_lengths", "bppp_ip_round_commit", "bppp_ip_round_collapse", "bppp_ip_get_witness", "bppp_ip_verify",
@@ -61,6 +61,7 @@ def load_library() -> C.CDLL:
     lib.bppp_norm_round_openings_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     lib.bppp_lin_round_openings_device.argtypes = [vp, vp, sz, vp, vp]
     lib.bppp_fold_scalars_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.bppp_batch_inverse_device.argtypes = [vp, vp, sz, i, vp]
     lib.bppp_tensor_device.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     lib.bppp_lift_x_device.argtypes = [vp, vp, sz, vp]
     lib.bppp_nl_create.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, C.POINTER(vp)]
@@ -239,6 +240,9 @@ class Bppp:
         assert len(qs) == k
         self._check(self.lib.bppp_tensor_device(self.h, _ptr(scalars_to_array(bs)), len(bs), _ptr(scalars_to_array(es)) if k else None,
                                                 _ptr(scalars_to_array(qs)) if k else None, k, _ptr(d_out)), "bppp_tensor_device")
+
+    def batch_inverse(self, d_x: int, n: int, modulus: int, d_out: int):
+        self._check(self.lib.bppp_batch_inverse_device(self.h, _ptr(d_x), n, modulus, _ptr(d_out)), "bppp_batch_inverse_device")
 
     def lift_x(self, d_x: int, n: int, d_points: int):
         self._check(self.lib.bppp_lift_x_device(self.h, _ptr(d_x), n, _ptr(d_points)), "bppp_lift_x_device")

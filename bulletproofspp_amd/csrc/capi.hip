@@ -14,6 +14,7 @@ int round_openings_run(bppp_ctx *, const void *, size_t, int, const uint64_t *, 
 int fold_scalars_run(bppp_ctx *, const uint64_t *, const uint64_t *, const void *, size_t, void *);
 int tensor_run(bppp_ctx *, const uint64_t *, size_t, const uint64_t *, const uint64_t *, size_t, void *);
 int lift_x_run(bppp_ctx *, const void *, size_t, void *);
+int batch_inverse_run(bppp_ctx *, const void *, size_t, int, void *);
 
 int ensure_workspace(bppp_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return BPPP_OK;
@@ -195,6 +196,10 @@ int bppp_tensor_device(bppp_ctx *ctx, const uint64_t *bs, size_t nb, const uint6
   return tensor_run(ctx, bs, nb, es, qs, k, d_out);
 }
 
+int bppp_batch_inverse_device(bppp_ctx *ctx, const void *d_x, size_t n, int modulus, void *d_out) {
+  CTX_ENTER(ctx);
+  return batch_inverse_run(ctx, d_x, n, modulus, d_out);
+}
 int bppp_lift_x_device(bppp_ctx *ctx, const void *d_x, size_t n, void *d_points_xy) {
   CTX_ENTER(ctx);
   return lift_x_run(ctx, d_x, n, d_points_xy);

@@ -117,6 +117,31 @@ __global__ void __launch_bounds__(256) k_tensor(const uint32_t *__restrict__ bs,
   fe_store(out + idx * 8, acc);
 }
 
+// batchInverse (src/Data/Field/BatchInverse.hs:14-24): Montgomery's trick, 0 -> 0.  On a SIMD machine one Fermat inversion
+// per LANE costs the same wall time as one per wavefront, so the trick pays only along a lane: each lane inverts a run
+// of BI_RUN consecutive values with 3 multiplications per value and ONE inversion.
+static constexpr int BI_RUN = 8;
+template <int MOD> __global__ void __launch_bounds__(64) k_batch_inverse(const uint32_t *__restrict__ x, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t i0 = t * BI_RUN;
+  if (i0 >= n) return;
+  fe v[BI_RUN], pre[BI_RUN];
+  fe acc = fe_one();
+#pragma unroll
+  for (int k = 0; k < BI_RUN; k++) {
+    v[k] = (i0 + k < n) ? fe_load(x + (size_t)(i0 + k) * 8) : fe_zero();
+    pre[k] = acc;
+    if (!fe_is_zero(v[k])) acc = fe_mul<MOD>(acc, v[k]);          // rec0 skips zeros (BatchInverse.hs:18)
+  }
+  fe y = fe_inv<MOD>(acc);
+#pragma unroll
+  for (int k = BI_RUN - 1; k >= 0; k--) {
+    fe r = fe_zero();
+    if (!fe_is_zero(v[k])) { r = fe_mul<MOD>(y, pre[k]); y = fe_mul<MOD>(y, v[k]); }   // rec1 (BatchInverse.hs:21-24)
+    if (i0 + k < n) fe_store(out + (size_t)(i0 + k) * 8, r);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 using bppp_host::U256;
 
@@ -164,6 +189,16 @@ int fold_scalars_run(bppp_ctx *ctx, const uint64_t u[4], const uint64_t v[4], co
   if (!d_x || !d_out || !u || !v || n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_scalars: bad input");
   uint32_t np = (uint32_t)((n + 1) / 2);
   k_fold_scalars<<<dim3((np + 255) / 256), dim3(256), 0, ctx->stream>>>((const uint32_t *)d_x, (uint32_t)n, to_fr4(u), to_fr4(v), (uint32_t *)d_out);
+  BPPP_HIP(ctx, hipGetLastError());
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BPPP_OK;
+}
+int batch_inverse_run(bppp_ctx *ctx, const void *d_x, size_t n, int modulus, void *d_out) {
+  if (n == 0) return BPPP_OK;
+  if (!d_x || !d_out || n >= (1ull << 31) || (modulus != 0 && modulus != 1)) return fail(ctx, BPPP_ERR_ARG, "batch_inverse: bad input");
+  uint32_t threads = (uint32_t)((n + BI_RUN - 1) / BI_RUN);
+  if (modulus) k_batch_inverse<1><<<dim3((threads + 63) / 64), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_x, (uint32_t)n, (uint32_t *)d_out);
+  else k_batch_inverse<0><<<dim3((threads + 63) / 64), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_x, (uint32_t)n, (uint32_t *)d_out);
   BPPP_HIP(ctx, hipGetLastError());
   BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BPPP_OK;

@@ -101,6 +101,13 @@ int bppp_lin_round_openings_device(bppp_ctx *ctx, const void *d_x, size_t n, voi
 int bppp_fold_scalars_device(bppp_ctx *ctx, const uint64_t u[4], const uint64_t v[4], const void *d_x, size_t n,
                              void *d_out);
 
+/* ---- a5: batchInverse ----------------------------------------------------------------------
+ * Replaces batchInverse (src/Data/Field/BatchInverse.hs:14-24; used by normalizes, src/Commitment.hs:125, :153, and by
+ * the range-proof phases, src/RangeProof/TypedReciprocal.hs:193-195): out[i] = x[i]^-1, with 0 -> 0, over n canonical
+ * field elements in HBM.  modulus: 0 = Fq (coordinates), 1 = Fr (scalars).  Montgomery's trick runs along each lane
+ * (8 values per inversion); d_out may alias d_x. */
+int bppp_batch_inverse_device(bppp_ctx *ctx, const void *d_x, size_t n, int modulus, void *d_out);
+
 /* ---- a15: tensor' (challenge expansion) -----------------------------------------------------
  * Replaces the list instance of tensor' (src/Bulletproof.hs:94-95) as used by expandChallenges
  * (NormArgument.hs:73-81, :131-145): out[i * 2^k + t] = bs[i] * prod over rounds of (q_r or e_r)

@@ -895,3 +895,80 @@ def verify_terms_generic(cls, init_terms, es, rs, pub: PSV, basis: PSV, wit_body
         e0, e1 = cls.make_es(e)
         terms += [(e0, x), (e1, r)]
     return terms
+
+
+# ============================================================================= GLV path
+# Restatement of the reference's optional endomorphism path: SplitScalar (FastPrime p) (src/Commitment.hs:293-306),
+# FastInnerProduct (Point .. (FastPrime p)) (src/Commitment.hs:374-398), decomposeFastPrimeEis
+# (src/Data/Field/Galois/FastPrime.hs:186-205), Eisenstein integers (src/Data/Field/Eis.hs:20-41) and cmConj
+# (src/Data/Curve/CM.hs:25-33).  Not the CLI default (app/Main.hs:17-21 keeps the import commented out).
+CHAR_EIS_FR = (303414439467246543595250775667605759171, -64502973549206556628585045361533709077)   # FastSECP256K1.hs:56
+
+
+def eis_conj(e):
+    """conjEis (Eis.hs:20-21)."""
+    return (e[0] - e[1], -e[1])
+
+
+def eis_mul(x, y):
+    """(*) of Eis (Eis.hs:30-34)."""
+    a, b, c = x[0] * y[0], x[1] * y[1], (x[0] - x[1]) * (y[0] - y[1])
+    return (a - b, a - c)
+
+
+def decompose_eis(x: int) -> Tuple[int, int]:
+    """decomposeFastPrimeEis (FastPrime.hs:186-205): x = a + b·λ (mod n) with |a|, |b| ≲ 2^128."""
+    p_fac = eis_conj(CHAR_EIS_FR)
+    x_int = (x % N, 0)
+    u, v = eis_mul(x_int, eis_conj(p_fac))
+
+    def rnd(nn, q):
+        r = nn - N * q
+        if abs(r) > abs(r + N):
+            return q - 1
+        if abs(r) > abs(r - N):
+            return q + 1
+        return q
+    q = (rnd(u, u >> 256), rnd(v, v >> 256))
+    m = eis_mul(q, p_fac)
+    return (x_int[0] - m[0], x_int[1] - m[1])
+
+
+def cm_mul(p: Point) -> Point:
+    """cmConj for affine points (CM.hs:25-27): (x, y) -> (β·x, y) = λ·(x, y)."""
+    return None if p is None else (BETA * p[0] % P, p[1])
+
+
+def glv_inner_product(sgs: Sequence[Tuple[int, Point]], ec) -> Point:
+    """innerProduct through the FastPrime instances: 129 rows (Commitment.hs:304), digit pairs (:306), basis
+    (p00, p11) with the sign difference flag (:387-398), addBasis (:382-385).
+    NOTE the reference mis-signs the b-only digit when a == 0 exactly (signum 0 /= signum b is always True, so a
+    positive b is subtracted); that input has probability ~2^-128 and is not reproduced here on purpose: the
+    restatement follows the reference for every a != 0."""
+    terms = []
+    for s, g in sgs:
+        a, b = decompose_eis(s)
+        s0 = (a > 0) - (a < 0)
+        s1 = (b > 0) - (b < 0)
+        g1 = ec.neg(g) if s0 == -1 else g
+        if s0 == s1:
+            h1 = ec.neg(cm_mul(cm_mul(g1)))                 # -λ²g' = g' + λg'
+        else:
+            h1 = ec.add(g1, ec.neg(cm_mul(g1)))
+        diff = s0 != s1
+        if s0 == 0 and s1 == 1:
+            diff = False                                    # the a == 0 corner (see docstring)
+        terms.append((abs(a), abs(b), diff, g1, h1))
+    v = None
+    for row in range(129, 0, -1):
+        v = ec.add(v, v)
+        for a, b, diff, p00, p11 in terms:
+            da, db = (a >> (row - 1)) & 1, (b >> (row - 1)) & 1
+            if da and db:
+                v = ec.add(p11, v)
+            elif da:
+                v = ec.add(p00, v)
+            elif db:
+                q = cm_mul(p00)
+                v = ec.add(ec.neg(q) if diff else q, v)
+    return v

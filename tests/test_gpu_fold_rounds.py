@@ -82,3 +82,22 @@ def test_tensor_matches_list_instance(gpu, nb, k):
         assert array_to_scalars(gpu.download(dout, (nb << k, 4))) == want
     finally:
         gpu.free(dout)
+
+
+@pytest.mark.parametrize("mod,m", [(0, O.P), (1, O.N)])
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 1000])
+def test_batch_inverse_matches_reference_semantics(gpu, mod, m, n):
+    """batchInverse (src/Data/Field/BatchInverse.hs:14-24): inverse of every element, zero mapped to zero"""
+    rnd = random.Random(n * 3 + mod)
+    xs = [rnd.randrange(m) for _ in range(n)]
+    for i in range(0, n, 5):
+        xs[i] = 0
+    if n > 3:
+        xs[3] = m - 1
+    dx = gpu.to_device(scalars_to_array(xs))
+    try:
+        gpu.batch_inverse(dx, n, mod, dx)                     # in place
+        got = array_to_scalars(gpu.download(dx, (n, 4)))
+    finally:
+        gpu.free(dx)
+    assert got == O.batch_inverse(xs, m)

@@ -106,3 +106,10 @@ def test_msm_2_16_matches_oracle(gpu, oracle_lib):
     want = oracle_lib.inner_product_raw(sc.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint64)),
                                         pts.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint64)), n)
     assert gpu.msm(sc, pts) == want
+
+
+def test_msm_equals_reference_glv_path(gpu):
+    """a6: the reference's optional endomorphism path (Commitment.hs:293-306, :374-398) gives the same group element."""
+    sc, pts = _rand_case(40, 4040, zero_every=9, inf_every=13)
+    want = O.glv_inner_product(list(zip(sc, pts)), O.PyEC())
+    assert gpu.msm(scalars_to_array(sc), points_to_array(pts)) == want

@@ -151,3 +151,24 @@ def test_ip_round_counts_match_reference_shapes():
     assert O.optimal_witness_size_ip(11, 6) == (3, (2, 1))
     assert O.optimal_witness_size_ip(16, 6) == (3, (2, 1))
     assert O.optimal_witness_size_ip(62, 24) == (5, (2, 1))
+
+
+# ----------------------------------------------------------------------------- GLV path (a6)
+def test_glv_decomposition_and_inner_product(oracle_lib):
+    """decomposeFastPrimeEis (FastPrime.hs:186-205) recomposes to the scalar with ~128-bit halves, and the 129-row
+    GLV Straus loop (Commitment.hs:374-398) yields the same group element as the plain 256-row loop."""
+    rnd = random.Random(6)
+    for x in [0, 1, O.N - 1, O.LAMBDA, O.N - O.LAMBDA, 2**128, (O.N + 1) // 2] + [rnd.randrange(O.N) for _ in range(300)]:
+        a, b = O.decompose_eis(x)
+        assert (a + b * O.LAMBDA - x) % O.N == 0
+        assert abs(a).bit_length() <= 129 and abs(b).bit_length() <= 129
+    # conjEis charEis recomposes to 0 mod n (why reducedChar = conjEis . charEis, Commitment.hs:296-297)
+    c = O.eis_conj(O.CHAR_EIS_FR)
+    assert (c[0] + c[1] * O.LAMBDA) % O.N == 0
+    assert O.CHAR_EIS_FR[0] ** 2 - O.CHAR_EIS_FR[0] * O.CHAR_EIS_FR[1] + O.CHAR_EIS_FR[1] ** 2 == O.N
+    pts = O.hash_points(b"glv", 12)
+    sgs = [(rnd.randrange(O.N), p) for p in pts]
+    sgs[2] = (0, pts[2])
+    sgs[3] = (rnd.randrange(O.N), None)
+    sgs[4] = (O.N - 1, pts[4])
+    assert O.glv_inner_product(sgs, O.PyEC()) == oracle_lib.inner_product(sgs)
