@@ -100,6 +100,37 @@ def proveBPM(n_rounds: int, com: NormLinearBP, oracle: OracleFn):
     return resps, es
 
 
+ORACLE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64))
+
+
+def _wrap_oracle(fn: OracleFn):
+    """adapts a Python oracle (list of points, newest first -> scalar) to bppp_oracle_fn"""
+    def cb(_user, pts, n, out):
+        arr = np.ctypeslib.as_array(pts, shape=(n, 8))
+        e = fn([array_to_point(arr[i]) for i in range(n)]) % N_ORDER
+        for k_, v in enumerate(int_to_limbs(e)):
+            out[k_] = int(v)
+    return ORACLE_CB(cb)
+
+
+def proveBPM_native(n_rounds: int, com: NormLinearBP, oracle_whole_transcript: OracleFn, transcript: Sequence[Point] = ()):
+    """src/Bulletproof.hs:357-359 through bppp_nl_prove: the round loop runs in the library (C++), calling back into the
+    injected oracle once per round with the whole transcript (newest first), exactly as ZKPT does (src/ZKP.hs:96-101)."""
+    gpu = com.gpu
+    cap = len(transcript) + 2 * n_rounds + 2
+    tr = np.zeros((cap, 8), dtype=np.uint64)
+    if len(transcript):
+        tr[:len(transcript)] = points_to_array(list(transcript))
+    ntr = C.c_size_t(len(transcript))
+    resp = np.zeros((max(n_rounds, 1), 16), dtype=np.uint64)
+    es = np.zeros((max(n_rounds, 1), 4), dtype=np.uint64)
+    cb = _wrap_oracle(oracle_whole_transcript)
+    rc = gpu.lib.bppp_nl_prove(com.h, n_rounds, C.cast(cb, C.c_void_p), None, _ptr(tr), C.byref(ntr), cap, _ptr(resp), _ptr(es))
+    gpu._check(rc, "bppp_nl_prove")
+    resps = [(array_to_point(resp[i, :8]), array_to_point(resp[i, 8:])) for i in range(n_rounds)]
+    return resps, array_to_scalars(es)[:n_rounds], [array_to_point(tr[i]) for i in range(ntr.value)]
+
+
 def verifyBPM(gpu: Bppp, q: int, sp: int, g: Point, pub_norm: Sequence[int], ngs: Sequence[Point], pub_lin_c: Sequence[int],
               pub_lin_x: Sequence[int], lgs: Sequence[Point], es: Sequence[int], responses: Sequence[Tuple[Point, Point]],
               wit_norm: Sequence[int], wit_lin: Sequence[int], init_terms: Sequence[Tuple[int, Point]]) -> bool:

@@ -33,6 +33,31 @@ __global__ void __launch_bounds__(64) k_fold_points(const uint32_t *__restrict__
   aff_store(out + (size_t)j * 16, xyzz_to_aff(acc));
 }
 
+// Several independent folds in ONE launch (norm basis, linear basis, ... of one collapse): each workgroup belongs to one
+// segment, so the row schedule is still wave-uniform; the folds' ~1.5 ms dependency chains then run side by side
+// instead of back to back.
+struct FoldSeg { FoldK K; const uint32_t *pts; uint32_t *out; uint32_t n, first_block; };
+struct FoldSegs { FoldSeg s[3]; int nseg; };
+__global__ void __launch_bounds__(64) k_fold_points_multi(FoldSegs S) {
+  int si = 0;
+  if (S.nseg > 1 && blockIdx.x >= S.s[1].first_block) si = 1;
+  if (S.nseg > 2 && blockIdx.x >= S.s[2].first_block) si = 2;
+  const FoldSeg &sg = S.s[si];
+  uint32_t j = (blockIdx.x - sg.first_block) * blockDim.x + threadIdx.x;
+  uint32_t np = (sg.n + 1) / 2;
+  if (j >= np) return;
+  aff GL = aff_cneg(aff_load(sg.pts + (size_t)(2 * j) * 16), sg.K.bneg != 0);
+  aff GR = aff_inf();
+  if (2 * j + 1 < sg.n) GR = aff_cneg(aff_load(sg.pts + (size_t)(2 * j + 1) * 16), sg.K.aneg != 0);
+  xyzz acc = xyzz_inf();
+  for (int row = 128; row >= 0; row--) {
+    acc = xyzz_dbl(acc);
+    if ((sg.K.b[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GL);
+    if ((sg.K.a[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GR);
+  }
+  aff_store(sg.out + (size_t)j * 16, xyzz_to_aff(acc));
+}
+
 // pointX (app/Main.hs:68-72): y = sqrt(x^3 + 7) = (x^3+7)^((p+1)/4) since p = 3 mod 4; even root.
 __global__ void __launch_bounds__(64) k_lift_x(const uint32_t *__restrict__ xs, uint32_t n, uint32_t *__restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,21 +94,45 @@ int lift_x_run(bppp_ctx *ctx, const void *d_x, size_t n, void *d_out) {
   return BPPP_OK;
 }
 
-int fold_points_run(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
-                    const void *d_pts, size_t n, void *d_out) {
-  if (n == 0) return BPPP_OK;
-  if (!d_pts || !d_out || !b_mag || !a_mag) return fail(ctx, BPPP_ERR_ARG, "fold_points: null pointer");
-  if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_points: n too large");
-  FoldK K; memset(&K, 0, sizeof K);
+static int make_fold_k(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg, FoldK &K) {
+  memset(&K, 0, sizeof K);
   for (int i = 0; i < 3; i++) {
     if (2 * i < 5) K.b[2 * i] = (uint32_t)b_mag[i];
     if (2 * i + 1 < 5) K.b[2 * i + 1] = (uint32_t)(b_mag[i] >> 32);
     if (2 * i < 5) K.a[2 * i] = (uint32_t)a_mag[i];
     if (2 * i + 1 < 5) K.a[2 * i + 1] = (uint32_t)(a_mag[i] >> 32);
   }
-  // magnitudes must fit the 129 rows the reference walks
   if ((b_mag[2] >> 1) || (a_mag[2] >> 1)) return fail(ctx, BPPP_ERR_ARG, "fold_points: reduced scalar exceeds 129 bits");
   K.bneg = b_neg; K.aneg = a_neg;
+  return BPPP_OK;
+}
+// up to three folds in one launch; entries with n == 0 are skipped.  No stream synchronisation.
+int fold_points_multi_run(bppp_ctx *ctx, int nseg, const uint64_t *const b_mag[], const int b_neg[], const uint64_t *const a_mag[], const int a_neg[],
+                          const void *const d_pts[], const size_t n[], void *const d_out[]) {
+  FoldSegs S; memset(&S, 0, sizeof S);
+  uint32_t blocks = 0;
+  for (int i = 0; i < nseg && i < 3; i++) {
+    if (!n[i]) continue;
+    if (!d_pts[i] || !d_out[i] || n[i] >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_points_multi: bad segment");
+    FoldSeg &sg = S.s[S.nseg];
+    int rc = make_fold_k(ctx, b_mag[i], b_neg[i], a_mag[i], a_neg[i], sg.K); if (rc) return rc;
+    sg.pts = (const uint32_t *)d_pts[i]; sg.out = (uint32_t *)d_out[i]; sg.n = (uint32_t)n[i]; sg.first_block = blocks;
+    blocks += (uint32_t)(((n[i] + 1) / 2 + 63) / 64);
+    S.nseg++;
+  }
+  if (!S.nseg) return BPPP_OK;
+  k_fold_points_multi<<<dim3(blocks), dim3(64), 0, ctx->stream>>>(S);
+  BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
+
+int fold_points_run(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
+                    const void *d_pts, size_t n, void *d_out) {
+  if (n == 0) return BPPP_OK;
+  if (!d_pts || !d_out || !b_mag || !a_mag) return fail(ctx, BPPP_ERR_ARG, "fold_points: null pointer");
+  if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_points: n too large");
+  FoldK K;
+  { int rc = make_fold_k(ctx, b_mag, b_neg, a_mag, a_neg, K); if (rc) return rc; }
   uint32_t np = (uint32_t)((n + 1) / 2);
   k_fold_points<<<dim3((np + 63) / 64), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_pts, (uint32_t)n, K, (uint32_t *)d_out);
   BPPP_HIP(ctx, hipGetLastError());

@@ -18,7 +18,8 @@
 namespace bppp {
 int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
 int fold_points_run(bppp_ctx *, const uint64_t *, int, const uint64_t *, int, const void *, size_t, void *);
-int fold_scalars_run(bppp_ctx *, const uint64_t *, const uint64_t *, const void *, size_t, void *);
+int fold_scalars_launch(bppp_ctx *, const uint64_t *, const uint64_t *, const void *, size_t, void *);
+int fold_points_multi_run(bppp_ctx *, int, const uint64_t *const[], const int[], const uint64_t *const[], const int[], const void *const[], const size_t[], void *const[]);
 int tensor_run(bppp_ctx *, const uint64_t *, size_t, const uint64_t *, const uint64_t *, size_t, void *);
 
 struct FrA { uint32_t v[8]; };
@@ -296,31 +297,37 @@ int bppp_ip_round_collapse(bppp_ip *ip, const uint64_t e_[4]) {
   IP_HIP(ip, hipMemsetAsync(ip->P[d], 0, ip->cap * 64, st));
   uint64_t u[4], v[4];
   int rc;
+  std::pair<SInt, SInt> ab, cd, abl;
+  const uint64_t *bm[3], *am[3]; int bn[3], an[3]; const void *src[3]; void *dst[3]; size_t cnt[3]; int nseg = 0;
   if (ip->m) {
-    auto ab = rational_reduce_scalar(mmul(ip->qinv, ei, M));
+    ab = rational_reduce_scalar(mmul(ip->qinv, ei, M));
     U256 b0 = extract_scalar(ab.second), b0i = minv(b0, M);
-    auto cd = rational_reduce_scalar(e);
+    cd = rational_reduce_scalar(e);
     U256 d0 = extract_scalar(cd.second), d0i = minv(d0, M);
     b0i.store(u); mmul(b0i, mmul(e, ip->q, M), M).store(v);
-    rc = fold_scalars_run(ctx, u, v, ip->x[c], ip->m, ip->x[d]); if (rc) return rc;
+    rc = fold_scalars_launch(ctx, u, v, ip->x[c], ip->m, ip->x[d]); if (rc) return rc;
     d0i.store(u); mmul(d0i, ei, M).store(v);
-    rc = fold_scalars_run(ctx, u, v, ip->y[c], ip->m, ip->y[d]); if (rc) return rc;
-    rc = fold_points_run(ctx, ab.second.m, ab.second.neg, ab.first.m, ab.first.neg, ip->P[c], ip->m, ip->P[d]); if (rc) return rc;
-    rc = fold_points_run(ctx, cd.second.m, cd.second.neg, cd.first.m, cd.first.neg, ip->P[c] + me * 16, ip->m, ip->P[d] + me2 * 16); if (rc) return rc;
+    rc = fold_scalars_launch(ctx, u, v, ip->y[c], ip->m, ip->y[d]); if (rc) return rc;
+    bm[nseg] = ab.second.m; bn[nseg] = ab.second.neg; am[nseg] = ab.first.m; an[nseg] = ab.first.neg;
+    src[nseg] = ip->P[c]; dst[nseg] = ip->P[d]; cnt[nseg] = ip->m; nseg++;
+    bm[nseg] = cd.second.m; bn[nseg] = cd.second.neg; am[nseg] = cd.first.m; an[nseg] = cd.first.neg;
+    src[nseg] = ip->P[c] + me * 16; dst[nseg] = ip->P[d] + me2 * 16; cnt[nseg] = ip->m; nseg++;
     ip->ny = mmul(ip->ny, d0, M);
     ip->nx = mmul(mmul(ip->nx, b0, M), ip->qinv, M);
     ip->q = mmul(ip->q, ip->q, M); ip->qinv = mmul(ip->qinv, ip->qinv, M);
   }
   if (ip->l) {
-    auto ab = rational_reduce_scalar(ei);
-    U256 a0 = extract_scalar(ab.first), b0 = extract_scalar(ab.second), b0i = minv(b0, M);
+    abl = rational_reduce_scalar(ei);
+    U256 a0 = extract_scalar(abl.first), b0 = extract_scalar(abl.second), b0i = minv(b0, M);
     b0.store(u); a0.store(v);
-    rc = fold_scalars_run(ctx, u, v, ip->lc[c], ip->l, ip->lc[d]); if (rc) return rc;
+    rc = fold_scalars_launch(ctx, u, v, ip->lc[c], ip->l, ip->lc[d]); if (rc) return rc;
     b0i.store(u); mmul(e, b0i, M).store(v);
-    rc = fold_scalars_run(ctx, u, v, ip->lx[c], ip->l, ip->lx[d]); if (rc) return rc;
-    rc = fold_points_run(ctx, ab.second.m, ab.second.neg, ab.first.m, ab.first.neg, ip->P[c] + 2 * me * 16, ip->l, ip->P[d] + 2 * me2 * 16); if (rc) return rc;
+    rc = fold_scalars_launch(ctx, u, v, ip->lx[c], ip->l, ip->lx[d]); if (rc) return rc;
+    bm[nseg] = abl.second.m; bn[nseg] = abl.second.neg; am[nseg] = abl.first.m; an[nseg] = abl.first.neg;
+    src[nseg] = ip->P[c] + 2 * me * 16; dst[nseg] = ip->P[d] + 2 * me2 * 16; cnt[nseg] = ip->l; nseg++;
     ip->ln = mmul(ip->ln, b0, M);
   }
+  rc = fold_points_multi_run(ctx, nseg, bm, bn, am, an, src, cnt, dst); if (rc) return rc;
   IP_HIP(ip, hipMemcpyAsync(ip->P[d] + (2 * me2 + le2) * 16, ip->P[c] + (2 * me + le) * 16, 64, hipMemcpyDeviceToDevice, st));
   IP_HIP(ip, hipStreamSynchronize(st));
   ip->m = ip->m ? m2 : 0; ip->l = ip->l ? l2 : 0; ip->cur = d;

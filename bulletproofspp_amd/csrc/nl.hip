@@ -26,7 +26,8 @@ int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, ui
 int fold_points_run(bppp_ctx *, const uint64_t *, int, const uint64_t *, int, const void *, size_t, void *);
 int norm_round_sums_run(bppp_ctx *, const void *, size_t, const uint64_t *, uint64_t *, uint64_t *);
 int lin_round_sums_run(bppp_ctx *, const void *, const void *, size_t, uint64_t *, uint64_t *);
-int fold_scalars_run(bppp_ctx *, const uint64_t *, const uint64_t *, const void *, size_t, void *);
+int fold_scalars_launch(bppp_ctx *, const uint64_t *, const uint64_t *, const void *, size_t, void *);
+int fold_points_multi_run(bppp_ctx *, int, const uint64_t *const[], const int[], const uint64_t *const[], const int[], const void *const[], const size_t[], void *const[]);
 int tensor_run(bppp_ctx *, const uint64_t *, size_t, const uint64_t *, const uint64_t *, size_t, void *);
 
 struct FrK { uint32_t v[8]; };
@@ -197,25 +198,31 @@ int bppp_nl_round_collapse(bppp_nl *nl, const uint64_t e_[4]) {
   nl->s = madd(nl->s, madd(mmul(e, nl->sX, M), mmul(e1, nl->sR, M), M), M);
   NL_HIP(nl, hipMemsetAsync(nl->P[d], 0, nl->cap * 64, st));
   uint64_t u[4], v[4];
+  // the basis folds of both sub-arguments go out as ONE launch (their 129-row chains then run side by side)
+  std::pair<SInt, SInt> abn, abl;
+  const uint64_t *bm[2], *am[2]; int bn[2], an[2]; const void *src[2]; void *dst[2]; size_t cnt[2]; int nseg = 0;
   if (nl->n) {   // Norm.collapse (NormArgument.hs:123-129)
-    auto ab = rational_reduce_scalar(mmul(e, nl->qinv, M));
-    U256 b0 = extract_scalar(ab.second), b0i = minv(b0, M);
+    abn = rational_reduce_scalar(mmul(e, nl->qinv, M));
+    U256 b0 = extract_scalar(abn.second), b0i = minv(b0, M);
     b0i.store(u); mmul(mmul(e, nl->q, M), b0i, M).store(v);
-    int rc = fold_scalars_run(ctx, u, v, nl->x[c], nl->n, nl->x[d]); if (rc) return rc;
-    rc = fold_points_run(ctx, ab.second.m, ab.second.neg, ab.first.m, ab.first.neg, nl->P[c], nl->n, nl->P[d]); if (rc) return rc;
+    int rc = fold_scalars_launch(ctx, u, v, nl->x[c], nl->n, nl->x[d]); if (rc) return rc;
+    bm[nseg] = abn.second.m; bn[nseg] = abn.second.neg; am[nseg] = abn.first.m; an[nseg] = abn.first.neg;
+    src[nseg] = nl->P[c]; dst[nseg] = nl->P[d]; cnt[nseg] = nl->n; nseg++;
     nl->nn = mmul(mmul(nl->nn, b0, M), nl->qinv, M);
     nl->q = mmul(nl->q, nl->q, M); nl->qinv = mmul(nl->qinv, nl->qinv, M);
   }
   if (nl->l) {   // Linear.collapse (NormArgument.hs:64-71)
-    auto ab = rational_reduce_scalar(e);
-    U256 a0 = extract_scalar(ab.first), b0 = extract_scalar(ab.second), b0i = minv(b0, M);
+    abl = rational_reduce_scalar(e);
+    U256 a0 = extract_scalar(abl.first), b0 = extract_scalar(abl.second), b0i = minv(b0, M);
     b0.store(u); a0.store(v);
-    int rc = fold_scalars_run(ctx, u, v, nl->lc[c], nl->l, nl->lc[d]); if (rc) return rc;
+    int rc = fold_scalars_launch(ctx, u, v, nl->lc[c], nl->l, nl->lc[d]); if (rc) return rc;
     b0i.store(u); mmul(e, b0i, M).store(v);
-    rc = fold_scalars_run(ctx, u, v, nl->lx[c], nl->l, nl->lx[d]); if (rc) return rc;
-    rc = fold_points_run(ctx, ab.second.m, ab.second.neg, ab.first.m, ab.first.neg, nl->P[c] + ne * 16, nl->l, nl->P[d] + ne2 * 16); if (rc) return rc;
+    rc = fold_scalars_launch(ctx, u, v, nl->lx[c], nl->l, nl->lx[d]); if (rc) return rc;
+    bm[nseg] = abl.second.m; bn[nseg] = abl.second.neg; am[nseg] = abl.first.m; an[nseg] = abl.first.neg;
+    src[nseg] = nl->P[c] + ne * 16; dst[nseg] = nl->P[d] + ne2 * 16; cnt[nseg] = nl->l; nseg++;
     nl->ln = mmul(nl->ln, b0, M);
   }
+  { int rc = fold_points_multi_run(ctx, nseg, bm, bn, am, an, src, cnt, dst); if (rc) return rc; }
   NL_HIP(nl, hipMemcpyAsync(nl->P[d] + (ne2 + le2) * 16, nl->P[c] + (ne + le) * 16, 64, hipMemcpyDeviceToDevice, st));
   NL_HIP(nl, hipStreamSynchronize(st));
   nl->n = nl->n ? n2 : 0; nl->l = nl->l ? l2 : 0; nl->cur = d;
@@ -319,6 +326,47 @@ int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q_[4], const uint64_t sp_[4], c
   } while (0);
   hipStreamSynchronize(st);
   return rc;
+}
+
+// proveBPM (src/Bulletproof.hs:357-359) entirely behind the ABI: n_rounds x proveRoundM (:346-355) with the caller's
+// oracle.  The oracle sees what ZKPT's `oracle` sees (src/ZKP.hs:96-101): the WHOLE transcript, newest commitments first,
+// as affine points; it returns the first challenge (`head <$> oracle [ac, bc]`).  `transcript_xy` / `*ntranscript` carry the
+// commitments made before the argument starts (e.g. by the range proof) and receive the responses.  responses_xy gets the
+// n_rounds (X, R) pairs LAST ROUND FIRST (:359); es likewise.
+int bppp_nl_prove(bppp_nl *nl, size_t n_rounds, bppp_oracle_fn oracle, void *user, uint64_t *transcript_xy, size_t *ntranscript,
+                  size_t transcript_cap, uint64_t *responses_xy, uint64_t *es) {
+  if (!nl || !oracle || !responses_xy || !es || !transcript_xy || !ntranscript) return BPPP_ERR_ARG;
+  if (*ntranscript + 2 * n_rounds > transcript_cap) return bppp::fail(nl->ctx, BPPP_ERR_ARG, "nl_prove: transcript buffer too small");
+  for (size_t r = 0; r < n_rounds; r++) {
+    uint64_t sX[4], sR[4], X[8], R[8], e[4];
+    int rc = bppp_nl_round_commit(nl, sX, X, sR, R); if (rc) return rc;
+    // cs' = xs ++ cs (ZKP.hs:98): prepend [ac, bc]
+    memmove(transcript_xy + 16, transcript_xy, *ntranscript * 64);
+    memcpy(transcript_xy, X, 64); memcpy(transcript_xy + 8, R, 64);
+    *ntranscript += 2;
+    oracle(user, transcript_xy, *ntranscript, e);
+    if (cmp(U256::load(e), R_().m) >= 0) return bppp::fail(nl->ctx, BPPP_ERR_ARG, "nl_prove: oracle returned a non-canonical scalar");
+    rc = bppp_nl_round_collapse(nl, e); if (rc) return rc;
+    size_t slot = n_rounds - 1 - r;                       // fmap (: resps): the newest response goes to the front
+    memcpy(responses_xy + 16 * slot, X, 64); memcpy(responses_xy + 16 * slot + 8, R, 64);
+    memcpy(es + 4 * slot, e, 32);
+  }
+  return BPPP_OK;
+}
+
+// the challenge derivation of verifyBPM (src/Bulletproof.hs:374): foldrM walks the responses from the right (first round
+// first) and conses, so es comes out ordered like the responses (last round first).
+int bppp_nl_verify_challenges(bppp_oracle_fn oracle, void *user, const uint64_t *responses_xy, size_t k, uint64_t *transcript_xy,
+                              size_t *ntranscript, size_t transcript_cap, uint64_t *es) {
+  if (!oracle || (k && (!responses_xy || !es)) || !transcript_xy || !ntranscript) return BPPP_ERR_ARG;
+  if (*ntranscript + 2 * k > transcript_cap) return BPPP_ERR_ARG;
+  for (size_t i = k; i-- > 0;) {
+    memmove(transcript_xy + 16, transcript_xy, *ntranscript * 64);
+    memcpy(transcript_xy, responses_xy + 16 * i, 128);
+    *ntranscript += 2;
+    oracle(user, transcript_xy, *ntranscript, es + 4 * i);
+  }
+  return BPPP_OK;
 }
 
 }  // extern "C"

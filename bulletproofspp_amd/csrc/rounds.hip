@@ -184,12 +184,17 @@ int round_openings_run(bppp_ctx *ctx, const void *d_x, size_t n, int scale, cons
   BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BPPP_OK;
 }
-int fold_scalars_run(bppp_ctx *ctx, const uint64_t u[4], const uint64_t v[4], const void *d_x, size_t n, void *d_out) {
+int fold_scalars_launch(bppp_ctx *ctx, const uint64_t u[4], const uint64_t v[4], const void *d_x, size_t n, void *d_out) {
   if (n == 0) return BPPP_OK;
   if (!d_x || !d_out || !u || !v || n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_scalars: bad input");
   uint32_t np = (uint32_t)((n + 1) / 2);
   k_fold_scalars<<<dim3((np + 255) / 256), dim3(256), 0, ctx->stream>>>((const uint32_t *)d_x, (uint32_t)n, to_fr4(u), to_fr4(v), (uint32_t *)d_out);
   BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
+int fold_scalars_run(bppp_ctx *ctx, const uint64_t u[4], const uint64_t v[4], const void *d_x, size_t n, void *d_out) {
+  int rc = fold_scalars_launch(ctx, u, v, d_x, n, d_out);
+  if (rc) return rc;
   BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BPPP_OK;
 }

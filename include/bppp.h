@@ -150,6 +150,18 @@ int bppp_nl_verify(bppp_ctx *ctx, const uint64_t q[4], const uint64_t sp[4], con
                    size_t llen, const uint64_t *es, size_t k, const uint64_t *wit_norm, size_t fn, const uint64_t *wit_lin, size_t fl,
                    const uint64_t *init_scalars, const uint64_t *init_points_xy, size_t ninit, const uint64_t *responses_xy, uint64_t out_xy[8]);
 
+/* The injected Fiat-Shamir oracle (MonadZKP.oracle, src/ZKP.hs:57, :96-101; app/Main.hs:75-80 is the CLI's SHA-256 one):
+ * called with the WHOLE transcript so far, newest commitments first, as affine points; writes the first challenge. */
+typedef void (*bppp_oracle_fn)(void *user, const uint64_t *transcript_xy, size_t npoints, uint64_t challenge[4]);
+/* proveBPM (src/Bulletproof.hs:357-359): n_rounds x proveRoundM with the caller's oracle; responses and challenges come out
+ * LAST ROUND FIRST.  transcript_xy (capacity transcript_cap points) holds *ntranscript earlier commitments on entry and
+ * receives the responses (newest first). */
+int bppp_nl_prove(bppp_nl *nl, size_t n_rounds, bppp_oracle_fn oracle, void *user, uint64_t *transcript_xy, size_t *ntranscript,
+                  size_t transcript_cap, uint64_t *responses_xy, uint64_t *es);
+/* the challenge derivation of verifyBPM (src/Bulletproof.hs:374) with the same oracle contract */
+int bppp_nl_verify_challenges(bppp_oracle_fn oracle, void *user, const uint64_t *responses_xy, size_t k, uint64_t *transcript_xy,
+                              size_t *ntranscript, size_t transcript_cap, uint64_t *es);
+
 /* ---- a12: the inner-product flavour (src/Bulletproof/InnerProductArgument.hs; the CLI's default, app/Parse.hs:100)
  * Same contract as bppp_nl_*.  `r` is the argument of makeNorm (:194-206; q = r^4): the norm vector (nlen scalars on nlen
  * points) is re-expressed as ceil(nlen/2) inner-product pairs with the basis change g' = g1 + r g0, h' = g1 - r g0 done

@@ -205,3 +205,24 @@ def test_ip_flavour_prove_and_verify(gpu, oracle_lib, nl, ll):
     if nw:
         assert not verifyBPM_IP(gpu, r, 0, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, [(nw[0] + 1) % O.N] + nw[1:], lw, [(1, C)])
     assert not verifyBPM_IP(gpu, r, 3, g, [0] * nl, gs, cs, [0] * ll, hs, es, resps, nw, lw, [(1, C)])
+
+
+def test_prove_loop_in_library_with_oracle_callback(gpu, oracle_lib):
+    """bppp_nl_prove: proveBPM's loop (Bulletproof.hs:357-359) in C++ with the oracle injected as a callback that receives
+    the whole transcript, newest first (ZKP.hs:96-101) — same responses / challenges / final opening as the oracle."""
+    from bulletproofspp_amd.bulletproof import proveBPM_native
+    nl, ll = 33, 6
+    g, gs, hs, xs, ls, cs, q = _instance(nl, ll, 9001)
+    body = O.NormLinear.make(1, q, cs, xs, gs, ls, hs)
+    wit = O.PSV(body.eval_scalar(), g, body)
+    rounds, _ = O.optimal_witness_size_nl(nl, ll)
+    pre = O.hash_points(b"pre", 3)                       # commitments made before the argument (e.g. by a range proof)
+    tr = O.Transcript(O.sha_oracle_fn())
+    tr.cs = list(pre)
+    fin, resps_o, es_o = O.prove_bp(rounds, wit, tr, oracle_lib)
+    com = NormLinearBP(gpu, wit.sc, g, q, cs, xs, gs, ls, hs)
+    resps, es, transcript = proveBPM_native(rounds, com, O.sha_oracle_fn(), transcript=pre)
+    assert resps == resps_o and es == es_o and transcript == tr.cs
+    nw, lw = com.getWitness()
+    assert (nw, lw) == (fin.body.norm.get_witness(), fin.body.lin.get_witness())
+    com.close()
