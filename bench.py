@@ -72,7 +72,14 @@ def cpu_baseline(sc_np: np.ndarray, pts_np: np.ndarray, sample: int):
     return res, dt
 
 
-def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real: int, steps: int, warmup: int):
+SHAPES = {   # (nrmLen, linLen, rounds, final norm, final lin, transcript commitments)
+    "64by64": (512, 261, 8, 2, 2, 68),              # examples/64by64: 64 values, base 256 shared, NL argument
+    "128by64+typed": (1152, 261, 9, 3, 1, 132),     # examples/128by64 with "typed": true (BASELINE config 4)
+}
+
+
+def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real: int, steps: int, warmup: int, shape: str = "64by64",
+                 cpu_baseline_leg: bool = False):
     """Secondary metric (BASELINE.json: "aggregated 64-bit range-proof verifies/sec"): batch verification of `batch`
     norm-linear arguments of the examples/64by64 shape (nrmLen 512, linLen 261, 8 rounds, 68 transcript commitments +
     16 responses per proof) per GPU with ONE combined MSM (bppp_nl_verify_batch_device).  The proofs are
@@ -82,7 +89,7 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
     import hashlib
     from bulletproofspp_amd.bulletproof import NormLinearBP, proveBPM, N_ORDER
     from bulletproofspp_amd.capi import scalars_to_array, points_to_array, array_to_point, _ptr
-    nlen, llen, k, fn, fl, ninit = 512, 261, 8, 2, 2, 68
+    nlen, llen, k, fn, fl, ninit = SHAPES[shape]
     rng = np.random.default_rng(0x64B + rank)
     # basis: h-less layout  g : hs(llen) ++ gs(nlen)  (TypedReciprocal.hs:334, :348-349), lifted on the GPU
     need = 1 + llen + nlen + ninit
@@ -177,12 +184,39 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
         dt = float(t.item())
     assert res is None
     terms = nlen + llen + 1 + batch * (ninit + 2 * k)
-    return {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
+    # algorithmic bytes per proof: (ninit + 2k) per-proof pairs x 96 B + (nlen + llen + 1) shared-basis scalars x 32 B
+    bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
+    res_d = {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
             "ms_per_batch": dt / steps * 1e3, "batch_per_gpu": batch, "combined_msm_terms": terms,
-            "shape": "examples/64by64: nrmLen 512, linLen 261, 8 rounds, 68+16 per-proof points (SURVEY.md App. B)",
+            "algorithmic_bytes_per_proof": bytes_per_proof,
+            "achieved_GBps": world * batch * steps * bytes_per_proof / dt / 1e9, "hbm_frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world),
+            "shape": f"{shape}: nrmLen {nlen}, linLen {llen}, {k} rounds, {ninit}+{2 * k} per-proof points (SURVEY.md App. B)",
             "proofs": f"{n_real} real proofs from the GPU prover tiled to {batch}; all verify (combined MSM = infinity)",
             "scope": "norm-linear argument level (verifyBPM, Bulletproof.hs:370-378); challenges and public vectors are inputs",
             "gpu_prove_ms_per_proof": prove_s * 1e3}
+    if cpu_baseline_leg and rank == 0:
+        # the reference verifies ONE proof with ONE 256-row Straus MSM over nlen + llen + 1 + ninit + 2k terms
+        # (src/Bulletproof.hs:377): time the oracle's restatement of that on this host (single thread)
+        import ctypes
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        ec = pyoracle.CEC()
+        nterm = nlen + llen + 1 + ninit + 2 * k
+        sc = rng.integers(0, 2**64, size=(nterm, 4), dtype=np.uint64)
+        sc[:, 3] = np.minimum(sc[:, 3], np.uint64(0xFFFFFFFFFFFFFFFD))
+        pts_np = np.ascontiguousarray(np.concatenate([points_to_array(gs), points_to_array(hs), points_to_array([g]),
+                                                      np.concatenate([points_to_array(p["init"]) for p in proofs[:1]]),
+                                                      np.concatenate([points_to_array(p["resp"]) for p in proofs[:1]])]))
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ec.inner_product_raw(sc.ctypes.data_as(u64p), pts_np.ctypes.data_as(u64p), nterm)
+        cdt = (time.perf_counter() - t0) / reps
+        res_d["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                                 "sample": f"{reps} single-proof verifier MSMs of {nterm} terms (the reference's one commit per verify, Bulletproof.hs:377) "
+                                           "through oracle/bppp_oracle.c's 256-row Straus restatement"}
+    return res_d
 
 
 def main():
@@ -272,7 +306,11 @@ def main():
 
     verify = None
     if args.verify_batch > 0:
-        verify = bench_verify(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, args.verify_real, max(3, args.steps // 2), 1)
+        vsteps = max(3, args.steps // 2)
+        verify = bench_verify(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, args.verify_real, vsteps, 1, "64by64",
+                              cpu_baseline_leg=(world == 1 and not args.no_cpu_baseline))
+        verify["other_shapes"] = [bench_verify(gpu, torch, dev, rank, world, dist, combine, max(1, args.verify_batch // 2), max(2, args.verify_real // 4),
+                                               vsteps, 1, "128by64+typed")]
 
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
