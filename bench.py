@@ -219,6 +219,66 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
     return res_d
 
 
+def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64"):
+    """Lockstep batch prover (bppp_nlb_*): `batch` norm-linear arguments of the examples/64by64 shape advanced round by round
+    together (proveBPM, src/Bulletproof.hs:357-359).  The injected oracle is a SHA-256 stand-in over the raw 128 bytes of each
+    proof's (X, R) chained with that proof's previous digest; hashing runs on the host inside the timed region (it is part of
+    a prover's round trip), everything else on the GPU."""
+    import ctypes as C
+    import hashlib
+    from bulletproofspp_amd.bulletproof import N_ORDER
+    from bulletproofspp_amd.capi import _ptr, scalars_to_array
+    nlen, llen, k, fn, fl, _ = SHAPES[shape]
+    rng = np.random.default_rng(0x9E0 + rank)
+    need = 1 + llen + nlen
+    pts = None
+    while pts is None or pts.shape[0] < need:
+        xs = rng.integers(0, 2**64, size=(3 * need, 4), dtype=np.uint64)
+        dx = torch.from_numpy(xs.view(np.int64)).to(dev)
+        dp = torch.zeros((3 * need, 8), dtype=torch.int64, device=dev)
+        gpu.lift_x(dx.data_ptr(), 3 * need, dp.data_ptr())
+        pts = dp[(dp != 0).any(dim=1)]
+    P = np.ascontiguousarray(pts[:need].cpu().numpy().view(np.uint64))
+    rnd_fr = lambda shape_: np.minimum(rng.integers(0, 2**64, size=shape_ + (4,), dtype=np.uint64), np.uint64(0xFFFFFFFFFFFFFFFD))
+    xs_, ls_, cs_, qs_ = rnd_fr((batch, nlen)), rnd_fr((batch, llen)), rnd_fr((batch, llen)), rnd_fr((batch,))
+    ss_ = rnd_fr((batch,))        # the scalar on g only shifts the commitments; any value exercises the same work
+    lib = gpu.lib
+
+    def one_batch():
+        h = C.c_void_p()
+        rc = lib.bppp_nlb_create(gpu.h, batch, _ptr(ss_), _ptr(P[0:1]), _ptr(qs_), _ptr(xs_.reshape(-1, 4)), _ptr(P[1 + llen:1 + llen + nlen]), nlen,
+                                 _ptr(cs_.reshape(-1, 4)), _ptr(ls_.reshape(-1, 4)), _ptr(P[1:1 + llen]), llen, C.byref(h))
+        gpu._check(rc, "bppp_nlb_create")
+        sX, sR = np.zeros((batch, 4), dtype=np.uint64), np.zeros((batch, 4), dtype=np.uint64)
+        X, R = np.zeros((batch, 8), dtype=np.uint64), np.zeros((batch, 8), dtype=np.uint64)
+        digests = [b"bppp%d" % b for b in range(batch)]
+        es = np.zeros((batch, 4), dtype=np.uint64)
+        for _ in range(k):
+            gpu._check(lib.bppp_nlb_round_commit(h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nlb_round_commit")
+            xb, rb = X.tobytes(), R.tobytes()
+            for b in range(batch):
+                digests[b] = hashlib.sha256(digests[b] + xb[64 * b:64 * b + 64] + rb[64 * b:64 * b + 64]).digest()
+                e = int.from_bytes(digests[b], "little") % N_ORDER
+                es[b] = [(e >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+            gpu._check(lib.bppp_nlb_round_collapse(h, _ptr(es)), "bppp_nlb_round_collapse")
+        nw, lw, s = np.zeros((batch * fn, 4), dtype=np.uint64), np.zeros((batch * fl, 4), dtype=np.uint64), np.zeros((batch, 4), dtype=np.uint64)
+        gpu._check(lib.bppp_nlb_get_witness(h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_nlb_get_witness")
+        lib.bppp_nlb_destroy(h)
+        return X
+
+    one_batch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_batch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "norm_linear_arguments_proved_per_sec", "value": batch * steps / dt, "unit": "proofs/s", "ms_per_batch": dt / steps * 1e3,
+            "batch": batch, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
+            "note": "lockstep batch prover (bppp_nlb_*): 2*batch round commitments per round as one batched MSM, all basis folds as one launch; "
+                    "host SHA-256 stand-in oracle inside the timed region; state upload + final opening download included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +290,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=4096, help="proofs per GPU in the batch-verify leg (0 = skip)")
     ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
+    ap.add_argument("--prove-batch", type=int, default=256, help="proofs advanced in lockstep in the prover leg (0 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -312,6 +373,10 @@ def main():
         verify["other_shapes"] = [bench_verify(gpu, torch, dev, rank, world, dist, combine, max(1, args.verify_batch // 2), max(2, args.verify_real // 4),
                                                vsteps, 1, "128by64+typed")]
 
+    prove = None
+    if args.prove_batch > 0 and world == 1:
+        prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2)
+
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
         # with N > 1 each step makes two library calls (the slice MSM and the tiny combine): the dominant
@@ -353,6 +418,8 @@ def main():
                                              "here (no GHC)", "seconds": cdt, "gpu_matches": True}
         if verify is not None:
             out["verify"] = verify
+        if prove is not None:
+            out["prove"] = prove
         print(json.dumps(out), flush=True)
     gpu.close()
     if dist is not None:

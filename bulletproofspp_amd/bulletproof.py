@@ -249,3 +249,68 @@ def verifyBPM_IP(gpu: Bppp, r: int, sp: int, g: Point, pub_norm: Sequence[int], 
                                 opt_s([s for s, _ in init_terms]), opt_p([p for _, p in init_terms]), len(init_terms), opt_p(flat), _ptr(out))
     gpu._check(rc, "bppp_ip_verify")
     return array_to_point(out) is None
+
+
+# ----------------------------------------------------------------------------- lockstep batch prover
+class NormLinearBatch:
+    """`batch` NormLinear arguments of one shape proved in lockstep on the device (bppp_nlb_*)."""
+
+    def __init__(self, gpu: Bppp, ss: Sequence[int], g: Point, qs: Sequence[int], cs: Sequence[Sequence[int]], nss: Sequence[Sequence[int]],
+                 ngs: Sequence[Point], lss: Sequence[Sequence[int]], lgs: Sequence[Point]):
+        B, nlen, llen = len(ss), len(ngs), len(lgs)
+        self.gpu, self.B = gpu, B
+        cat = lambda rows, n: np.concatenate([scalars_to_array(list(r) + [0] * (n - len(r))) for r in rows]) if n else None
+        h = C.c_void_p()
+        rc = gpu.lib.bppp_nlb_create(gpu.h, B, _ptr(scalars_to_array([s % N_ORDER for s in ss])), _ptr(points_to_array([g])),
+                                     _ptr(scalars_to_array([q % N_ORDER for q in qs])), _ptr(cat(nss, nlen)), _ptr(points_to_array(ngs)) if nlen else None, nlen,
+                                     _ptr(cat(cs, llen)), _ptr(cat(lss, llen)), _ptr(points_to_array(lgs)) if llen else None, llen, C.byref(h))
+        gpu._check(rc, "bppp_nlb_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.gpu.lib.bppp_nlb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lengths(self):
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self.gpu._check(self.gpu.lib.bppp_nlb_lengths(self.h, C.byref(a), C.byref(b), C.byref(c)), "bppp_nlb_lengths")
+        return int(a.value), int(b.value), int(c.value)
+
+    def makeScalarsComs(self):
+        B = self.B
+        sX, sR = np.zeros((B, 4), dtype=np.uint64), np.zeros((B, 4), dtype=np.uint64)
+        X, R = np.zeros((B, 8), dtype=np.uint64), np.zeros((B, 8), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_nlb_round_commit(self.h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nlb_round_commit")
+        return array_to_scalars(sX), [array_to_point(X[b]) for b in range(B)], array_to_scalars(sR), [array_to_point(R[b]) for b in range(B)]
+
+    def collapse(self, es: Sequence[int]):
+        self.gpu._check(self.gpu.lib.bppp_nlb_round_collapse(self.h, _ptr(scalars_to_array([e % N_ORDER for e in es]))), "bppp_nlb_round_collapse")
+
+    def getWitness(self):
+        B, n, l = self.lengths()
+        nw, lw, s = np.zeros((max(B * n, 1), 4), dtype=np.uint64), np.zeros((max(B * l, 1), 4), dtype=np.uint64), np.zeros((B, 4), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_nlb_get_witness(self.h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_nlb_get_witness")
+        nws, lws = array_to_scalars(nw), array_to_scalars(lw)
+        return [nws[b * n:(b + 1) * n] for b in range(B)], [lws[b * l:(b + 1) * l] for b in range(B)], array_to_scalars(s)
+
+
+def proveBPM_batch(n_rounds: int, com: NormLinearBatch, oracles: Sequence[OracleFn]):
+    """proveBPM (src/Bulletproof.hs:357-359) for every proof of the batch, one injected oracle per proof; per-proof responses
+    and challenges come out last round first."""
+    B = com.B
+    resps, es = [[] for _ in range(B)], [[] for _ in range(B)]
+    for _ in range(n_rounds):
+        _, X, _, R = com.makeScalarsComs()
+        e = [oracles[b]([X[b], R[b]]) % N_ORDER for b in range(B)]
+        com.collapse(e)
+        for b in range(B):
+            resps[b].insert(0, (X[b], R[b]))
+            es[b].insert(0, e[b])
+    return resps, es

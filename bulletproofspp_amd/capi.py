@@ -22,6 +22,7 @@ SYMBOLS = [
     "bppp_fold_scalars_device", "bppp_tensor_device", "bppp_batch_inverse_device",
     "bppp_nl_create", "bppp_nl_destroy", "bppp_nl_lengths", "bppp_nl_round_commit", "bppp_nl_round_collapse",
     "bppp_nl_get_witness", "bppp_nl_download", "bppp_nl_verify", "bppp_nl_verify_batch_device", "bppp_nl_prove", "bppp_nl_verify_challenges",
+    "bppp_nlb_create", "bppp_nlb_destroy", "bppp_nlb_lengths", "bppp_nlb_round_commit", "bppp_nlb_round_collapse", "bppp_nlb_get_witness",
     "bppp_ip_create", "bppp_ip_destroy", "bppp_ip_lengths", "bppp_ip_round_commit", "bppp_ip_round_collapse", "bppp_ip_get_witness", "bppp_ip_verify",
     "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
     "bppp_profile_enable", "bppp_profile_read",
@@ -74,6 +75,13 @@ def load_library() -> C.CDLL:
     lib.bppp_nl_download.argtypes = [vp] + [vp] * 9
     lib.bppp_nl_prove.argtypes = [vp, sz, vp, vp, vp, C.POINTER(sz), sz, vp, vp]
     lib.bppp_nl_verify_challenges.argtypes = [vp, vp, vp, sz, vp, C.POINTER(sz), sz, vp]
+    lib.bppp_nlb_create.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, C.POINTER(vp)]
+    lib.bppp_nlb_destroy.argtypes = [vp]
+    lib.bppp_nlb_destroy.restype = None
+    lib.bppp_nlb_lengths.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    lib.bppp_nlb_round_commit.argtypes = [vp, vp, vp, vp, vp]
+    lib.bppp_nlb_round_collapse.argtypes = [vp, vp]
+    lib.bppp_nlb_get_witness.argtypes = [vp, vp, vp, vp]
     lib.bppp_ip_create.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, C.POINTER(vp)]
     lib.bppp_ip_destroy.argtypes = [vp]
     lib.bppp_ip_destroy.restype = None

@@ -119,6 +119,22 @@ inline U256 minv(const U256 &a, const Mod &M) {  // 0 -> 0 (BatchInverse.hs:18,2
   return mpow(a, e, M);
 }
 
+// Montgomery's trick on the host (0 -> 0): one Fermat inversion for a whole vector (lockstep prover: 2-3 per proof per round)
+inline void batch_minv(U256 *v, size_t n, const Mod &M) {
+  if (!n) return;
+  U256 *pre = new U256[n];
+  U256 acc = U256::one();
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!v[i].is_zero()) acc = mmul(acc, v[i], M); }
+  U256 y = minv(acc, M);
+  for (size_t i = n; i-- > 0;) {
+    if (v[i].is_zero()) continue;
+    U256 inv = mmul(y, pre[i], M);
+    y = mmul(y, v[i], M);
+    v[i] = inv;
+  }
+  delete[] pre;
+}
+
 // a lazily-reduced device value: 10 limbs of radix 2^26 (csrc/fq26.cuh), any magnitude -> canonical mod p
 inline U256 from_limbs26(const uint32_t *n) {
   const Mod &M = FQ();
@@ -216,14 +232,25 @@ inline SInt smul(const SInt &a, const SInt &b) {
   r.neg = r.is_zero() ? false : (a.neg != b.neg);
   return r;
 }
-// truncating division (Haskell `quot`, Commitment.hs:254)
+// truncating division (Haskell `quot`, Commitment.hs:254).  Euclid's quotients are almost always a few bits long, so the
+// shift-subtract loop runs only over bits(a) - bits(b) + 1 positions.
 inline SInt squot(const SInt &a, const SInt &b) {
   SInt q = SInt::zero();
-  uint64_t rem[SInt::L] = {0};
-  for (int i = a.bits() - 1; i >= 0; i--) {
-    uint64_t c = (a.m[i >> 6] >> (i & 63)) & 1;
-    for (int k = 0; k < SInt::L; k++) { uint64_t nc = rem[k] >> 63; rem[k] = (rem[k] << 1) | c; c = nc; }
-    if (mcmp(rem, b.m) >= 0) { msub_mag(rem, rem, b.m); q.m[i >> 6] |= 1ULL << (i & 63); }
+  int na = a.bits(), nb = b.bits();
+  if (nb == 0 || na < nb) return q;
+  int sh = na - nb;
+  uint64_t rem[SInt::L], d[SInt::L + 1] = {0};
+  memcpy(rem, a.m, sizeof rem);
+  // d = |b| << sh
+  for (int i = 0; i < SInt::L; i++) {
+    int w = i + (sh >> 6), o = sh & 63;
+    if (w < SInt::L + 1) d[w] |= b.m[i] << o;
+    if (o && w + 1 < SInt::L + 1) d[w + 1] |= b.m[i] >> (64 - o);
+  }
+  for (int i = sh; i >= 0; i--) {
+    if (d[SInt::L] == 0 && mcmp(rem, d) >= 0) { msub_mag(rem, rem, d); q.m[i >> 6] |= 1ULL << (i & 63); }
+    for (int k = 0; k < SInt::L; k++) d[k] = (d[k] >> 1) | (d[k + 1] << 63);   // d >>= 1
+    d[SInt::L] >>= 1;
   }
   q.neg = q.is_zero() ? false : (a.neg != b.neg);
   return q;

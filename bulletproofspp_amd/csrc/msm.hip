@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__
       else xyzz_store(buckets + (size_t)cur * XYZZ_WORDS, acc);
       first = false; cur = k; acc = xyzz_inf();
     }
-    size_t pidx = shared_pts ? (size_t)idx : (size_t)(k / WM) * n + idx;
+    // shared_pts: 1 = one point array for every instance, 0 = one per instance, d >= 2 = one per d consecutive instances
+    size_t pidx = shared_pts == 1 ? (size_t)idx : (size_t)((k / WM) / (shared_pts ? shared_pts : 1)) * n + idx;
     aff P = aff_cneg(aff_load(points + pidx * 16), sg);
     xyzz_madd(acc, P);
     e = e_next;

@@ -1,0 +1,361 @@
+// nlb.hip — B norm-linear arguments (NL flavour) proved in LOCKSTEP: every kernel of a round carries the batch dimension.
+//
+// Same functions as nl.hip (proveRoundM, src/Bulletproof.hs:346-355; makeScalarsComs, src/Bulletproof/NormArgument.hs:113-118,
+// :56-59; collapse :123-129, :64-71) applied to `batch` independent proofs of one shape at once.  One proof's round is far
+// too small to fill 256 CUs (its MSMs have < 800 terms and its 129-row basis fold is a ~1.5 ms dependency chain), so a
+// single proof is latency-bound; B proofs share the launches: 2B round commitments are ONE batched MSM (each proof's X and R
+// share that proof's basis), B x ceil(n/2) basis folds are ONE launch with per-proof reduced scalars, and the Fr vector work
+// is one workgroup per proof.  The bases diverge after the first collapse (different challenges), so they are stored per proof.
+#include <string.h>
+#include <vector>
+#include "ctx.hpp"
+#include "ec.cuh"
+#include "hostmath.hpp"
+
+namespace bppp {
+int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
+
+BPPP_DI fe frb_pow(fe base, uint32_t e) {
+  fe acc = fe_one();
+  while (e) { if (e & 1u) acc = fe_mul<1>(acc, base); base = fe_sqr<1>(base); e >>= 1; }
+  return acc;
+}
+BPPP_DI void block_sum4(fe v[4], uint32_t *lds) {
+  const int t = threadIdx.x;
+  for (int k = 0; k < 4; k++) for (int i = 0; i < 8; i++) lds[(t * 4 + k) * 8 + i] = v[k].v[i];
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) {
+      for (int k = 0; k < 4; k++) {
+        fe x, y;
+        for (int i = 0; i < 8; i++) { x.v[i] = lds[(t * 4 + k) * 8 + i]; y.v[i] = lds[((t + d) * 4 + k) * 8 + i]; }
+        x = fe_add<1>(x, y);
+        for (int i = 0; i < 8; i++) lds[(t * 4 + k) * 8 + i] = x.v[i];
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) for (int k = 0; k < 4; k++) for (int i = 0; i < 8; i++) v[k].v[i] = lds[k * 8 + i];
+}
+
+// one workgroup per proof: the four round sums (norm sX', sR'; linear sX, sR) and the X / R opening scalars over the
+// even-padded basis slices (layout as in nl.hip): scX = [q xR, qinv xL ... | xR, xL ...], scR = [0, xR ... | 0, xR ...]
+__global__ void __launch_bounds__(256) k_nlb_round(const uint32_t *__restrict__ x, const uint32_t *__restrict__ lc, const uint32_t *__restrict__ lx,
+                                                   uint32_t n, uint32_t l, uint32_t xstride, uint32_t lstride, const uint32_t *__restrict__ qs /*[B][2]: q, qinv*/,
+                                                   uint32_t T, uint32_t *__restrict__ sc /*[2B][T]*/, uint32_t *__restrict__ sums /*[B][4]*/) {
+  __shared__ uint32_t lds[256 * 4 * 8];
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  const uint32_t ne = n + (n & 1), np = (n + 1) / 2, lp = (l + 1) / 2;
+  const fe q = fe_load(qs + (size_t)b * 16), qinv = fe_load(qs + (size_t)b * 16 + 8);
+  fe q2 = fe_sqr<1>(q), q4 = fe_sqr<1>(q2);
+  fe w = frb_pow(q4, t), step = frb_pow(q4, 256);
+  uint32_t *scX = sc + (size_t)(2 * b) * T * 8, *scR = sc + (size_t)(2 * b + 1) * T * 8;
+  const uint32_t *xb = x + (size_t)b * xstride * 8, *lcb = lc + (size_t)b * lstride * 8, *lxb = lx + (size_t)b * lstride * 8;
+  fe s[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
+  for (uint32_t j = t; j < np; j += 256) {
+    fe xl = fe_load(xb + (size_t)(2 * j) * 8);
+    fe xr = (2 * j + 1 < n) ? fe_load(xb + (size_t)(2 * j + 1) * 8) : fe_zero();
+    fe wxr = fe_mul<1>(w, xr);
+    s[0] = fe_add<1>(s[0], fe_mul<1>(wxr, xl));
+    s[1] = fe_add<1>(s[1], fe_mul<1>(wxr, xr));
+    fe_store(scX + (size_t)(2 * j) * 8, fe_mul<1>(q, xr));
+    fe_store(scX + (size_t)(2 * j + 1) * 8, fe_mul<1>(qinv, xl));
+    fe_store(scR + (size_t)(2 * j) * 8, fe_zero());
+    fe_store(scR + (size_t)(2 * j + 1) * 8, xr);
+    w = fe_mul<1>(w, step);
+  }
+  for (uint32_t j = t; j < lp; j += 256) {
+    bool has = 2 * j + 1 < l;
+    fe cl = fe_load(lcb + (size_t)(2 * j) * 8), xl = fe_load(lxb + (size_t)(2 * j) * 8);
+    fe cr = has ? fe_load(lcb + (size_t)(2 * j + 1) * 8) : fe_zero();
+    fe xr = has ? fe_load(lxb + (size_t)(2 * j + 1) * 8) : fe_zero();
+    s[2] = fe_add<1>(s[2], fe_add<1>(fe_mul<1>(cl, xr), fe_mul<1>(cr, xl)));
+    s[3] = fe_add<1>(s[3], fe_mul<1>(cr, xr));
+    fe_store(scX + (size_t)(ne + 2 * j) * 8, xr);
+    fe_store(scX + (size_t)(ne + 2 * j + 1) * 8, xl);
+    fe_store(scR + (size_t)(ne + 2 * j) * 8, fe_zero());
+    fe_store(scR + (size_t)(ne + 2 * j + 1) * 8, xr);
+  }
+  block_sum4(s, lds);
+  if (t == 0) for (int k = 0; k < 4; k++) fe_store(sums + ((size_t)b * 4 + k) * 8, s[k]);
+}
+
+// per-proof collapse constants: FoldK for the two basis folds and (u, v) for the three scalar folds
+struct CollapseK {
+  uint32_t nb[5], na[5], lb[5], la[5];   // reduced scalars b', a' of the norm fold and of the linear fold (magnitudes)
+  int nbneg, naneg, lbneg, laneg;
+  uint32_t nu[8], nv[8];                 // norm x' = nu xL + nv xR
+  uint32_t cu[8], cv[8];                 // linear c' = cu cL + cv cR
+  uint32_t lu[8], lv[8];                 // linear x' = lu xL + lv xR
+};
+BPPP_DI fe fe_of8(const uint32_t *p) { fe r; for (int i = 0; i < 8; i++) r.v[i] = p[i]; return r; }
+
+__global__ void __launch_bounds__(256) k_nlb_fold_scalars(const uint32_t *__restrict__ x, const uint32_t *__restrict__ lc, const uint32_t *__restrict__ lx,
+                                                          uint32_t n, uint32_t l, uint32_t xstride, uint32_t lstride, const CollapseK *__restrict__ K,
+                                                          uint32_t *__restrict__ xo, uint32_t *__restrict__ lco, uint32_t *__restrict__ lxo) {
+  const uint32_t b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  const CollapseK &k = K[b];
+  if (j < (n + 1) / 2) {
+    const uint32_t *xb = x + (size_t)b * xstride * 8;
+    fe r = fe_mul<1>(fe_of8(k.nu), fe_load(xb + (size_t)(2 * j) * 8));
+    if (2 * j + 1 < n) r = fe_add<1>(r, fe_mul<1>(fe_of8(k.nv), fe_load(xb + (size_t)(2 * j + 1) * 8)));
+    fe_store(xo + ((size_t)b * xstride + j) * 8, r);
+  }
+  if (j < (l + 1) / 2) {
+    const uint32_t *cb = lc + (size_t)b * lstride * 8, *xb = lx + (size_t)b * lstride * 8;
+    bool has = 2 * j + 1 < l;
+    fe c = fe_mul<1>(fe_of8(k.cu), fe_load(cb + (size_t)(2 * j) * 8));
+    fe r = fe_mul<1>(fe_of8(k.lu), fe_load(xb + (size_t)(2 * j) * 8));
+    if (has) {
+      c = fe_add<1>(c, fe_mul<1>(fe_of8(k.cv), fe_load(cb + (size_t)(2 * j + 1) * 8)));
+      r = fe_add<1>(r, fe_mul<1>(fe_of8(k.lv), fe_load(xb + (size_t)(2 * j + 1) * 8)));
+    }
+    fe_store(lco + ((size_t)b * lstride + j) * 8, c);
+    fe_store(lxo + ((size_t)b * lstride + j) * 8, r);
+  }
+}
+
+// basis folds of all proofs: blockIdx.y = proof, blockIdx.x covers [norm pair chunks | linear pair chunks]; the 129-row
+// schedule is uniform per workgroup (scalars from the proof's CollapseK through scalar loads)
+__global__ void __launch_bounds__(64) k_nlb_fold_points(const uint32_t *__restrict__ P, uint32_t n, uint32_t l, uint32_t cap, uint32_t cap_out,
+                                                        const CollapseK *__restrict__ K, uint32_t nblk_norm, uint32_t *__restrict__ Po) {
+  const uint32_t b = blockIdx.y;
+  const bool lin = blockIdx.x >= nblk_norm;
+  const uint32_t cnt = lin ? l : n;
+  const uint32_t j = (lin ? blockIdx.x - nblk_norm : blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= (cnt + 1) / 2) return;
+  const CollapseK &k = K[b];
+  const uint32_t *kb = lin ? k.lb : k.nb, *ka = lin ? k.la : k.na;
+  const bool bneg = (lin ? k.lbneg : k.nbneg) != 0, aneg = (lin ? k.laneg : k.naneg) != 0;
+  const uint32_t ne = n + (n & 1), n2 = (n + 1) / 2, ne2 = n2 + (n2 & 1);
+  const uint32_t *src = P + ((size_t)b * cap + (lin ? ne : 0)) * 16;
+  uint32_t *dst = Po + ((size_t)b * cap_out + (lin ? ne2 : 0)) * 16;
+  aff GL = aff_cneg(aff_load(src + (size_t)(2 * j) * 16), bneg);
+  aff GR = aff_inf();
+  if (2 * j + 1 < cnt) GR = aff_cneg(aff_load(src + (size_t)(2 * j + 1) * 16), aneg);
+  xyzz acc = xyzz_inf();
+  for (int row = 128; row >= 0; row--) {
+    uint32_t wb = __builtin_amdgcn_readfirstlane(kb[row >> 5]), wa = __builtin_amdgcn_readfirstlane(ka[row >> 5]);
+    acc = xyzz_dbl(acc);
+    if ((wb >> (row & 31)) & 1u) xyzz_madd(acc, GL);
+    if ((wa >> (row & 31)) & 1u) xyzz_madd(acc, GR);
+  }
+  aff_store(dst + (size_t)j * 16, xyzz_to_aff(acc));
+}
+// g (and the infinity padding) of every proof carried into the next layout
+__global__ void k_nlb_move_g(const uint32_t *__restrict__ P, uint32_t cap, uint32_t cap_out, uint32_t src_off, uint32_t dst_off, uint32_t *__restrict__ Po) {
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  if (t < 16) Po[((size_t)b * cap_out + dst_off) * 16 + t] = P[((size_t)b * cap + src_off) * 16 + t];
+}
+}  // namespace bppp
+
+using namespace bppp;
+using namespace bppp_host;
+
+struct bppp_nlb {
+  bppp_ctx *ctx;
+  size_t batch, n, l, n0, l0, cap, xstride, lstride;   // cap: allocation per proof; the CURRENT point stride is even(n)+even(l)+1
+  uint32_t *x[2], *lx[2], *lc[2], *P[2];
+  uint32_t *sc, *sums, *qs;
+  CollapseK *dK;
+  int cur;
+  std::vector<U256> q, qinv, nn, ln, s, sX, sR;
+};
+static size_t evb(size_t v) { return v + (v & 1); }
+#define NLB_HIP(o, call)                                                                                   \
+  do {                                                                                                     \
+    hipError_t _e = (call);                                                                                \
+    if (_e != hipSuccess) return bppp::fail((o)->ctx, BPPP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" {
+
+void bppp_nlb_destroy(bppp_nlb *o) {
+  if (!o) return;
+  hipSetDevice(o->ctx->device);
+  hipStreamSynchronize(o->ctx->stream);
+  for (int k = 0; k < 2; k++) { hipFree(o->x[k]); hipFree(o->lx[k]); hipFree(o->lc[k]); hipFree(o->P[k]); }
+  hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK);
+  delete o;
+}
+
+// `batch` x makeNormLinearBP' 1 q_b cs_b nss_b ngs lss_b lgs (NormArgument.hs:162) inside makePSV s_b g: the basis (g, G, H) is
+// shared by all proofs at the start; scalars are [batch][...] host arrays.
+int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
+                    const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
+                    bppp_nlb **out) {
+  if (!ctx || !out || !s || !g_xy || !q || !batch) return BPPP_ERR_ARG;
+  if ((nlen && (!norm_x || !norm_g_xy)) || (llen && (!lin_c || !lin_x || !lin_h_xy)) || nlen + llen == 0 || nlen >= (1u << 24) || llen >= (1u << 24) ||
+      batch >= (1u << 20))
+    return fail(ctx, BPPP_ERR_ARG, "nlb_create: bad arguments");
+  hipSetDevice(ctx->device);
+  const Mod &M = FR();
+  bppp_nlb *o = new bppp_nlb();
+  o->ctx = ctx; o->batch = batch; o->n = o->n0 = nlen; o->l = o->l0 = llen; o->cur = 0;
+  o->cap = evb(nlen) + evb(llen) + 1; o->xstride = evb(nlen) + 2; o->lstride = evb(llen) + 2;
+  for (int k = 0; k < 2; k++) { o->x[k] = o->lx[k] = o->lc[k] = o->P[k] = nullptr; }
+  o->sc = o->sums = o->qs = nullptr; o->dK = nullptr;
+  bool bad = false;
+  for (int k = 0; k < 2; k++) {
+    bad |= hipMalloc(&o->x[k], batch * o->xstride * 32) != hipSuccess || hipMalloc(&o->lx[k], batch * o->lstride * 32) != hipSuccess;
+    bad |= hipMalloc(&o->lc[k], batch * o->lstride * 32) != hipSuccess || hipMalloc(&o->P[k], batch * o->cap * 64) != hipSuccess;
+  }
+  bad |= hipMalloc(&o->sc, 2 * batch * o->cap * 32) != hipSuccess || hipMalloc(&o->sums, batch * 4 * 32) != hipSuccess;
+  bad |= hipMalloc(&o->qs, batch * 64) != hipSuccess || hipMalloc(&o->dK, batch * sizeof(CollapseK)) != hipSuccess;
+  if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
+  hipStream_t st = ctx->stream;
+  NLB_HIP(o, hipMemsetAsync(o->P[0], 0, batch * o->cap * 64, st));
+  NLB_HIP(o, hipMemsetAsync(o->x[0], 0, batch * o->xstride * 32, st));
+  NLB_HIP(o, hipMemsetAsync(o->lx[0], 0, batch * o->lstride * 32, st));
+  NLB_HIP(o, hipMemsetAsync(o->lc[0], 0, batch * o->lstride * 32, st));
+  if (nlen) NLB_HIP(o, hipMemcpy2DAsync(o->x[0], o->xstride * 32, norm_x, nlen * 32, nlen * 32, batch, hipMemcpyHostToDevice, st));
+  if (llen) {
+    NLB_HIP(o, hipMemcpy2DAsync(o->lc[0], o->lstride * 32, lin_c, llen * 32, llen * 32, batch, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemcpy2DAsync(o->lx[0], o->lstride * 32, lin_x, llen * 32, llen * 32, batch, hipMemcpyHostToDevice, st));
+  }
+  for (size_t b = 0; b < batch; b++) {     // the shared starting basis, one copy per proof (they diverge after round 1)
+    uint32_t *pb = o->P[0] + b * o->cap * 16;
+    if (nlen) NLB_HIP(o, hipMemcpyAsync(pb, norm_g_xy, nlen * 64, hipMemcpyHostToDevice, st));
+    if (llen) NLB_HIP(o, hipMemcpyAsync(pb + evb(nlen) * 16, lin_h_xy, llen * 64, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemcpyAsync(pb + (evb(nlen) + evb(llen)) * 16, g_xy, 64, hipMemcpyHostToDevice, st));
+  }
+  o->q.resize(batch); o->qinv.resize(batch); o->nn.assign(batch, U256::one()); o->ln.assign(batch, U256::one());
+  o->s.resize(batch); o->sX.resize(batch); o->sR.resize(batch);
+  for (size_t b = 0; b < batch; b++) { o->q[b] = U256::load(q + 4 * b); o->qinv[b] = o->q[b]; o->s[b] = U256::load(s + 4 * b); }
+  batch_minv(o->qinv.data(), batch, M);
+  NLB_HIP(o, hipStreamSynchronize(st));
+  *out = o;
+  return BPPP_OK;
+}
+
+int bppp_nlb_lengths(const bppp_nlb *o, size_t *batch, size_t *nlen, size_t *llen) {
+  if (!o || !batch || !nlen || !llen) return BPPP_ERR_ARG;
+  *batch = o->batch; *nlen = o->n; *llen = o->l;
+  return BPPP_OK;
+}
+
+// first half of proveRoundM for every proof: sX, X, sR, R are [batch][4] / [batch][8]
+int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy) {
+  if (!o || !sX || !X_xy || !sR || !R_xy) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = o->ctx;
+  hipSetDevice(ctx->device);
+  const Mod &M = FR();
+  const size_t B = o->batch, ne = evb(o->n), le = evb(o->l), T = ne + le + 1;
+  const int c = o->cur;
+  hipStream_t st = ctx->stream;
+  std::vector<uint64_t> h(B * 16);
+  for (size_t b = 0; b < B; b++) { o->q[b].store(&h[8 * b]); o->qinv[b].store(&h[8 * b + 4]); }
+  NLB_HIP(o, hipMemcpyAsync(o->qs, h.data(), B * 64, hipMemcpyHostToDevice, st));
+  NLB_HIP(o, hipMemsetAsync(o->sc, 0, 2 * B * T * 32, st));
+  k_nlb_round<<<dim3((unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride, (uint32_t)o->lstride,
+                                                      o->qs, (uint32_t)T, o->sc, o->sums);
+  std::vector<uint64_t> sums(B * 16);
+  NLB_HIP(o, hipMemcpyAsync(sums.data(), o->sums, B * 128, hipMemcpyDeviceToHost, st));
+  NLB_HIP(o, hipStreamSynchronize(st));
+  std::vector<uint64_t> tails(B * 8);
+  for (size_t b = 0; b < B; b++) {
+    U256 q = o->q[b], q2 = mmul(q, q, M), q3 = mmul(q2, q, M), q4 = mmul(q2, q2, M), n2 = mmul(o->nn[b], o->nn[b], M);
+    U256 sXn = mmul(mmul(madd(n2, n2, M), q3, M), U256::load(&sums[16 * b]), M);         // 2 n^2 q^3 sX'  (NormArgument.hs:113)
+    U256 sRn = mmul(mmul(n2, q4, M), U256::load(&sums[16 * b + 4]), M);                   // n^2 q^4 sR'
+    o->sX[b] = madd(o->n ? sXn : U256::zero(), o->l ? U256::load(&sums[16 * b + 8]) : U256::zero(), M);
+    o->sR[b] = madd(o->n ? sRn : U256::zero(), o->l ? U256::load(&sums[16 * b + 12]) : U256::zero(), M);
+    o->sX[b].store(sX + 4 * b); o->sR[b].store(sR + 4 * b);
+    o->sX[b].store(&tails[8 * b]); o->sR[b].store(&tails[8 * b + 4]);
+  }
+  // the scalar on g is the last term of each instance: instance 2b (X) and 2b+1 (R)
+  NLB_HIP(o, hipMemcpy2DAsync(o->sc + (T - 1) * 8, T * 32, tails.data(), 32, 32, 2 * B, hipMemcpyHostToDevice, st));
+  std::vector<uint64_t> outs(2 * B * 8);
+  int rc = msm_run(ctx, o->sc, o->P[c], T, 2 * B, 2, 0, outs.data());   // X and R of a proof share that proof's basis
+  if (rc) return rc;
+  for (size_t b = 0; b < B; b++) { memcpy(X_xy + 8 * b, &outs[16 * b], 64); memcpy(R_xy + 8 * b, &outs[16 * b + 8], 64); }
+  return BPPP_OK;
+}
+
+// second half of proveRoundM for every proof; es is [batch][4]
+int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
+  if (!o || !es) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = o->ctx;
+  hipSetDevice(ctx->device);
+  const Mod &M = FR();
+  const size_t B = o->batch;
+  const int c = o->cur, d = 1 - c;
+  const size_t ne = evb(o->n), le = evb(o->l), n2 = (o->n + 1) / 2, l2 = (o->l + 1) / 2, ne2 = evb(n2), le2 = evb(l2);
+  hipStream_t st = ctx->stream;
+  std::vector<CollapseK> K(B);
+  auto put5 = [](uint32_t *dst, const SInt &v) { for (int i = 0; i < 5; i++) dst[i] = (uint32_t)(v.m[i / 2] >> (32 * (i & 1))); };
+  auto put8 = [](uint32_t *dst, const U256 &v) { for (int i = 0; i < 8; i++) dst[i] = (uint32_t)(v.w[i / 2] >> (32 * (i & 1))); };
+  std::vector<U256> inv(2 * B, U256::zero()), a0l(B), b0n(B), b0l(B);
+  for (size_t b = 0; b < B; b++) {
+    const U256 e = U256::load(es + 4 * b);
+    if (cmp(e, M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
+    U256 e1 = msub(mmul(e, e, M), U256::one(), M);
+    o->s[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
+    memset(&K[b], 0, sizeof(CollapseK));
+    if (o->n) {
+      auto ab = rational_reduce_scalar(mmul(e, o->qinv[b], M));
+      if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
+      b0n[b] = extract_scalar(ab.second); inv[2 * b] = b0n[b];
+      put5(K[b].nb, ab.second); put5(K[b].na, ab.first); K[b].nbneg = ab.second.neg; K[b].naneg = ab.first.neg;
+    }
+    if (o->l) {
+      auto ab = rational_reduce_scalar(e);
+      if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
+      a0l[b] = extract_scalar(ab.first); b0l[b] = extract_scalar(ab.second); inv[2 * b + 1] = b0l[b];
+      put5(K[b].lb, ab.second); put5(K[b].la, ab.first); K[b].lbneg = ab.second.neg; K[b].laneg = ab.first.neg;
+    }
+  }
+  batch_minv(inv.data(), 2 * B, M);              // every b0^-1 of the round with ONE field inversion
+  for (size_t b = 0; b < B; b++) {
+    const U256 e = U256::load(es + 4 * b);
+    if (o->n) {
+      put8(K[b].nu, inv[2 * b]); put8(K[b].nv, mmul(mmul(e, o->q[b], M), inv[2 * b], M));
+      o->nn[b] = mmul(mmul(o->nn[b], b0n[b], M), o->qinv[b], M);
+      o->q[b] = mmul(o->q[b], o->q[b], M); o->qinv[b] = mmul(o->qinv[b], o->qinv[b], M);
+    }
+    if (o->l) {
+      put8(K[b].cu, b0l[b]); put8(K[b].cv, a0l[b]); put8(K[b].lu, inv[2 * b + 1]); put8(K[b].lv, mmul(e, inv[2 * b + 1], M));
+      o->ln[b] = mmul(o->ln[b], b0l[b], M);
+    }
+  }
+  NLB_HIP(o, hipMemcpyAsync(o->dK, K.data(), B * sizeof(CollapseK), hipMemcpyHostToDevice, st));
+  NLB_HIP(o, hipMemsetAsync(o->P[d], 0, B * o->cap * 64, st));
+  NLB_HIP(o, hipMemsetAsync(o->x[d], 0, B * o->xstride * 32, st));
+  NLB_HIP(o, hipMemsetAsync(o->lx[d], 0, B * o->lstride * 32, st));
+  NLB_HIP(o, hipMemsetAsync(o->lc[d], 0, B * o->lstride * 32, st));
+  uint32_t maxp = (uint32_t)std::max(n2, l2);
+  if (maxp) {
+    k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride,
+                                                                                   (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
+    uint32_t nbn = (uint32_t)((n2 + 63) / 64), nbl = (uint32_t)((l2 + 63) / 64);
+    if (!o->n) nbn = 0;
+    if (!o->l) nbl = 0;
+    k_nlb_fold_points<<<dim3(nbn + nbl, (unsigned)B), dim3(64), 0, st>>>(o->P[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)(ne + le + 1),
+                                                                         (uint32_t)(ne2 + le2 + 1), o->dK, nbn, o->P[d]);
+  }
+  k_nlb_move_g<<<dim3((unsigned)B), dim3(64), 0, st>>>(o->P[c], (uint32_t)(ne + le + 1), (uint32_t)(ne2 + le2 + 1), (uint32_t)(ne + le), (uint32_t)(ne2 + le2), o->P[d]);
+  NLB_HIP(o, hipGetLastError());
+  NLB_HIP(o, hipStreamSynchronize(st));
+  o->n = o->n ? n2 : 0; o->l = o->l ? l2 : 0; o->cur = d;
+  return BPPP_OK;
+}
+
+// getWitness of every proof: norm_w [batch][nlen], lin_w [batch][llen] (current lengths), s [batch][4]
+int bppp_nlb_get_witness(bppp_nlb *o, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s) {
+  if (!o || (o->n && !norm_w) || (o->l && !lin_w)) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = o->ctx;
+  hipSetDevice(ctx->device);
+  const Mod &M = FR();
+  const int c = o->cur;
+  hipStream_t st = ctx->stream;
+  if (o->n) NLB_HIP(o, hipMemcpy2DAsync(norm_w, o->n * 32, o->x[c], o->xstride * 32, o->n * 32, o->batch, hipMemcpyDeviceToHost, st));
+  if (o->l) NLB_HIP(o, hipMemcpy2DAsync(lin_w, o->l * 32, o->lx[c], o->lstride * 32, o->l * 32, o->batch, hipMemcpyDeviceToHost, st));
+  NLB_HIP(o, hipStreamSynchronize(st));
+  for (size_t b = 0; b < o->batch; b++) {
+    for (size_t i = 0; i < o->n; i++) mmul(U256::load(norm_w + 4 * (b * o->n + i)), o->nn[b], M).store(norm_w + 4 * (b * o->n + i));
+    for (size_t i = 0; i < o->l; i++) mmul(U256::load(lin_w + 4 * (b * o->l + i)), o->ln[b], M).store(lin_w + 4 * (b * o->l + i));
+    if (s) o->s[b].store(s + 4 * b);
+  }
+  return BPPP_OK;
+}
+
+}  // extern "C"

@@ -60,8 +60,9 @@ int bppp_msm(bppp_ctx *ctx, const uint64_t *scalars, const uint64_t *points_xy, 
 int bppp_msm_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, int window_bits,
                     uint64_t out_xy[8]);
 /* `batch` independent MSMs of n terms each in one pass (one per proof: verifyBPM's single commit,
- * src/Bulletproof.hs:377).  d_scalars is [batch][n]; d_points_xy is [batch][n] or, when
- * shared_points != 0, one [n] basis used by every instance.  out_xy is [batch][8] on the host. */
+ * src/Bulletproof.hs:377).  d_scalars is [batch][n]; d_points_xy is [batch][n] when shared_points == 0, one [n] basis used
+ * by every instance when shared_points == 1, and [batch / d][n] (one basis per d consecutive instances, e.g. the X and R
+ * commitments of one proof) when shared_points == d >= 2.  out_xy is [batch][8] on the host. */
 int bppp_msm_batch_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, size_t batch,
                           int shared_points, int window_bits, uint64_t *out_xy);
 
@@ -161,6 +162,20 @@ int bppp_nl_prove(bppp_nl *nl, size_t n_rounds, bppp_oracle_fn oracle, void *use
 /* the challenge derivation of verifyBPM (src/Bulletproof.hs:374) with the same oracle contract */
 int bppp_nl_verify_challenges(bppp_oracle_fn oracle, void *user, const uint64_t *responses_xy, size_t k, uint64_t *transcript_xy,
                               size_t *ntranscript, size_t transcript_cap, uint64_t *es);
+
+/* ---- lockstep batch prover: `batch` norm-linear arguments of one shape advance round by round together ----------------
+ * Same functions as bppp_nl_* (proveRoundM, src/Bulletproof.hs:346-355) with a leading batch dimension on every array:
+ * one proof cannot fill the chip (its MSMs have < 800 terms, its basis fold is one ~1.5 ms dependency chain), B proofs
+ * share every launch.  The starting basis (g, G, H) is shared; q, s and the vectors are per proof ([batch][...]). */
+typedef struct bppp_nlb bppp_nlb;
+int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
+                    const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
+                    bppp_nlb **out);
+void bppp_nlb_destroy(bppp_nlb *nlb);
+int bppp_nlb_lengths(const bppp_nlb *nlb, size_t *batch, size_t *nlen, size_t *llen);
+int bppp_nlb_round_commit(bppp_nlb *nlb, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy);   /* [batch][4], [batch][8] */
+int bppp_nlb_round_collapse(bppp_nlb *nlb, const uint64_t *es);                                         /* [batch][4] */
+int bppp_nlb_get_witness(bppp_nlb *nlb, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s);
 
 /* ---- a12: the inner-product flavour (src/Bulletproof/InnerProductArgument.hs; the CLI's default, app/Parse.hs:100)
  * Same contract as bppp_nl_*.  `r` is the argument of makeNorm (:194-206; q = r^4): the norm vector (nlen scalars on nlen

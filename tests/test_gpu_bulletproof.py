@@ -226,3 +226,33 @@ def test_prove_loop_in_library_with_oracle_callback(gpu, oracle_lib):
     nw, lw = com.getWitness()
     assert (nw, lw) == (fin.body.norm.get_witness(), fin.body.lin.get_witness())
     com.close()
+
+
+@pytest.mark.parametrize("nl,ll,B", [(12, 5, 3), (33, 6, 5), (64, 7, 2), (7, 0, 2), (0, 6, 2)])
+def test_lockstep_batch_prover_equals_oracle(gpu, oracle_lib, nl, ll, B):
+    """bppp_nlb_*: B proofs advanced together; each proof's responses, challenges and final opening equal the oracle's
+    single-proof run with that proof's own injected oracle."""
+    from bulletproofspp_amd.bulletproof import NormLinearBatch, proveBPM_batch
+    g, gs, hs, _, _, _, _ = _instance(nl, ll, 7000 + nl)
+    rnd = random.Random(B * 100 + nl)
+    xs = [[rnd.randrange(O.N) for _ in range(nl)] for _ in range(B)]
+    ls = [[rnd.randrange(O.N) for _ in range(ll)] for _ in range(B)]
+    cs = [[rnd.randrange(O.N) for _ in range(ll)] for _ in range(B)]
+    qs = [rnd.randrange(1, O.N) for _ in range(B)]
+    rounds, _ = O.optimal_witness_size_nl(nl, ll)
+    rounds = max(rounds, 1)
+    want, ss = [], []
+    for b in range(B):
+        body = O.NormLinear.make(1, qs[b], cs[b], xs[b], gs, ls[b], hs)
+        wit = O.PSV(body.eval_scalar(), g, body)
+        ss.append(wit.sc)
+        want.append(O.prove_bp(rounds, wit, O.Transcript(O.sha_oracle_fn(b"b%d" % b)), oracle_lib))
+    com = NormLinearBatch(gpu, ss, g, qs, cs, xs, gs, ls, hs)
+    trs = [O.Transcript(O.sha_oracle_fn(b"b%d" % b)) for b in range(B)]
+    resps, es = proveBPM_batch(rounds, com, [t.oracle for t in trs])
+    nws, lws, s_fin = com.getWitness()
+    com.close()
+    for b in range(B):
+        fin, resps_o, es_o = want[b]
+        assert resps[b] == resps_o and es[b] == es_o
+        assert nws[b] == fin.body.norm.get_witness() and lws[b] == fin.body.lin.get_witness() and s_fin[b] == fin.sc
