@@ -244,7 +244,10 @@ def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64b
     ss_ = rnd_fr((batch,))        # the scalar on g only shifts the commitments; any value exercises the same work
     lib = gpu.lib
 
+    tm = {"create": 0.0, "round_commit": 0.0, "oracle_hash": 0.0, "round_collapse": 0.0, "get_witness": 0.0}
+
     def one_batch():
+        t = time.perf_counter()
         h = C.c_void_p()
         rc = lib.bppp_nlb_create(gpu.h, batch, _ptr(ss_), _ptr(P[0:1]), _ptr(qs_), _ptr(xs_.reshape(-1, 4)), _ptr(P[1 + llen:1 + llen + nlen]), nlen,
                                  _ptr(cs_.reshape(-1, 4)), _ptr(ls_.reshape(-1, 4)), _ptr(P[1:1 + llen]), llen, C.byref(h))
@@ -252,22 +255,29 @@ def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64b
         sX, sR = np.zeros((batch, 4), dtype=np.uint64), np.zeros((batch, 4), dtype=np.uint64)
         X, R = np.zeros((batch, 8), dtype=np.uint64), np.zeros((batch, 8), dtype=np.uint64)
         digests = [b"bppp%d" % b for b in range(batch)]
-        es = np.zeros((batch, 4), dtype=np.uint64)
+        t2 = time.perf_counter(); tm["create"] += t2 - t; t = t2
         for _ in range(k):
             gpu._check(lib.bppp_nlb_round_commit(h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nlb_round_commit")
+            t2 = time.perf_counter(); tm["round_commit"] += t2 - t; t = t2
             xb, rb = X.tobytes(), R.tobytes()
+            eb = []
             for b in range(batch):
-                digests[b] = hashlib.sha256(digests[b] + xb[64 * b:64 * b + 64] + rb[64 * b:64 * b + 64]).digest()
-                e = int.from_bytes(digests[b], "little") % N_ORDER
-                es[b] = [(e >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+                d = digests[b] = hashlib.sha256(digests[b] + xb[64 * b:64 * b + 64] + rb[64 * b:64 * b + 64]).digest()
+                eb.append((int.from_bytes(d, "little") % N_ORDER).to_bytes(32, "little"))
+            es = np.frombuffer(b"".join(eb), dtype=np.uint64).reshape(batch, 4)
+            t2 = time.perf_counter(); tm["oracle_hash"] += t2 - t; t = t2
             gpu._check(lib.bppp_nlb_round_collapse(h, _ptr(es)), "bppp_nlb_round_collapse")
+            t2 = time.perf_counter(); tm["round_collapse"] += t2 - t; t = t2
         nw, lw, s = np.zeros((batch * fn, 4), dtype=np.uint64), np.zeros((batch * fl, 4), dtype=np.uint64), np.zeros((batch, 4), dtype=np.uint64)
         gpu._check(lib.bppp_nlb_get_witness(h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_nlb_get_witness")
         lib.bppp_nlb_destroy(h)
+        tm["get_witness"] += time.perf_counter() - t
         return X
 
     one_batch()
     torch.cuda.synchronize()
+    for kk in tm:
+        tm[kk] = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         one_batch()
@@ -275,6 +285,7 @@ def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64b
     dt = time.perf_counter() - t0
     return {"metric": "norm_linear_arguments_proved_per_sec", "value": batch * steps / dt, "unit": "proofs/s", "ms_per_batch": dt / steps * 1e3,
             "batch": batch, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
+            "host_call_ms_per_batch": {kk: v / steps * 1e3 for kk, v in tm.items()},
             "note": "lockstep batch prover (bppp_nlb_*): 2*batch round commitments per round as one batched MSM, all basis folds as one launch; "
                     "host SHA-256 stand-in oracle inside the timed region; state upload + final opening download included"}
 

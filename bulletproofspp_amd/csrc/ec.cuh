@@ -107,7 +107,7 @@ BPPP_DI void xyzz_add(xyzz &acc, const xyzz &q) {
 }
 
 // normalize / jacToAff (Commitment.hs:121, :172-173): one inversion per point; canonical output.
-__device__ __noinline__ aff xyzz_to_aff(const xyzz &p) {
+BPPP_DI aff xyzz_to_aff(const xyzz &p) {
   if (xyzz_is_inf(p)) return aff_inf();
   fq inv = fq_inv(fq_mul(p.ZZ, p.ZZZ));
   aff r;

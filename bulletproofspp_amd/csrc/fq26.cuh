@@ -223,7 +223,7 @@ BPPP_DI fq fq_sqr_n(fq x, int n) {
   for (int i = 0; i < n; i++) x = fq_sqr(x);
   return x;
 }
-__device__ __noinline__ fq fq_inv(const fq &a) {
+BPPP_DI fq fq_inv(const fq &a) {
   fq x2 = fq_mul(fq_sqr(a), a);
   fq x3 = fq_mul(fq_sqr(x2), a);
   fq x6 = fq_mul(fq_sqr_n(x3, 3), x3);

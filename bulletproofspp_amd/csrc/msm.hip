@@ -383,6 +383,38 @@ __global__ void __launch_bounds__(64) k_reduce2(const uint32_t *__restrict__ red
   if (lane == 0) xyzz_store(winsum + (size_t)nbw * XYZZ_WORDS, v);
 }
 
+// Many small windows (batched MSMs of a few hundred terms: M <= 256 buckets per window, thousands of windows): a whole
+// wavefront per window leaves most lanes idle and pays two 6-step scans.  Here a GROUP of G lanes (G | 64, G <= M) owns one
+// window: lane g sums its Lw = M/G buckets serially, the G lane sums go through a log2(G)-step suffix scan inside the
+// group, and the window sum goes straight to `winsum` (no k_reduce2 pass).
+__global__ void __launch_bounds__(64) k_reduce_groups(const uint32_t *__restrict__ buckets, int M, int G, uint32_t NB, uint32_t *__restrict__ winsum) {
+  const uint32_t lane = threadIdx.x, gl = lane & (uint32_t)(G - 1);
+  const uint32_t nbw = (blockIdx.x * 64u + lane) / (uint32_t)G;
+  const int Lw = M / G;
+  xyzz run = xyzz_inf(), acc = xyzz_inf();
+  if (nbw < NB) {
+    const uint32_t *b = buckets + ((size_t)nbw * M + (size_t)gl * Lw) * XYZZ_WORDS;
+    for (int k = Lw - 1; k >= 0; k--) {
+      xyzz B = xyzz_load(b + (size_t)k * XYZZ_WORDS);
+      xyzz_add(run, B);
+      xyzz_add(acc, run);
+    }
+  }
+  xyzz suf = run;                                // inclusive suffix scan of the lane sums inside the group
+  for (int d = 1; d < G; d <<= 1) {
+    xyzz o = xyzz_shfl_down(suf, d);
+    if ((int)gl + d < G) xyzz_add(suf, o);
+  }
+  xyzz v = (gl >= 1) ? suf : xyzz_inf();         // sum_g g * S_g = sum_{g>=1} suf_g, times Lw
+  for (int k = Lw; k > 1; k >>= 1) v = xyzz_dbl(v);
+  xyzz_add(v, acc);
+  for (int d = G >> 1; d >= 1; d >>= 1) {
+    xyzz o = xyzz_shfl_down(v, d);
+    if ((int)gl + d < G) xyzz_add(v, o);
+  }
+  if (gl == 0 && nbw < NB) xyzz_store(winsum + (size_t)nbw * XYZZ_WORDS, v);
+}
+
 // 5. batched window combine: one lane per MSM instance
 __global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restrict__ winsum, int W, int c, uint32_t batch, uint32_t *__restrict__ out_aff) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,18 +430,20 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restric
 
 // ------------------------------------------------------------------------------------------------
 // host orchestration
-static int choose_window(size_t n) {
+static int choose_window(size_t n, size_t batch) {
   // Cost model in units of one mixed addition (~68 ps chip-wide, measured at 2^20; profiles/):
   //   accumulate: one addition per (scalar, window that holds real bits): ceil(255/c) windows (+ half a window when
   //               c divides 255: the top digit then wraps for half the scalars and a carry window appears);
-  //   reduce:     ~10 per bucket (the wave-prefix bucket reduction is latency-bound; fitted at c = 13..16);
+  //   reduce:     ~10 per bucket (the wave-prefix bucket reduction is latency-bound; fitted at c = 13..16); ~4.5 per
+  //               bucket for a large batch of small MSMs, which goes through k_reduce_groups (throughput-bound);
   //   heavy top:  when the top window has few real bits its buckets hold n / 2^r entries each and go through the
   //               wave-cooperative merge tree: a flat ~1.5e6 (0.1 ms) once they span many lanes.
   double best = 1e300; int bc = 8;
   for (int c = 4; c <= 16; c++) {
     int W = 256 / c + 1, full = 254 / c, r = 255 - c * full;       // r = real bits in the top window (1..c)
     double weff = full + 1 + (r == c ? 0.5 : 0.0);
-    double cost = weff * (double)n + 10.0 * W * (double)(1u << (c - 1));
+    const bool groups = c <= 9 && (double)batch * W >= 4096.0;
+    double cost = weff * (double)n + (groups ? 4.5 : 10.0) * W * (double)(1u << (c - 1));
     double top_bucket = r == c ? n / 2.0 : (double)n / (double)(1u << (r < 20 ? r : 20));
     if ((r == c || r < c - 1) && top_bucket > 1024.0) cost += 1.5e6;
     if (cost < best) { best = cost; bc = c; }
@@ -421,6 +455,7 @@ struct MsmPlan {
   size_t n, batch; int c, W, M, CH, hist_threads, Lw, WPW;
   uint64_t NB, FB, total_max;
   int L; uint64_t G;           // sorted entries per lane, number of lanes
+  int RG;                      // k_reduce_groups lanes per window (0 = wave-per-window path)
   int ntiles;
 };
 
@@ -442,6 +477,8 @@ static MsmPlan make_plan(size_t n, size_t batch, int c) {
     p.WPW = p.M / p.Lw / 64;
     if (p.WPW < 1) p.WPW = 1;
   }
+  p.RG = 0;
+  if (p.M <= 256 && p.NB >= 4096) p.RG = std::min(8, p.M);   // M is a power of two >= 2
   // slice length: long enough that few buckets straddle lanes, short enough to keep >= ~64K lanes
   p.L = 4;
   while (p.L < 64 && p.total_max / (uint64_t)(2 * p.L) >= 65536) p.L <<= 1;
@@ -467,7 +504,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
   if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
   if (!d_scalars || !d_points) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
   if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "msm: n must be < 2^31");
-  int c = window_bits ? window_bits : choose_window(n);
+  int c = window_bits ? window_bits : choose_window(n, batch);
   if (c < 2 || c > 16) return fail(ctx, BPPP_ERR_ARG, "msm: window_bits must be in [2,16]");
   MsmPlan p = make_plan(n, batch, c);
   if (p.FB >= (1ull << 32) - 1 || p.total_max >= (1ull << 32) - 1)
@@ -529,8 +566,12 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     k_merge_heavy2<<<dim3(256), dim3(64), 0, st>>>(heavy_buckets, heavy_count, chunk_sums, buckets);
     prof_mark(ctx, 4);
     // 4. bucket reduce
-    k_reduce1<<<dim3((unsigned)p.NB, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
-    k_reduce2<<<dim3((unsigned)p.NB), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
+    if (p.RG) {
+      k_reduce_groups<<<dim3((unsigned)((p.NB * p.RG + 63) / 64)), dim3(64), 0, st>>>(buckets, p.M, p.RG, (uint32_t)p.NB, winsum);
+    } else {
+      k_reduce1<<<dim3((unsigned)p.NB, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
+      k_reduce2<<<dim3((unsigned)p.NB), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
+    }
     prof_mark(ctx, 5);
     // 5. window combine
     if (batch > 4) {

@@ -7,6 +7,8 @@
 // share that proof's basis), B x ceil(n/2) basis folds are ONE launch with per-proof reduced scalars, and the Fr vector work
 // is one workgroup per proof.  The bases diverge after the first collapse (different challenges), so they are stored per proof.
 #include <string.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "ctx.hpp"
 #include "ec.cuh"
@@ -152,6 +154,17 @@ __global__ void k_nlb_move_g(const uint32_t *__restrict__ P, uint32_t cap, uint3
 using namespace bppp;
 using namespace bppp_host;
 
+// per-proof host arithmetic of a round (two half-GCDs and a few Fr products each) spread over the host cores: at B in the
+// thousands it is otherwise as long as the round's GPU work
+template <class F> static void parallel_for(size_t n, F f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 64);
+  if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++) th.emplace_back([=] { for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i); });
+  for (auto &x : th) x.join();
+}
+
 struct bppp_nlb {
   bppp_ctx *ctx;
   size_t batch, n, l, n0, l0, cap, xstride, lstride;   // cap: allocation per proof; the CURRENT point stride is even(n)+even(l)+1
@@ -181,6 +194,17 @@ void bppp_nlb_destroy(bppp_nlb *o) {
 
 // `batch` x makeNormLinearBP' 1 q_b cs_b nss_b ngs lss_b lgs (NormArgument.hs:162) inside makePSV s_b g: the basis (g, G, H) is
 // shared by all proofs at the start; scalars are [batch][...] host arrays.
+}  // extern "C"
+namespace bppp {
+// copy one basis (words4 uint4) to every proof's slot
+__global__ void __launch_bounds__(256) k_nlb_broadcast(const uint4 *__restrict__ src, uint32_t words4, uint4 *__restrict__ dst, uint32_t batch) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= words4) return;
+  uint4 v = src[i];
+  for (uint32_t b = blockIdx.y; b < batch; b += gridDim.y) dst[(size_t)b * words4 + i] = v;
+}
+}  // namespace bppp
+extern "C" {
 int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
                     const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
                     bppp_nlb **out) {
@@ -213,11 +237,15 @@ int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
     NLB_HIP(o, hipMemcpy2DAsync(o->lc[0], o->lstride * 32, lin_c, llen * 32, llen * 32, batch, hipMemcpyHostToDevice, st));
     NLB_HIP(o, hipMemcpy2DAsync(o->lx[0], o->lstride * 32, lin_x, llen * 32, llen * 32, batch, hipMemcpyHostToDevice, st));
   }
-  for (size_t b = 0; b < batch; b++) {     // the shared starting basis, one copy per proof (they diverge after round 1)
-    uint32_t *pb = o->P[0] + b * o->cap * 16;
-    if (nlen) NLB_HIP(o, hipMemcpyAsync(pb, norm_g_xy, nlen * 64, hipMemcpyHostToDevice, st));
-    if (llen) NLB_HIP(o, hipMemcpyAsync(pb + evb(nlen) * 16, lin_h_xy, llen * 64, hipMemcpyHostToDevice, st));
-    NLB_HIP(o, hipMemcpyAsync(pb + (evb(nlen) + evb(llen)) * 16, g_xy, 64, hipMemcpyHostToDevice, st));
+  {   // the shared starting basis: uploaded once (staged in the not-yet-used second buffer), then one copy per proof (they diverge after round 1)
+    uint32_t *stg = o->P[1];
+    NLB_HIP(o, hipMemsetAsync(stg, 0, o->cap * 64, st));
+    if (nlen) NLB_HIP(o, hipMemcpyAsync(stg, norm_g_xy, nlen * 64, hipMemcpyHostToDevice, st));
+    if (llen) NLB_HIP(o, hipMemcpyAsync(stg + evb(nlen) * 16, lin_h_xy, llen * 64, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemcpyAsync(stg + (evb(nlen) + evb(llen)) * 16, g_xy, 64, hipMemcpyHostToDevice, st));
+    const size_t words4 = o->cap * 4;     // uint4 per basis
+    k_nlb_broadcast<<<dim3((unsigned)((words4 + 255) / 256), (unsigned)std::min<size_t>(batch, 65535)), dim3(256), 0, st>>>(
+        (const uint4 *)stg, (uint32_t)words4, (uint4 *)o->P[0], (uint32_t)batch);
   }
   o->q.resize(batch); o->qinv.resize(batch); o->nn.assign(batch, U256::one()); o->ln.assign(batch, U256::one());
   o->s.resize(batch); o->sX.resize(batch); o->sR.resize(batch);
@@ -285,25 +313,28 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   auto put5 = [](uint32_t *dst, const SInt &v) { for (int i = 0; i < 5; i++) dst[i] = (uint32_t)(v.m[i / 2] >> (32 * (i & 1))); };
   auto put8 = [](uint32_t *dst, const U256 &v) { for (int i = 0; i < 8; i++) dst[i] = (uint32_t)(v.w[i / 2] >> (32 * (i & 1))); };
   std::vector<U256> inv(2 * B, U256::zero()), a0l(B), b0n(B), b0l(B);
-  for (size_t b = 0; b < B; b++) {
+  for (size_t b = 0; b < B; b++)
+    if (cmp(U256::load(es + 4 * b), M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
+  std::atomic<int> too_big{0};
+  parallel_for(B, [&](size_t b) {
     const U256 e = U256::load(es + 4 * b);
-    if (cmp(e, M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
     U256 e1 = msub(mmul(e, e, M), U256::one(), M);
     o->s[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
     memset(&K[b], 0, sizeof(CollapseK));
     if (o->n) {
       auto ab = rational_reduce_scalar(mmul(e, o->qinv[b], M));
-      if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
+      if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) too_big = 1;
       b0n[b] = extract_scalar(ab.second); inv[2 * b] = b0n[b];
       put5(K[b].nb, ab.second); put5(K[b].na, ab.first); K[b].nbneg = ab.second.neg; K[b].naneg = ab.first.neg;
     }
     if (o->l) {
       auto ab = rational_reduce_scalar(e);
-      if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
+      if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) too_big = 1;
       a0l[b] = extract_scalar(ab.first); b0l[b] = extract_scalar(ab.second); inv[2 * b + 1] = b0l[b];
       put5(K[b].lb, ab.second); put5(K[b].la, ab.first); K[b].lbneg = ab.second.neg; K[b].laneg = ab.first.neg;
     }
-  }
+  });
+  if (too_big) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
   batch_minv(inv.data(), 2 * B, M);              // every b0^-1 of the round with ONE field inversion
   for (size_t b = 0; b < B; b++) {
     const U256 e = U256::load(es + 4 * b);

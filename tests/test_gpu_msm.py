@@ -89,6 +89,31 @@ def test_msm_batch(gpu, oracle_lib):
     assert got == [oracle_lib.inner_product(list(zip(s, pts))) for s in sc]
 
 
+@pytest.mark.parametrize("n,batch,c,per_instance", [(37, 160, 0, True), (64, 1100, 5, False), (21, 2100, 2, True), (50, 200, 9, True)])
+def test_msm_many_small_instances(gpu, oracle_lib, n, batch, c, per_instance):
+    """Thousands of (instance, window) pairs with <= 256 buckets each: the grouped bucket reduction (k_reduce_groups) instead
+    of one wavefront per window.  Zero scalars, repeated points and an all-zero instance included."""
+    rnd = random.Random(n * 1000 + batch)
+    base = O.hash_points(b"many", n * (3 if per_instance else 1))
+    sc = [[rnd.randrange(O.N) if rnd.random() > 0.1 else 0 for _ in range(n)] for _ in range(batch)]
+    sc[3] = [0] * n
+    sc[5] = [1] * n
+    ds = gpu.to_device(np.concatenate([scalars_to_array(s) for s in sc]))
+    if per_instance:
+        pts = [[base[(b * 7 + j) % len(base)] for j in range(n)] for b in range(batch)]
+        dp = gpu.to_device(np.concatenate([points_to_array(p) for p in pts]))
+    else:
+        pts = [base] * batch
+        dp = gpu.to_device(points_to_array(base))
+    try:
+        got = gpu.msm_batch_device(ds, dp, n, batch, shared_points=not per_instance, window_bits=c)
+    finally:
+        gpu.free(ds); gpu.free(dp)
+    check = list(range(0, batch, max(1, batch // 40))) + [3, 5, batch - 1]
+    for b in check:
+        assert got[b] == oracle_lib.inner_product(list(zip(sc[b], pts[b]))), b
+
+
 def test_msm_2_16_matches_oracle(gpu, oracle_lib):
     """BASELINE config 2: 2^16-term MSM, bit-exact vs the Straus restatement (a few seconds of CPU)."""
     n = 1 << 16
