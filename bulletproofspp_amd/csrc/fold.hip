@@ -5,57 +5,50 @@
 // called from the three `collapse` methods (NormArgument.hs:71, :129; InnerProductArgument.hs:100-101).
 //
 // The reference runs a 129-row Straus loop per pair and pays one field inversion per pair
-// (normalizeBasis on two points, Commitment.hs:347).  Here every lane owns one pair and all lanes
-// walk the same 129-row double/add schedule (the scalars are wave-uniform, so the row branches
-// are scalar branches: no divergence); inputs are already affine, so no normalisation pass.
+// (normalizeBasis on two points, Commitment.hs:347).  Here every lane owns one pair and walks the joint-sparse-form
+// schedule of (b', a') against its own four-entry table in LDS (foldcore.cuh); inputs are already affine.
 #include <string.h>
 #include "ctx.hpp"
-#include "ec.cuh"
+#include "foldcore.cuh"
+#include "hostmath.hpp"
 
 namespace bppp {
 
-struct FoldK { uint32_t b[5], a[5]; int bneg, aneg; };
+struct FoldK { uint32_t dig[FOLD_DIGIT_WORDS]; int bneg, aneg; };
 
 __global__ void __launch_bounds__(64) k_fold_points(const uint32_t *__restrict__ pts, uint32_t n, FoldK K, uint32_t *__restrict__ out) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t np = (n + 1) / 2;
-  if (j >= np) return;
-  aff GL = aff_cneg(aff_load(pts + (size_t)(2 * j) * 16), K.bneg != 0);
-  aff GR = aff_inf();
-  if (2 * j + 1 < n) GR = aff_cneg(aff_load(pts + (size_t)(2 * j + 1) * 16), K.aneg != 0);
-  xyzz acc = xyzz_inf();
-  // rationalReducedScalarLength = 129 rows, most significant first (Commitment.hs:286, :348-353)
-  for (int row = 128; row >= 0; row--) {
-    acc = xyzz_dbl(acc);
-    if ((K.b[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GL);
-    if ((K.a[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GR);
+  __shared__ uint32_t tab[FOLD_TAB_WORDS];
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, np = (n + 1) / 2;
+  aff GL = aff_inf(), GR = aff_inf();
+  if (j < np) {
+    GL = aff_cneg(aff_load(pts + (size_t)(2 * j) * 16), K.bneg != 0);
+    if (2 * j + 1 < n) GR = aff_cneg(aff_load(pts + (size_t)(2 * j + 1) * 16), K.aneg != 0);
   }
-  aff_store(out + (size_t)j * 16, xyzz_to_aff(acc));
+  aff r = fold_pair_jsf(GL, GR, K.dig, tab, threadIdx.x);
+  if (j < np) aff_store(out + (size_t)j * 16, r);
 }
 
-// Several independent folds in ONE launch (norm basis, linear basis, ... of one collapse): each workgroup belongs to one
-// segment, so the row schedule is still wave-uniform; the folds' ~1.5 ms dependency chains then run side by side
-// instead of back to back.
-struct FoldSeg { FoldK K; const uint32_t *pts; uint32_t *out; uint32_t n, first_block; };
-struct FoldSegs { FoldSeg s[3]; int nseg; };
-__global__ void __launch_bounds__(64) k_fold_points_multi(FoldSegs S) {
+// Several independent folds in ONE launch (norm basis, linear basis, ... of one collapse): the pairs of all segments are
+// numbered consecutively, so wavefronts are full even when a segment is short; a lane reads the digits of its own segment.
+struct FoldSeg { FoldK K; const uint32_t *pts; uint32_t *out; uint32_t n, first_pair; };
+struct FoldSegs { FoldSeg s[3]; int nseg; uint32_t total_pairs; };
+__global__ void __launch_bounds__(64) k_fold_points_multi(FoldSegs S_) {
+  const FoldSegs *S = &S_;
+  __shared__ uint32_t tab[FOLD_TAB_WORDS];
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   int si = 0;
-  if (S.nseg > 1 && blockIdx.x >= S.s[1].first_block) si = 1;
-  if (S.nseg > 2 && blockIdx.x >= S.s[2].first_block) si = 2;
-  const FoldSeg &sg = S.s[si];
-  uint32_t j = (blockIdx.x - sg.first_block) * blockDim.x + threadIdx.x;
-  uint32_t np = (sg.n + 1) / 2;
-  if (j >= np) return;
-  aff GL = aff_cneg(aff_load(sg.pts + (size_t)(2 * j) * 16), sg.K.bneg != 0);
-  aff GR = aff_inf();
-  if (2 * j + 1 < sg.n) GR = aff_cneg(aff_load(sg.pts + (size_t)(2 * j + 1) * 16), sg.K.aneg != 0);
-  xyzz acc = xyzz_inf();
-  for (int row = 128; row >= 0; row--) {
-    acc = xyzz_dbl(acc);
-    if ((sg.K.b[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GL);
-    if ((sg.K.a[row >> 5] >> (row & 31)) & 1u) xyzz_madd(acc, GR);
+  if (S->nseg > 1 && g >= S->s[1].first_pair) si = 1;
+  if (S->nseg > 2 && g >= S->s[2].first_pair) si = 2;
+  const FoldSeg *sg = &S->s[si];
+  const uint32_t j = g - sg->first_pair;
+  const bool active = g < S->total_pairs;
+  aff GL = aff_inf(), GR = aff_inf();
+  if (active) {
+    GL = aff_cneg(aff_load(sg->pts + (size_t)(2 * j) * 16), sg->K.bneg != 0);
+    if (2 * j + 1 < sg->n) GR = aff_cneg(aff_load(sg->pts + (size_t)(2 * j + 1) * 16), sg->K.aneg != 0);
   }
-  aff_store(sg.out + (size_t)j * 16, xyzz_to_aff(acc));
+  aff r = fold_pair_jsf(GL, GR, sg->K.dig, tab, threadIdx.x);
+  if (active) aff_store(sg->out + (size_t)j * 16, r);
 }
 
 // pointX (app/Main.hs:68-72): y = sqrt(x^3 + 7) = (x^3+7)^((p+1)/4) since p = 3 mod 4; even root.
@@ -96,13 +89,8 @@ int lift_x_run(bppp_ctx *ctx, const void *d_x, size_t n, void *d_out) {
 
 static int make_fold_k(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg, FoldK &K) {
   memset(&K, 0, sizeof K);
-  for (int i = 0; i < 3; i++) {
-    if (2 * i < 5) K.b[2 * i] = (uint32_t)b_mag[i];
-    if (2 * i + 1 < 5) K.b[2 * i + 1] = (uint32_t)(b_mag[i] >> 32);
-    if (2 * i < 5) K.a[2 * i] = (uint32_t)a_mag[i];
-    if (2 * i + 1 < 5) K.a[2 * i + 1] = (uint32_t)(a_mag[i] >> 32);
-  }
   if ((b_mag[2] >> 1) || (a_mag[2] >> 1)) return fail(ctx, BPPP_ERR_ARG, "fold_points: reduced scalar exceeds 129 bits");
+  bppp_host::jsf_recode(b_mag, a_mag, K.dig);
   K.bneg = b_neg; K.aneg = a_neg;
   return BPPP_OK;
 }
@@ -110,18 +98,19 @@ static int make_fold_k(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const 
 int fold_points_multi_run(bppp_ctx *ctx, int nseg, const uint64_t *const b_mag[], const int b_neg[], const uint64_t *const a_mag[], const int a_neg[],
                           const void *const d_pts[], const size_t n[], void *const d_out[]) {
   FoldSegs S; memset(&S, 0, sizeof S);
-  uint32_t blocks = 0;
+  uint32_t pairs = 0;
   for (int i = 0; i < nseg && i < 3; i++) {
     if (!n[i]) continue;
     if (!d_pts[i] || !d_out[i] || n[i] >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_points_multi: bad segment");
     FoldSeg &sg = S.s[S.nseg];
     int rc = make_fold_k(ctx, b_mag[i], b_neg[i], a_mag[i], a_neg[i], sg.K); if (rc) return rc;
-    sg.pts = (const uint32_t *)d_pts[i]; sg.out = (uint32_t *)d_out[i]; sg.n = (uint32_t)n[i]; sg.first_block = blocks;
-    blocks += (uint32_t)(((n[i] + 1) / 2 + 63) / 64);
+    sg.pts = (const uint32_t *)d_pts[i]; sg.out = (uint32_t *)d_out[i]; sg.n = (uint32_t)n[i]; sg.first_pair = pairs;
+    pairs += (uint32_t)((n[i] + 1) / 2);
     S.nseg++;
   }
   if (!S.nseg) return BPPP_OK;
-  k_fold_points_multi<<<dim3(blocks), dim3(64), 0, ctx->stream>>>(S);
+  S.total_pairs = pairs;
+  k_fold_points_multi<<<dim3((pairs + 63) / 64), dim3(64), 0, ctx->stream>>>(S);
   BPPP_HIP(ctx, hipGetLastError());
   return BPPP_OK;
 }

@@ -256,6 +256,29 @@ inline SInt squot(const SInt &a, const SInt &b) {
   return q;
 }
 
+// Joint sparse form (Solinas, "Low-weight binary representations for pairs of integers") of two magnitudes < 2^129:
+// digits (u0_i, u1_i) in {-1,0,1}^2 with sum_i u_i 2^i = k and at most half of the rows non-zero on average.
+// Output: 4 bits per row, [1:0] = code(u0), [3:2] = code(u1), code(0)=0, code(+1)=1, code(-1)=3; 130 rows in 17 words.
+// Consumed by foldcore.cuh (device) as the add schedule of b'*GL + a'*GR.
+inline void jsf_recode(const uint64_t k0_[3], const uint64_t k1_[3], uint32_t out[17]) {
+  uint64_t k0[3] = {k0_[0], k0_[1], k0_[2]}, k1[3] = {k1_[0], k1_[1], k1_[2]};
+  memset(out, 0, 17 * sizeof(uint32_t));
+  unsigned d0 = 0, d1 = 0;
+  auto nz = [](const uint64_t *k) { return (k[0] | k[1] | k[2]) != 0; };
+  auto shr1 = [](uint64_t *k) { k[0] = (k[0] >> 1) | (k[1] << 63); k[1] = (k[1] >> 1) | (k[2] << 63); k[2] >>= 1; };
+  for (int i = 0; i < 130 && (nz(k0) || nz(k1) || d0 || d1); i++) {
+    unsigned l0 = (unsigned)(k0[0] & 7) + d0, l1 = (unsigned)(k1[0] & 7) + d1;     // low bits of k + d (mod 8 is all we need)
+    int u0 = 0, u1 = 0;
+    if (l0 & 1) { u0 = 2 - (int)(l0 & 3); if (((l0 & 7) == 3 || (l0 & 7) == 5) && (l1 & 3) == 2) u0 = -u0; }
+    if (l1 & 1) { u1 = 2 - (int)(l1 & 3); if (((l1 & 7) == 3 || (l1 & 7) == 5) && (l0 & 3) == 2) u1 = -u1; }
+    if (2 * (int)d0 == 1 + u0) d0 = 1 - d0;
+    if (2 * (int)d1 == 1 + u1) d1 = 1 - d1;
+    shr1(k0); shr1(k1);
+    unsigned code = (u0 == 0 ? 0u : u0 > 0 ? 1u : 3u) | ((u1 == 0 ? 0u : u1 > 0 ? 1u : 3u) << 2);
+    out[i >> 3] |= code << (4 * (i & 7));
+  }
+}
+
 // reduceScalar (Commitment.hs:276-279): signed representative in (-n/2, n/2]
 inline SInt reduce_scalar(const U256 &x) {
   SInt r = SInt::zero();

@@ -11,7 +11,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
-#include "ec.cuh"
+#include "foldcore.cuh"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) k_nlb_round(const uint32_t *__restrict__ 
 
 // per-proof collapse constants: FoldK for the two basis folds and (u, v) for the three scalar folds
 struct CollapseK {
-  uint32_t nb[5], na[5], lb[5], la[5];   // reduced scalars b', a' of the norm fold and of the linear fold (magnitudes)
+  uint32_t dn[FOLD_DIGIT_WORDS], dl[FOLD_DIGIT_WORDS];   // joint-sparse-form digits of (b', a') for the norm fold and the linear fold
   int nbneg, naneg, lbneg, laneg;
   uint32_t nu[8], nv[8];                 // norm x' = nu xL + nv xR
   uint32_t cu[8], cv[8];                 // linear c' = cu cL + cv cR
@@ -117,32 +117,28 @@ __global__ void __launch_bounds__(256) k_nlb_fold_scalars(const uint32_t *__rest
   }
 }
 
-// basis folds of all proofs: blockIdx.y = proof, blockIdx.x covers [norm pair chunks | linear pair chunks]; the 129-row
-// schedule is uniform per workgroup (scalars from the proof's CollapseK through scalar loads)
+// basis folds of all proofs: the pairs [norm | linear] of every proof are numbered consecutively over the whole batch, so
+// wavefronts are full in every round (a late round has a handful of pairs per proof); each lane walks the digit schedule of
+// its own proof and fold (foldcore.cuh)
 __global__ void __launch_bounds__(64) k_nlb_fold_points(const uint32_t *__restrict__ P, uint32_t n, uint32_t l, uint32_t cap, uint32_t cap_out,
-                                                        const CollapseK *__restrict__ K, uint32_t nblk_norm, uint32_t *__restrict__ Po) {
-  const uint32_t b = blockIdx.y;
-  const bool lin = blockIdx.x >= nblk_norm;
-  const uint32_t cnt = lin ? l : n;
-  const uint32_t j = (lin ? blockIdx.x - nblk_norm : blockIdx.x) * blockDim.x + threadIdx.x;
-  if (j >= (cnt + 1) / 2) return;
+                                                        const CollapseK *__restrict__ K, uint32_t batch, uint32_t *__restrict__ Po) {
+  __shared__ uint32_t tab[FOLD_TAB_WORDS];
+  const uint32_t n2 = (n + 1) / 2, l2 = (l + 1) / 2, pp = n2 + l2;
+  const uint64_t g = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool active = g < (uint64_t)batch * pp;
+  const uint32_t b = active ? (uint32_t)(g / pp) : 0, r = active ? (uint32_t)(g % pp) : 0;
+  const bool lin = r >= n2;
+  const uint32_t cnt = lin ? l : n, j = lin ? r - n2 : r;
   const CollapseK &k = K[b];
-  const uint32_t *kb = lin ? k.lb : k.nb, *ka = lin ? k.la : k.na;
-  const bool bneg = (lin ? k.lbneg : k.nbneg) != 0, aneg = (lin ? k.laneg : k.naneg) != 0;
-  const uint32_t ne = n + (n & 1), n2 = (n + 1) / 2, ne2 = n2 + (n2 & 1);
-  const uint32_t *src = P + ((size_t)b * cap + (lin ? ne : 0)) * 16;
-  uint32_t *dst = Po + ((size_t)b * cap_out + (lin ? ne2 : 0)) * 16;
-  aff GL = aff_cneg(aff_load(src + (size_t)(2 * j) * 16), bneg);
-  aff GR = aff_inf();
-  if (2 * j + 1 < cnt) GR = aff_cneg(aff_load(src + (size_t)(2 * j + 1) * 16), aneg);
-  xyzz acc = xyzz_inf();
-  for (int row = 128; row >= 0; row--) {
-    uint32_t wb = __builtin_amdgcn_readfirstlane(kb[row >> 5]), wa = __builtin_amdgcn_readfirstlane(ka[row >> 5]);
-    acc = xyzz_dbl(acc);
-    if ((wb >> (row & 31)) & 1u) xyzz_madd(acc, GL);
-    if ((wa >> (row & 31)) & 1u) xyzz_madd(acc, GR);
+  const uint32_t ne = n + (n & 1), ne2 = n2 + (n2 & 1);
+  aff GL = aff_inf(), GR = aff_inf();
+  if (active) {
+    const uint32_t *src = P + ((size_t)b * cap + (lin ? ne : 0)) * 16;
+    GL = aff_cneg(aff_load(src + (size_t)(2 * j) * 16), (lin ? k.lbneg : k.nbneg) != 0);
+    if (2 * j + 1 < cnt) GR = aff_cneg(aff_load(src + (size_t)(2 * j + 1) * 16), (lin ? k.laneg : k.naneg) != 0);
   }
-  aff_store(dst + (size_t)j * 16, xyzz_to_aff(acc));
+  aff res = fold_pair_jsf(GL, GR, lin ? k.dl : k.dn, tab, threadIdx.x);
+  if (active) aff_store(Po + ((size_t)b * cap_out + (lin ? ne2 : 0) + j) * 16, res);
 }
 // g (and the infinity padding) of every proof carried into the next layout
 __global__ void k_nlb_move_g(const uint32_t *__restrict__ P, uint32_t cap, uint32_t cap_out, uint32_t src_off, uint32_t dst_off, uint32_t *__restrict__ Po) {
@@ -310,7 +306,6 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   const size_t ne = evb(o->n), le = evb(o->l), n2 = (o->n + 1) / 2, l2 = (o->l + 1) / 2, ne2 = evb(n2), le2 = evb(l2);
   hipStream_t st = ctx->stream;
   std::vector<CollapseK> K(B);
-  auto put5 = [](uint32_t *dst, const SInt &v) { for (int i = 0; i < 5; i++) dst[i] = (uint32_t)(v.m[i / 2] >> (32 * (i & 1))); };
   auto put8 = [](uint32_t *dst, const U256 &v) { for (int i = 0; i < 8; i++) dst[i] = (uint32_t)(v.w[i / 2] >> (32 * (i & 1))); };
   std::vector<U256> inv(2 * B, U256::zero()), a0l(B), b0n(B), b0l(B);
   for (size_t b = 0; b < B; b++)
@@ -325,13 +320,13 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
       auto ab = rational_reduce_scalar(mmul(e, o->qinv[b], M));
       if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) too_big = 1;
       b0n[b] = extract_scalar(ab.second); inv[2 * b] = b0n[b];
-      put5(K[b].nb, ab.second); put5(K[b].na, ab.first); K[b].nbneg = ab.second.neg; K[b].naneg = ab.first.neg;
+      jsf_recode(ab.second.m, ab.first.m, K[b].dn); K[b].nbneg = ab.second.neg; K[b].naneg = ab.first.neg;
     }
     if (o->l) {
       auto ab = rational_reduce_scalar(e);
       if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) too_big = 1;
       a0l[b] = extract_scalar(ab.first); b0l[b] = extract_scalar(ab.second); inv[2 * b + 1] = b0l[b];
-      put5(K[b].lb, ab.second); put5(K[b].la, ab.first); K[b].lbneg = ab.second.neg; K[b].laneg = ab.first.neg;
+      jsf_recode(ab.second.m, ab.first.m, K[b].dl); K[b].lbneg = ab.second.neg; K[b].laneg = ab.first.neg;
     }
   });
   if (too_big) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
@@ -357,11 +352,9 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   if (maxp) {
     k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride,
                                                                                    (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
-    uint32_t nbn = (uint32_t)((n2 + 63) / 64), nbl = (uint32_t)((l2 + 63) / 64);
-    if (!o->n) nbn = 0;
-    if (!o->l) nbl = 0;
-    k_nlb_fold_points<<<dim3(nbn + nbl, (unsigned)B), dim3(64), 0, st>>>(o->P[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)(ne + le + 1),
-                                                                         (uint32_t)(ne2 + le2 + 1), o->dK, nbn, o->P[d]);
+    const uint64_t pairs = (uint64_t)B * (n2 + l2);
+    k_nlb_fold_points<<<dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st>>>(o->P[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)(ne + le + 1),
+                                                                                (uint32_t)(ne2 + le2 + 1), o->dK, (uint32_t)B, o->P[d]);
   }
   k_nlb_move_g<<<dim3((unsigned)B), dim3(64), 0, st>>>(o->P[c], (uint32_t)(ne + le + 1), (uint32_t)(ne2 + le2 + 1), (uint32_t)(ne + le), (uint32_t)(ne2 + le2), o->P[d]);
   NLB_HIP(o, hipGetLastError());

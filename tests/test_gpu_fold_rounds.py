@@ -25,6 +25,20 @@ def test_fold_points_matches_pair_ip(gpu, oracle_lib, n):
     assert [array_to_point(got[j]) for j in range(len(want))] == want
 
 
+@pytest.mark.parametrize("b,a", [(1, 1), (1, -1), (0, 5), (7, 0), (0, 0), (-3, 2**128 + 12345), (2**129 - 1, -(2**129 - 1)),
+                                 (0x155555555555555555555555555555555, 0xAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA), (-(2**128), 2**64 - 1)])
+def test_fold_points_edge_pairs(gpu, oracle_lib, b, a):
+    """Pairs the joint-sparse-form table must get right by the group law: GR = GL (sum entry is a doubling, difference is
+    infinity), GR = -GL (the reverse), either or both members infinity, plus ordinary pairs; scalar edge cases."""
+    ec = O.PyEC()
+    h = O.hash_points(b"edge", 6)
+    neg = lambda p: (p[0], O.P - p[1])
+    pts = [h[0], h[0], h[1], neg(h[1]), None, h[2], h[3], None, None, None, h[4], h[5], h[5], h[5]]
+    got = gpu.fold_points(b, a, points_to_array(pts))
+    want = [oracle_lib.pair_ip(b, pts[2 * j], a, pts[2 * j + 1]) for j in range(len(pts) // 2)]
+    assert [array_to_point(got[j]) for j in range(len(want))] == want
+
+
 def test_rational_reduce_edges(gpu):
     rnd = random.Random(3)
     for x in [0, 1, 2, O.N - 1, O.N - 2, 2**128, 2**129, (O.N - 1) // 2, (O.N + 1) // 2] + [rnd.randrange(O.N) for _ in range(300)]:
