@@ -219,15 +219,18 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
     return res_d
 
 
-def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64"):
+def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64", pipelines: int = 2):
     """Lockstep batch prover (bppp_nlb_*): `batch` norm-linear arguments of the examples/64by64 shape advanced round by round
     together (proveBPM, src/Bulletproof.hs:357-359).  The injected oracle is a SHA-256 stand-in over the raw 128 bytes of each
     proof's (X, R) chained with that proof's previous digest; hashing runs on the host inside the timed region (it is part of
-    a prover's round trip), everything else on the GPU."""
+    a prover's round trip), everything else on the GPU.  The batch is split over `pipelines` contexts (one HIP stream and
+    one host thread each): a round's host share (challenge hashing, half-GCDs) and its latency-bound window combine
+    of one part overlap the other part's kernels."""
     import ctypes as C
     import hashlib
+    import threading
     from bulletproofspp_amd.bulletproof import N_ORDER
-    from bulletproofspp_amd.capi import _ptr, scalars_to_array
+    from bulletproofspp_amd.capi import Bppp, _ptr
     nlen, llen, k, fn, fl, _ = SHAPES[shape]
     rng = np.random.default_rng(0x9E0 + rank)
     need = 1 + llen + nlen
@@ -243,36 +246,59 @@ def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64b
     xs_, ls_, cs_, qs_ = rnd_fr((batch, nlen)), rnd_fr((batch, llen)), rnd_fr((batch, llen)), rnd_fr((batch,))
     ss_ = rnd_fr((batch,))        # the scalar on g only shifts the commitments; any value exercises the same work
     lib = gpu.lib
-
+    pipelines = max(1, min(pipelines, batch // 64 if batch >= 128 else 1))
+    ctxs = [gpu] + [Bppp(gpu_device(dev)) for _ in range(pipelines - 1)]
+    bounds = [batch * i // pipelines for i in range(pipelines + 1)]
     tm = {"create": 0.0, "round_commit": 0.0, "oracle_hash": 0.0, "round_collapse": 0.0, "get_witness": 0.0}
+    lock = threading.Lock()
+    errors = []
+
+    def part(g, lo, hi):
+        try:
+            nb = hi - lo
+            loc = dict.fromkeys(tm, 0.0)
+            t = time.perf_counter()
+            h = C.c_void_p()
+            c_ = lambda a: np.ascontiguousarray(a)
+            rc = lib.bppp_nlb_create(g.h, nb, _ptr(c_(ss_[lo:hi])), _ptr(P[0:1]), _ptr(c_(qs_[lo:hi])), _ptr(c_(xs_[lo:hi]).reshape(-1, 4)),
+                                     _ptr(P[1 + llen:1 + llen + nlen]), nlen, _ptr(c_(cs_[lo:hi]).reshape(-1, 4)), _ptr(c_(ls_[lo:hi]).reshape(-1, 4)),
+                                     _ptr(P[1:1 + llen]), llen, C.byref(h))
+            g._check(rc, "bppp_nlb_create")
+            sX, sR = np.zeros((nb, 4), dtype=np.uint64), np.zeros((nb, 4), dtype=np.uint64)
+            X, R = np.zeros((nb, 8), dtype=np.uint64), np.zeros((nb, 8), dtype=np.uint64)
+            digests = [b"bppp%d" % b for b in range(lo, hi)]
+            t2 = time.perf_counter(); loc["create"] += t2 - t; t = t2
+            for _ in range(k):
+                g._check(lib.bppp_nlb_round_commit(h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nlb_round_commit")
+                t2 = time.perf_counter(); loc["round_commit"] += t2 - t; t = t2
+                xb, rb = X.tobytes(), R.tobytes()
+                eb = []
+                for b in range(nb):
+                    d = digests[b] = hashlib.sha256(digests[b] + xb[64 * b:64 * b + 64] + rb[64 * b:64 * b + 64]).digest()
+                    eb.append((int.from_bytes(d, "little") % N_ORDER).to_bytes(32, "little"))
+                es = np.frombuffer(b"".join(eb), dtype=np.uint64).reshape(nb, 4)
+                t2 = time.perf_counter(); loc["oracle_hash"] += t2 - t; t = t2
+                g._check(lib.bppp_nlb_round_collapse(h, _ptr(es)), "bppp_nlb_round_collapse")
+                t2 = time.perf_counter(); loc["round_collapse"] += t2 - t; t = t2
+            nw, lw, s = np.zeros((nb * fn, 4), dtype=np.uint64), np.zeros((nb * fl, 4), dtype=np.uint64), np.zeros((nb, 4), dtype=np.uint64)
+            g._check(lib.bppp_nlb_get_witness(h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_nlb_get_witness")
+            lib.bppp_nlb_destroy(h)
+            loc["get_witness"] += time.perf_counter() - t
+            with lock:
+                for kk in tm:
+                    tm[kk] += loc[kk] / pipelines
+        except Exception as e:      # surfaced by one_batch
+            errors.append(e)
 
     def one_batch():
-        t = time.perf_counter()
-        h = C.c_void_p()
-        rc = lib.bppp_nlb_create(gpu.h, batch, _ptr(ss_), _ptr(P[0:1]), _ptr(qs_), _ptr(xs_.reshape(-1, 4)), _ptr(P[1 + llen:1 + llen + nlen]), nlen,
-                                 _ptr(cs_.reshape(-1, 4)), _ptr(ls_.reshape(-1, 4)), _ptr(P[1:1 + llen]), llen, C.byref(h))
-        gpu._check(rc, "bppp_nlb_create")
-        sX, sR = np.zeros((batch, 4), dtype=np.uint64), np.zeros((batch, 4), dtype=np.uint64)
-        X, R = np.zeros((batch, 8), dtype=np.uint64), np.zeros((batch, 8), dtype=np.uint64)
-        digests = [b"bppp%d" % b for b in range(batch)]
-        t2 = time.perf_counter(); tm["create"] += t2 - t; t = t2
-        for _ in range(k):
-            gpu._check(lib.bppp_nlb_round_commit(h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nlb_round_commit")
-            t2 = time.perf_counter(); tm["round_commit"] += t2 - t; t = t2
-            xb, rb = X.tobytes(), R.tobytes()
-            eb = []
-            for b in range(batch):
-                d = digests[b] = hashlib.sha256(digests[b] + xb[64 * b:64 * b + 64] + rb[64 * b:64 * b + 64]).digest()
-                eb.append((int.from_bytes(d, "little") % N_ORDER).to_bytes(32, "little"))
-            es = np.frombuffer(b"".join(eb), dtype=np.uint64).reshape(batch, 4)
-            t2 = time.perf_counter(); tm["oracle_hash"] += t2 - t; t = t2
-            gpu._check(lib.bppp_nlb_round_collapse(h, _ptr(es)), "bppp_nlb_round_collapse")
-            t2 = time.perf_counter(); tm["round_collapse"] += t2 - t; t = t2
-        nw, lw, s = np.zeros((batch * fn, 4), dtype=np.uint64), np.zeros((batch * fl, 4), dtype=np.uint64), np.zeros((batch, 4), dtype=np.uint64)
-        gpu._check(lib.bppp_nlb_get_witness(h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_nlb_get_witness")
-        lib.bppp_nlb_destroy(h)
-        tm["get_witness"] += time.perf_counter() - t
-        return X
+        th = [threading.Thread(target=part, args=(ctxs[i], bounds[i], bounds[i + 1])) for i in range(1, pipelines)]
+        for t_ in th:
+            t_.start()
+        part(ctxs[0], bounds[0], bounds[1])
+        for t_ in th:
+            t_.join()
+        if errors:
+            raise errors[0]
 
     one_batch()
     torch.cuda.synchronize()
@@ -283,11 +309,18 @@ def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64b
         one_batch()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for g in ctxs[1:]:
+        g.close()
     return {"metric": "norm_linear_arguments_proved_per_sec", "value": batch * steps / dt, "unit": "proofs/s", "ms_per_batch": dt / steps * 1e3,
-            "batch": batch, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
+            "batch": batch, "pipelines": pipelines, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
             "host_call_ms_per_batch": {kk: v / steps * 1e3 for kk, v in tm.items()},
             "note": "lockstep batch prover (bppp_nlb_*): 2*batch round commitments per round as one batched MSM, all basis folds as one launch; "
-                    "host SHA-256 stand-in oracle inside the timed region; state upload + final opening download included"}
+                    "host SHA-256 stand-in oracle inside the timed region; state upload + final opening download included; "
+                    "host_call_ms_per_batch is the mean over pipelines of the wall time inside each call"}
+
+
+def gpu_device(dev) -> int:
+    return dev.index if getattr(dev, "index", None) is not None else 0
 
 
 def main():
@@ -301,7 +334,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=4096, help="proofs per GPU in the batch-verify leg (0 = skip)")
     ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
-    ap.add_argument("--prove-batch", type=int, default=256, help="proofs advanced in lockstep in the prover leg (0 = skip; N = 1 only)")
+    ap.add_argument("--prove-pipelines", type=int, default=2, help="contexts (stream + host thread) the prover batch is split over")
+    ap.add_argument("--prove-batch", type=int, default=2048, help="proofs advanced in lockstep in the prover leg (0 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -386,7 +420,7 @@ def main():
 
     prove = None
     if args.prove_batch > 0 and world == 1:
-        prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2)
+        prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2, pipelines=args.prove_pipelines)
 
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}

@@ -152,12 +152,12 @@ using namespace bppp_host;
 
 // per-proof host arithmetic of a round (two half-GCDs and a few Fr products each) spread over the host cores: at B in the
 // thousands it is otherwise as long as the round's GPU work
-template <class F> static void parallel_for(size_t n, F f) {
+template <class F> static void parallel_ranges(size_t n, F f) {     // f(lo, hi) on disjoint ranges covering [0, n)
   unsigned hw = std::thread::hardware_concurrency();
   size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 64);
-  if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  if (nt <= 1) { f((size_t)0, n); return; }
   std::vector<std::thread> th;
-  for (size_t t = 0; t < nt; t++) th.emplace_back([=] { for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i); });
+  for (size_t t = 0; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
   for (auto &x : th) x.join();
 }
 
@@ -277,7 +277,7 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
   NLB_HIP(o, hipMemcpyAsync(sums.data(), o->sums, B * 128, hipMemcpyDeviceToHost, st));
   NLB_HIP(o, hipStreamSynchronize(st));
   std::vector<uint64_t> tails(B * 8);
-  for (size_t b = 0; b < B; b++) {
+  parallel_ranges(B, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) {
     U256 q = o->q[b], q2 = mmul(q, q, M), q3 = mmul(q2, q, M), q4 = mmul(q2, q2, M), n2 = mmul(o->nn[b], o->nn[b], M);
     U256 sXn = mmul(mmul(madd(n2, n2, M), q3, M), U256::load(&sums[16 * b]), M);         // 2 n^2 q^3 sX'  (NormArgument.hs:113)
     U256 sRn = mmul(mmul(n2, q4, M), U256::load(&sums[16 * b + 4]), M);                   // n^2 q^4 sR'
@@ -285,7 +285,7 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
     o->sR[b] = madd(o->n ? sRn : U256::zero(), o->l ? U256::load(&sums[16 * b + 12]) : U256::zero(), M);
     o->sX[b].store(sX + 4 * b); o->sR[b].store(sR + 4 * b);
     o->sX[b].store(&tails[8 * b]); o->sR[b].store(&tails[8 * b + 4]);
-  }
+  } });
   // the scalar on g is the last term of each instance: instance 2b (X) and 2b+1 (R)
   NLB_HIP(o, hipMemcpy2DAsync(o->sc + (T - 1) * 8, T * 32, tails.data(), 32, 32, 2 * B, hipMemcpyHostToDevice, st));
   std::vector<uint64_t> outs(2 * B * 8);
@@ -311,7 +311,8 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   for (size_t b = 0; b < B; b++)
     if (cmp(U256::load(es + 4 * b), M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
   std::atomic<int> too_big{0};
-  parallel_for(B, [&](size_t b) {
+  parallel_ranges(B, [&](size_t lo, size_t hi) {
+   for (size_t b = lo; b < hi; b++) {
     const U256 e = U256::load(es + 4 * b);
     U256 e1 = msub(mmul(e, e, M), U256::one(), M);
     o->s[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
@@ -328,10 +329,9 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
       a0l[b] = extract_scalar(ab.first); b0l[b] = extract_scalar(ab.second); inv[2 * b + 1] = b0l[b];
       jsf_recode(ab.second.m, ab.first.m, K[b].dl); K[b].lbneg = ab.second.neg; K[b].laneg = ab.first.neg;
     }
-  });
-  if (too_big) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
-  batch_minv(inv.data(), 2 * B, M);              // every b0^-1 of the round with ONE field inversion
-  for (size_t b = 0; b < B; b++) {
+   }
+   batch_minv(inv.data() + 2 * lo, 2 * (hi - lo), M);              // every b0^-1 of the range with ONE field inversion
+   for (size_t b = lo; b < hi; b++) {
     const U256 e = U256::load(es + 4 * b);
     if (o->n) {
       put8(K[b].nu, inv[2 * b]); put8(K[b].nv, mmul(mmul(e, o->q[b], M), inv[2 * b], M));
@@ -342,7 +342,9 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
       put8(K[b].cu, b0l[b]); put8(K[b].cv, a0l[b]); put8(K[b].lu, inv[2 * b + 1]); put8(K[b].lv, mmul(e, inv[2 * b + 1], M));
       o->ln[b] = mmul(o->ln[b], b0l[b], M);
     }
-  }
+   }
+  });
+  if (too_big) return fail(ctx, BPPP_ERR_ARG, "nlb: reduced scalar exceeds 129 bits");
   NLB_HIP(o, hipMemcpyAsync(o->dK, K.data(), B * sizeof(CollapseK), hipMemcpyHostToDevice, st));
   NLB_HIP(o, hipMemsetAsync(o->P[d], 0, B * o->cap * 64, st));
   NLB_HIP(o, hipMemsetAsync(o->x[d], 0, B * o->xstride * 32, st));
