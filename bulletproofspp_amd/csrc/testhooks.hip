@@ -1,5 +1,6 @@
 // testhooks.hip — device field / group arithmetic exposed to the parity tests (include/bppp_test.h).
 #include "../../include/bppp_test.h"
+#include <vector>
 #include "ctx.hpp"
 #include "ec.cuh"
 
@@ -92,5 +93,48 @@ extern "C" int bppp_test_point_op(bppp_ctx *ctx, int op, const uint64_t *p, cons
       rc = bppp::fail(ctx, BPPP_ERR_HIP, "test_point_op: kernel or copy failed");
   }
   hipFree(da); hipFree(db); hipFree(dout);
+  return rc;
+}
+
+// ---- measured VALU ceiling for the field layer: independent fq_mul chains, 8 waves per SIMD, nothing but multiplies.
+// bench.py reports the accumulate kernel's modular-multiplication rate as a fraction of this.
+namespace bppp {
+__global__ void __launch_bounds__(256) k_mulmod_rate(const uint32_t *__restrict__ seed, int iters, uint32_t *__restrict__ sink) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  fq a[4], b;
+  for (int k = 0; k < 4; k++) a[k] = fq_from_fe(fe_load(seed + (size_t)((t + 17 * k) & 1023) * 8));
+  b = fq_from_fe(fe_load(seed + (size_t)((t * 7 + 3) & 1023) * 8));
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = fq_mul(a[k], b);
+  }
+  fq r = fq_add(fq_add(a[0], a[1]), fq_add(a[2], a[3]));
+  uint32_t x = 0;
+  for (int i = 0; i < 10; i++) x ^= r.n[i];
+  if (x == 0x12345u) sink[t & 63] = x;       // keeps the chains live; practically never taken
+}
+}  // namespace bppp
+extern "C" int bppp_test_mulmod_rate(bppp_ctx *ctx, int iters, double *mulmods_per_sec) {
+  if (!ctx || !mulmods_per_sec || iters < 1) return BPPP_ERR_ARG;
+  hipSetDevice(ctx->device);
+  uint32_t *seed = nullptr, *sink = nullptr;
+  if (hipMalloc(&seed, 1024 * 32) != hipSuccess || hipMalloc(&sink, 256) != hipSuccess) { hipFree(seed); return bppp::fail(ctx, BPPP_ERR_HIP, "mulmod_rate: hipMalloc"); }
+  std::vector<uint32_t> h(1024 * 8);
+  uint64_t z = 0x9E3779B97F4A7C15ull;
+  for (auto &w : h) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; w = (uint32_t)(z >> 16); }
+  for (int i = 0; i < 1024; i++) h[8 * i + 7] &= 0x7FFFFFFFu;      // < p
+  hipMemcpy(seed, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipMemset(sink, 0, 256);
+  const int blocks = 256 * 4 * 8 / 4 * 2;     // 8 waves per SIMD on 256 CUs, two rounds of them
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  bppp::k_mulmod_rate<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(seed, 8, sink);          // warm-up
+  hipEventRecord(e0, ctx->stream);
+  bppp::k_mulmod_rate<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(seed, iters, sink);
+  hipEventRecord(e1, ctx->stream);
+  int rc = BPPP_OK;
+  if (hipEventSynchronize(e1) != hipSuccess) rc = bppp::fail(ctx, BPPP_ERR_HIP, "mulmod_rate: kernel failed");
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  *mulmods_per_sec = ms > 0 ? (double)blocks * 256.0 * 4.0 * iters / (ms * 1e-3) : 0.0;
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(seed); hipFree(sink);
   return rc;
 }

@@ -21,6 +21,9 @@ int bppp_test_fe_op(bppp_ctx *ctx, int op, int modulus, const uint64_t *a, const
 /* out[i] = p[i] + q[i] (complete group law; op 0: mixed XYZZ+affine, op 1: XYZZ+XYZZ, op 2: 2*p[i]);
  * host arrays of n x 8 uint64 affine points */
 int bppp_test_point_op(bppp_ctx *ctx, int op, const uint64_t *p, const uint64_t *q, size_t n, uint64_t *out);
+/* Measured ceiling of the field layer: modular multiplications per second of a kernel that does nothing but independent
+ * Fq multiplications (10x26-bit limbs) at 8 wavefronts per SIMD.  bench.py quotes the MSM's multiplication rate against it. */
+int bppp_test_mulmod_rate(bppp_ctx *ctx, int iters, double *mulmods_per_sec);
 #ifdef __cplusplus
 }
 #endif
