@@ -1,0 +1,655 @@
+"""Typed reciprocal range proofs (RangeProof.TypedReciprocal + RangeProof.Internal + the generic RangeProof wrapper of the
+reference) on top of the GPU norm-linear argument — SURVEY.md section 8(f) rank 1.
+
+This is HOST protocol logic (phase 1-3 commitments' scalars, blinding algebra, public constants); everything that touches
+curve points goes through a `Backend`: `commit` (the reference's `commitRPW` = one Pedersen MSM, src/RangeProof/Internal.hs:45-50)
+and the norm-linear argument's prover / verifier (src/Bulletproof.hs:346-378).  `GpuBackend` is the product backend (C ABI:
+bppp_msm, bppp_nl_*); there is no CPU backend in the package — the tests inject one built from `oracle/` to check that the GPU
+path yields the same transcript bit for bit.
+
+Names follow the reference so the call sites read like src/RangeProof/TypedReciprocal.hs.  Only the NL argument flavour is
+wired (the `examples/{32by64,64by64,96by64,128by64}` schemas use it).  The reference cannot be run here (no GHC), so proofs are
+pinned by algebraic closure (prove -> verify accepts; any tampering rejects) and by the shapes of SURVEY.md Appendix B, not by
+reference-generated vectors: parity of this layer with the Haskell implementation is UNPINNED.
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141      # group order: the scalar field `s`
+Point = Optional[Tuple[int, int]]
+OracleN = Callable[[List[Point], int], List[int]]     # whole transcript (newest first), count -> that many challenges
+RandFn = Callable[[int], int]                         # counter -> scalar (ZKPT's `h n`, src/ZKP.hs:88-92)
+
+
+# ----------------------------------------------------------------------------- small helpers (src/Utils.hs)
+def inv(a: int) -> int:
+    a %= N
+    return pow(a, N - 2, N) if a else 0
+
+
+def batch_inverse(xs: Sequence[int]) -> List[int]:
+    """batchInverse (src/Data/Field/BatchInverse.hs:18-39): Montgomery's trick, 0 -> 0."""
+    pre, acc = [], 1
+    for x in xs:
+        pre.append(acc)
+        if x % N:
+            acc = acc * x % N
+    y = inv(acc)
+    out = [0] * len(xs)
+    for i in range(len(xs) - 1, -1, -1):
+        if xs[i] % N:
+            out[i] = y * pre[i] % N
+            y = y * xs[i] % N
+    return out
+
+
+def powers1(a: int, n: int) -> List[int]:
+    """first n of powers' a = [a, a^2, ...] (Utils.hs:107-108)"""
+    out, c = [], 1
+    for _ in range(n):
+        c = c * a % N
+        out.append(c)
+    return out
+
+
+def integer_log(b: int, n: int) -> int:
+    """integerLog (Utils.hs:78-79)"""
+    r = 0
+    while n >= b:
+        n //= b
+        r += 1
+    return r
+
+
+def pad_right(n: int, z, xs: Sequence) -> list:
+    return (list(xs) + [z] * n)[:n]
+
+
+def insert_at(n: int, x, xs: Sequence) -> list:
+    xs = list(xs)
+    return xs[:n] + [x] + xs[n:]
+
+
+def remove_at(n: int, xs: Sequence) -> list:
+    xs = list(xs)
+    return xs[:n] + xs[n + 1:]
+
+
+# ----------------------------------------------------------------------------- RPWitness (RangeProof/Internal.hs:20-43)
+@dataclass
+class RPW:
+    sc: int = 0
+    lin: List[int] = field(default_factory=list)
+    nrm: List[int] = field(default_factory=list)
+
+    def __add__(self, o: "RPW") -> "RPW":        # (^+^) = zipWithDef'' (+) 0 0
+        z = lambda a, b: [((a[i] if i < len(a) else 0) + (b[i] if i < len(b) else 0)) % N for i in range(max(len(a), len(b)))]
+        return RPW((self.sc + o.sc) % N, z(self.lin, o.lin), z(self.nrm, o.nrm))
+
+    def scale(self, s: int) -> "RPW":            # (*^)
+        return RPW(self.sc * s % N, [x * s % N for x in self.lin], [x * s % N for x in self.nrm])
+
+
+# ----------------------------------------------------------------------------- ranges and digits (TypedReciprocal.hs:77-131)
+@dataclass
+class RangeData:
+    base: int
+    lo: int
+    hi: int
+    is_shared: bool
+    is_output: bool
+    is_assumed: bool
+    has_bit: bool
+    base_coeffs: List[int]
+
+
+def make_range_data(base: int, lo: int, hi: int, is_shared: bool = False, is_output: bool = False, is_assumed: bool = False) -> Optional[RangeData]:
+    """makeRangeData (TypedReciprocal.hs:103-120) for the field of characteristic N; None if the range is invalid."""
+    if not (hi > lo and base > 1 and hi - lo < N):
+        return None
+    b, w = base, hi - lo
+    n1 = integer_log(b, w - 1)
+    has_bit = ((w - 1) % (b - 1)) != 0
+    tail = [b ** (n1 - i) for i in range(1, n1 + 1)]
+    if not has_bit:
+        bs = [(w - b ** n1) // (b - 1)] + tail
+    elif w < 2 * b ** n1:
+        bs = [w - b ** n1] + tail
+    else:
+        bn1 = 1 + w // (2 * (b - 1)) - (b ** n1 - 1) // (b - 1)
+        bs = [w - bn1 * (b - 1) - b ** n1, bn1] + tail
+    return RangeData(b, lo, hi, is_shared, is_output, is_assumed, has_bit, [] if is_assumed else bs)
+
+
+def digits(rd: RangeData, n: int) -> List[int]:
+    """digits (TypedReciprocal.hs:125-127): greedy mixed-radix digits; the first is binary when has_bit."""
+    out = []
+    for i, coeff in enumerate(rd.base_coeffs):
+        radix = 2 if (rd.has_bit and i == 0) else rd.base
+        d = min(radix - 1, n // coeff)
+        n -= d * coeff
+        out.append(d)
+    return out
+
+
+def counts(xs: Sequence[int], ys: Sequence[int]) -> List[int]:
+    m: Dict[int, int] = {}
+    for y in ys:
+        m[y] = m.get(y, 0) + 1
+    return [m.get(x, 0) for x in xs]
+
+
+# Phase1 (TypedReciprocal.hs:56-60): ("inline", idx, base, b, d, m, s) | ("shared", idx, base, b, d) | ("typing", idx, io, ia, v, t);
+# private fields (d, m, v, t) are None on the verifier's side
+def make_phase1s(ind: int, rd: RangeData, n: Optional[int]):
+    """makePhase1s / makePhase1sVer (TypedReciprocal.hs:133-169): (phase-1 records, shared multiplicities or None)."""
+    if rd.is_assumed:
+        return [], None
+    ver = n is None
+    n_adj = 0 if ver else n - rd.lo
+    if not (0 <= n_adj < rd.hi - rd.lo):
+        raise ValueError("value outside its range")
+    b = rd.base
+    ds = digits(rd, n_adj)
+    ms = ([ds[0]] + counts(range(1, b), ds[1:])) if rd.has_bit else counts(range(1, b), ds)
+    ns = ([1] if rd.has_bit else []) + list(range(1, b))
+    radix = lambda i: 2 if (rd.has_bit and i == 0) else b
+    priv = (lambda v: None) if ver else (lambda v: v % N)
+    if rd.is_shared:
+        ph1s = [("shared", ind, radix(i), rd.base_coeffs[i] % N, priv(ds[i])) for i in range(min(len(rd.base_coeffs), len(ds)))]
+        return ph1s, (None if ver else [m % N for m in ms])
+    ln = max(len(rd.base_coeffs), len(ds), len(ms), len(ns))
+    bs_, ds_, ms_, ns_ = (pad_right(ln, 0, w) for w in (rd.base_coeffs, ds, ms, ns))
+    return [("inline", ind, radix(i), bs_[i] % N, priv(ds_[i]), priv(ms_[i]), ns_[i] % N) for i in range(ln)], None
+
+
+def get_ds_ms(ph1s) -> Tuple[List[int], List[int]]:
+    """getDsMs (TypedReciprocal.hs:74-80)"""
+    ds, ms = [], []
+    for p in ph1s:
+        if p[0] == "inline":
+            ds.append(p[4]); ms.append(p[5])
+        elif p[0] == "shared":
+            ds.append(p[4]); ms.append(0)
+        else:
+            ds.append(p[5]); ms.append(0)
+    return ds, ms
+
+
+# Phase2 (TypedReciprocal.hs:180-181)
+@dataclass
+class Ph2:
+    is_t: bool
+    d: Optional[int]
+    m: Optional[int]
+    u: int
+    v: int
+    r: Optional[int]
+    c: int
+
+
+def make_phase2s(e: int, e_inv: int, x: int, base_map: Dict[int, int], ph1s, private: bool) -> List[Ph2]:
+    """makePhase2s (TypedReciprocal.hs:185-205).  private=False is the verifier's `b ~ ()` instantiation."""
+    dens, ss, ps, vs, rec = [], [], [], [], []
+    for p in ph1s:
+        xi = pow(x, 2 * (p[1] + 1), N)
+        if p[0] == "typing":
+            _, _, io, ia, v, t = p
+            x2 = (-x) % N if io else x % N
+            dens.append((e + t) % N if private else 0); ss.append(0); ps.append(v if private else 0); vs.append(x2)
+            rec.append((True, t, 0 if private else None, 0 if ia else xi, x2))
+        elif p[0] == "inline":
+            _, _, base, b, d, m, s = p
+            x2 = base_map[base]
+            dens.append((e + d) % N if private else 0); ss.append(0 if s == 0 else (e + s) % N); ps.append(1); vs.append(x2)
+            rec.append((False, d, m, xi * b % N, x2))
+        else:
+            _, _, base, b, d = p
+            x2 = base_map[base]
+            dens.append((e + d) % N if private else 0); ss.append(0); ps.append(1); vs.append(x2)
+            rec.append((False, d, 0 if private else None, xi * b % N, x2))
+    rs = [a * b % N for a, b in zip(ps, batch_inverse(dens))] if private else [None] * len(ph1s)
+    cs = [v * (0 if s == 0 else (e_inv - s) % N) % N for v, s in zip(vs, batch_inverse(ss))]
+    return [Ph2(is_t, d, m, u, v, r, c) for (is_t, d, m, u, v), r, c in zip(rec, rs, cs)]
+
+
+def make_shared_coeffs(e: int, e_inv: int, m_bases: Sequence[int], base_map: Dict[int, int]) -> List[int]:
+    """makeSharedCoeffs (TypedReciprocal.hs:213-216)"""
+    xs, ss = [], []
+    for b in m_bases:
+        for s in range(1, b):
+            xs.append(base_map[b]); ss.append((e + s) % N)
+    return [x * ((e_inv - si) % N) % N for x, si in zip(xs, batch_inverse(ss))]
+
+
+def make_error_terms(e: int, xp: int, shared_cs: Sequence[int], bls_ms: Sequence[int], ph3s) -> List[int]:
+    """makeErrorTerms (TypedReciprocal.hs:226-243); ph3s = [(Ph2, q2, bl)]"""
+    tot = [0, 0, 0, 2 * sum(a * b for a, b in zip(shared_cs, bls_ms)) % N, 0, 0]
+    for p, q2, bl in ph3s:
+        d, m, u, v, r, c = p.d, p.m, p.u, p.v, p.r, p.c
+        rC = xp * (u + q2) % N if p.is_t else u
+        dC = (v + q2 * e) % N
+        errs = [q2 * bl * bl,
+                2 * q2 * m * bl,
+                q2 * m * m + 2 * bl * (q2 * d + dC),
+                2 * (bl * (q2 * r + rC) + m * (q2 * d + dC)),
+                (q2 * d * d + 2 * d * dC) + 2 * (bl * c + m * (q2 * r + rC)),
+                (q2 * r * r + 2 * r * rC) + 2 * c * d]
+        tot = [(a + b) % N for a, b in zip(tot, errs)]
+    return tot
+
+
+def input_coeffs(has_types: bool, assumed: Sequence[bool], x: int, q0: int) -> List[int]:
+    """inputCoeffs (TypedReciprocal.hs:325-328)"""
+    xp = [0 if a else p for a, p in zip(assumed, powers1(x * x % N, len(assumed)))]
+    return [(a + b) % N for a, b in zip(powers1(q0, len(assumed)), xp)] if has_types else xp
+
+
+def make_bp_coeffs(has_types: bool, xp: int, r0: int, r1: int, t: int, cs: Sequence[int]) -> List[int]:
+    """makeBpCoeffs (TypedReciprocal.hs:391-396)"""
+    rs = r0 * r1 % N
+    tp = lambda k: pow(t, k, N)
+    return [(-xp) % N if has_types else 0, rs * t % N, rs * tp(2) % N, rs * tp(3) % N, r0 * tp(4) % N, rs * tp(6) % N] + \
+           [2 * tp(3) * c % N for c in cs]
+
+
+def make_public_consts(e: int, e_inv: int, x: int, xp: int, q0: int, q0_inv: int, t: int, has_types: bool, rds: Sequence[RangeData],
+                       pub_vt: Sequence[Tuple[bool, int, int]], ph2s: Sequence[Ph2]) -> RPW:
+    """makePublicConsts (TypedReciprocal.hs:246-274); pub_vt entries are (isOutput, type, amount) as destructured at :258."""
+    tp = lambda k: pow(t, k, N)
+    mins = [0 if rd.is_assumed else rd.lo % N for rd in rds]
+    pub_rs = batch_inverse([(e + ty) % N for _, ty, _ in pub_vt])
+    pub_sum = sum(((-r * v) if is_out else (r * v)) for (is_out, _, v), r in zip(pub_vt, pub_rs)) % N
+    z = -2 * tp(5) * sum(a * b for a, b in zip(mins, powers1(x * x % N, len(mins))))
+    if has_types:
+        z -= 2 * tp(5) * x * pub_sum
+    ts0, ts1 = [], []
+    for p, q2, qi2 in zip(ph2s, powers1(q0, len(ph2s)), powers1(q0_inv, len(ph2s))):
+        if p.is_t:
+            rC, p2C = xp * (qi2 * p.u + 1) % N, 0
+        else:
+            rC, p2C = qi2 * p.u % N, (2 * q2 + 2 * e_inv * p.v) % N
+        pv = (tp(2) * (e + qi2 * p.v) + tp(3) * rC + tp(4) * (qi2 * p.c)) % N
+        ts0.append((q2 * pv * pv + tp(5) * p2C) % N)
+        ts1.append(pv)
+    return RPW((z + sum(ts0)) % N, [], ts1)
+
+
+# ----------------------------------------------------------------------------- blinding (RangeProof/Internal.hs:118-196)
+def blind_witness(n: int, k: int, ls: Sequence[int], ns: Sequence[int], rnd: Callable[[], int]) -> RPW:
+    """blindWitness (:130-139)"""
+    n_bls = 2 * n - 1 if k == 1 else 2 * n - k + 1
+    bls = pad_right(2 * n + 1, 0, insert_at(2 * n - k, 0, [rnd() for _ in range(n_bls)]))
+    return RPW(bls[0], bls[1:] + list(ls), list(ns))
+
+
+def blind_err_witness(n: int, es: Sequence[int], ls: Sequence[int], ns: Sequence[int], rnd: Callable[[], int]) -> RPW:
+    """blindErrWitness (:142-149)"""
+    bls = pad_right(2 * n + 1, 0, insert_at(n, 0, [rnd() for _ in range(n + 1)]) + list(es))
+    return RPW(bls[0], bls[1:] + list(ls), list(ns))
+
+
+def _scale_errs(n: int, s: int, xs: Sequence[int]) -> List[int]:
+    """scaleErrs (:118-121)"""
+    xs = list(xs)
+    ys, zs = xs[:n + 1], xs[n + 1:]
+    a, b = zs[:n - 2], zs[n - 2:]
+    return ys + [s * v % N for v in a] + b
+
+
+def _sum_diagonals(table: Sequence[Sequence[int]]) -> List[int]:
+    """sumDiagonals (:104-111)"""
+    m: Dict[int, int] = {}
+    for a, row in enumerate(table):
+        for b, v in enumerate(row):
+            m[a + b] = (m.get(a + b, 0) + v) % N
+    return [m[k] for k in sorted(m)]
+
+
+def blind_blinding_term(bl_bls: RPW, tC: int, r0: int, r0_inv: int, r1: int, r1_inv: int, errs: Sequence[int], wits: Sequence[RPW], input_bl: int) -> RPW:
+    """blindBlindingTerm (:154-196)"""
+    assert bl_bls.sc == 0
+    blT, bls_lin, bls_nrm = bl_bls.lin[0], bl_bls.lin[1:], bl_bls.nrm
+    rs_inv = r0_inv * r1_inv % N
+    n = len(wits)
+    wits1, wit_err = wits[:n - 1], wits[n - 1]
+    wit_err_row = [wit_err.sc] + pad_right(2 * n, 0, wit_err.lin[:n + 1])
+    wit_rows = [[w.sc] + w.lin[:2 * n] for w in wits1]
+    wit_rows1 = [[r[0], r[1]] + [(-v) % N for v in r[2:]] for r in wit_rows + [wit_err_row]]
+    errs1 = [(-v) % N for v in [(errs[0] - tC * blT) % N] + [rs_inv * v % N for v in errs[1:]]]
+    add_consts = lambda a, b, r: [(a * r[0] + b * r[1]) % N] + r[2:]
+    table = [insert_at(2 * n - 1, 0, row) for row in
+             [errs1] + [_scale_errs(n, r1_inv, add_consts(rs_inv, rs_inv * tC % N, r)) for r in wit_rows1]]
+    bl_errs = _scale_errs(n, r1, remove_at(2 * n - 1, _sum_diagonals(table))[:2 * n])
+    bl_errs[-1] = (bl_errs[-1] - 2 * input_bl) % N
+    return RPW((-bl_errs[0]) % N, [blT] + bl_errs[1:] + list(bls_lin), list(bls_nrm))
+
+
+# ----------------------------------------------------------------------------- the curve side: backends
+class Backend:
+    """What the protocol needs from the curve: the Pedersen MSM and the norm-linear argument."""
+
+    def commit(self, scalars: Sequence[int], points: Sequence[Point]) -> Point:
+        raise NotImplementedError
+
+    def prove_bp(self, n_rounds: int, sc: int, g: Point, q: int, cs, nrm, gs, lin, hs, oracle1: Callable[[List[Point]], int]):
+        """proveBPM on PSV(sc, g, NormLinear 1 q cs nrm gs lin hs); returns (responses last round first, norm witness, linear witness)"""
+        raise NotImplementedError
+
+    def verify_bp(self, q: int, sp: int, g: Point, pub_nrm, gs, cs, pub_lin, hs, es, responses, wit_nrm, wit_lin, init_terms) -> bool:
+        raise NotImplementedError
+
+
+class GpuBackend(Backend):
+    """The product backend: every group operation runs on the MI355X through the C ABI."""
+
+    def __init__(self, gpu):
+        self.gpu = gpu
+
+    def commit(self, scalars, points):
+        from .capi import points_to_array, scalars_to_array
+        if not len(scalars):
+            return None
+        return self.gpu.msm(scalars_to_array([s % N for s in scalars]), points_to_array(list(points)))
+
+    def prove_bp(self, n_rounds, sc, g, q, cs, nrm, gs, lin, hs, oracle1):
+        from .bulletproof import NormLinearBP, proveBPM
+        com = NormLinearBP(self.gpu, sc, g, q, cs, nrm, gs, lin, hs)
+        try:
+            resps, _ = proveBPM(n_rounds, com, oracle1)
+            nw, lw = com.getWitness()
+        finally:
+            com.close()
+        return resps, nw, lw
+
+    def verify_bp(self, q, sp, g, pub_nrm, gs, cs, pub_lin, hs, es, responses, wit_nrm, wit_lin, init_terms):
+        from .bulletproof import verifyBPM
+        pad = lambda xs, n: list(xs) + [0] * (n - len(xs))
+        return verifyBPM(self.gpu, q, sp, g, pad(pub_nrm, len(gs)), gs, pad(cs, len(hs)), pad(pub_lin, len(hs)), hs, es, responses, wit_nrm, wit_lin,
+                         init_terms)
+
+
+# ----------------------------------------------------------------------------- transcript (src/ZKP.hs:73-101)
+class Transcript:
+    """ZKPT's state: all commitments so far (newest first) and the random counter."""
+
+    def __init__(self, oracle: OracleN, rand: Optional[RandFn] = None):
+        self.fn, self.rand_fn, self.cs, self.n = oracle, rand, [], 0
+
+    def oracle(self, xs: Sequence[Point], count: int = 1) -> List[int]:
+        self.cs = list(xs) + self.cs
+        return [v % N for v in self.fn(self.cs, count)]
+
+    def random(self) -> int:
+        if self.rand_fn is None:
+            raise RuntimeError("No Random in Verifier")        # app/Main.hs:202
+        v = self.rand_fn(self.n) % N
+        self.n += 1
+        return v
+
+
+def sha256_oracle(tag: bytes = b"bppp") -> OracleN:
+    """Stand-in for shaOracle (app/Main.hs:75-80): challenge n = SHA-256(tag, n, #commitments, decimal coordinates of the whole
+    transcript).  The exact `Show` text the reference hashes cannot be confirmed offline — documented choice."""
+    def fn(cs: List[Point], count: int) -> List[int]:
+        body = b"".join((b"inf" if p is None else str(p[0]).encode() + str(p[1]).encode()) for p in cs)
+        return [int.from_bytes(hashlib.sha256(tag + str(n).encode() + str(len(cs)).encode() + body).digest(), "big") % N for n in range(1, count + 1)]
+    return fn
+
+
+def hash_to_scalar(prefix: bytes) -> RandFn:
+    """hashToScalar rn . show (app/Main.hs:83-84, :189) — the prover's deterministic randomness."""
+    return lambda n: int.from_bytes(hashlib.sha256(prefix + str(n).encode()).digest(), "big") % N
+
+
+# ----------------------------------------------------------------------------- setup (TypedReciprocal.hs:332-359)
+@dataclass
+class SetupTRRP:
+    has_types: bool
+    m_bases: List[int]
+    sorted_bases: List[int]
+    nrm_len: int
+    lin_len: int
+    pub_vt: List[Tuple[bool, int, int]]
+    rds: List[RangeData]
+    g: Point
+    hs: List[Point]
+    gs: List[Point]
+    rounds: int
+    final_lens: Tuple[int, int]
+    backend: Backend
+
+    def base_map(self, x: int) -> Dict[int, int]:
+        """makeBaseMap: sortedBases zipped with x^3, x^5, ... (powers'' (x^3) (x^2), :349)"""
+        out, c = {}, pow(x, 3, N)
+        for b in self.sorted_bases:
+            out[b] = c
+            c = c * x % N * x % N
+        return out
+
+    def q_powers(self, q: int, n: int) -> List[int]:
+        """qPowers' of the NL Norm: powers' (q^2) (Bulletproof/NormArgument.hs:148)"""
+        return powers1(q * q % N, n)
+
+    def com(self, w: RPW) -> Point:
+        """commitRPW sc g lin hs nrm gs (RangeProof/Internal.hs:45-50)"""
+        assert len(w.lin) <= len(self.hs) and len(w.nrm) <= len(self.gs)
+        return self.backend.commit([w.sc] + list(w.lin) + list(w.nrm), [self.g] + self.hs[:len(w.lin)] + self.gs[:len(w.nrm)])
+
+
+def round_reduce(n: int) -> int:
+    return n // 2 + n % 2
+
+
+def number_rounds_reduce(n: int) -> Tuple[int, int]:
+    """numberRoundsReduce (src/Bulletproof.hs:300-304)"""
+    r = 0
+    while n >= 5:
+        n = round_reduce(n)
+        r += 1
+    return r, n
+
+
+def optimal_witness_size(n_len: int, l_len: int) -> Tuple[int, Tuple[int, int]]:
+    """optimalWitnessSize of the NL NormLinear (Bulletproof/NormArgument.hs:165-178)"""
+    nR, n1 = number_rounds_reduce(n_len)
+    lR, l1 = number_rounds_reduce(l_len)
+    r = max(nR, lR)
+    for _ in range(r - nR):
+        n1 = round_reduce(n1)
+    for _ in range(r - lR):
+        l1 = round_reduce(l1)
+    if n1 + l1 > 5:
+        return r + 1, (round_reduce(n1), round_reduce(l1))
+    return r, (n1, l1)
+
+
+def setup(backend: Backend, points: Sequence[Point], has_types: bool, pub_vt: Sequence[Tuple[bool, int, int]], rds: Sequence[RangeData]) -> SetupTRRP:
+    """setup (TypedReciprocal.hs:332-359): points = h : g : ps (h is not used by the proof, as in the reference)."""
+    live = [rd for rd in rds if not rd.is_assumed]
+    any_has_bit = any(rd.has_bit for rd in live)
+    any_shared_has_bit = any(rd.has_bit and rd.is_shared for rd in live)
+    pairs = sorted(((rd.is_shared, rd.base) for rd in live), key=lambda p: p[1])
+    m_bases = sorted(set(([2] if any_shared_has_bit else []) + [b for s, b in pairs if s]))
+    sorted_bases = sorted(set(([2] if any_has_bit else []) + [b for _, b in pairs]))
+    nrm_len = sum(len(rd.base_coeffs) + (1 if has_types else 0) for rd in rds)
+    lin_len = 6 + sum(b - 1 for b in m_bases)
+    ps = list(points[2:])
+    if len(ps) < lin_len + nrm_len:
+        raise ValueError("not enough basis points")
+    rounds, final = optimal_witness_size(nrm_len, lin_len)
+    return SetupTRRP(has_types, m_bases, sorted_bases, nrm_len, lin_len, list(pub_vt), list(rds), points[1], ps[:lin_len], ps[lin_len:lin_len + nrm_len],
+                     rounds, final, backend)
+
+
+# ----------------------------------------------------------------------------- witness (TypedReciprocal.hs:361-389)
+@dataclass
+class WitnessTRRP:
+    inputs: List[Tuple[int, int, int]]       # (amount, type, blinding) per input — the PedersenScalarPair's scalars
+    ph1s: list
+    base_mss: List[Tuple[int, List[int]]]
+
+
+def witness(st: SetupTRRP, inputs: Sequence[Tuple[int, int, int]]) -> WitnessTRRP:
+    """witnessTRRP (:372-389): inputs are (amount, type, blinding)."""
+    if len(inputs) != len(st.rds):
+        raise ValueError("Different number of values and ranges")
+    if st.has_types:
+        sums: Dict[int, int] = {}
+        for io, ty, v in st.pub_vt:
+            sums[ty % N] = (sums.get(ty % N, 0) + (-v if io else v)) % N
+        for (v, ty, _), rd in zip(inputs, st.rds):
+            sums[ty % N] = (sums.get(ty % N, 0) + (-v if rd.is_output else v)) % N
+        if any(sums.values()):
+            raise ValueError("amounts of some type do not balance")
+    ph1ss, mss = [], []
+    for i, ((v, _, _), rd) in enumerate(zip(inputs, st.rds)):
+        p, m = make_phase1s(i, rd, v)
+        ph1ss.append(p); mss.append(m)
+    types = [("typing", i, rd.is_output, rd.is_assumed, v % N, ty % N) for i, ((v, ty, _), rd) in enumerate(zip(inputs, st.rds))]
+    ph1s = (types if st.has_types else []) + [p for ps_ in ph1ss for p in ps_]
+    acc: Dict[int, List[int]] = {}
+    add = lambda b, ms: acc.__setitem__(b, [(x + y) % N for x, y in zip(acc[b], ms)] if b in acc else list(ms))
+    for rd, ms in zip(st.rds, mss):                      # baseMss (:363-370)
+        if ms is None:
+            continue
+        if rd.has_bit:
+            add(2, [ms[0]]); add(rd.base, ms[1:])
+        else:
+            add(rd.base, ms)
+    return WitnessTRRP([(v % N, ty % N, bl % N) for v, ty, bl in inputs], ph1s, sorted(acc.items()))
+
+
+# ----------------------------------------------------------------------------- proof object and the two protocol halves
+@dataclass
+class RangeProof:
+    """RP coms (PBP responses opening) (src/RangeProof.hs:90): coms = blCom : rCom : dmCom : mCom : nComs."""
+    coms: List[Point]
+    responses: List[Tuple[Point, Point]]      # last round first
+    wit_nrm: List[int]
+    wit_lin: List[int]
+
+
+@dataclass
+class SetupBP:
+    """SBP basis initCom publicCs rounds (src/Bulletproof.hs:327-328), flattened to what verifyBPM consumes."""
+    q: int
+    cs: List[int]
+    pub: RPW
+    init_terms: List[Tuple[int, Point]]
+    rounds: int
+
+
+def _init_terms(st: SetupTRRP, coms: Sequence[Point], x: int, q0: int, t: int) -> List[Tuple[int, Point]]:
+    """openWith of TranscriptTRRP (TypedReciprocal.hs:293-297)"""
+    bl, r, dm, m = coms[:4]
+    tp = lambda k: pow(t, k, N)
+    ss = [2 * tp(5) * c % N for c in input_coeffs(st.has_types, [rd.is_assumed for rd in st.rds], x, q0)]
+    return list(zip(ss, coms[4:])) + [(1, bl), (t % N, m), (tp(2), dm), (tp(3), r)]
+
+
+def prove_rp(st: SetupTRRP, w: WitnessTRRP, tr: Transcript) -> Tuple[List[Point], SetupBP, RPW]:
+    """proveTRRPM (TypedReciprocal.hs:399-446)"""
+    num_terms = 3
+    is_as = [rd.is_assumed for rd in st.rds]
+    m_bases = [b for b, _ in w.base_mss]
+    if m_bases != st.m_bases:
+        raise ValueError("witness does not cover the setup's shared bases")
+    ms_shared = [m for _, ms in w.base_mss for m in ms]
+    ds, ms_inline = get_ds_ms(w.ph1s)
+
+    n_wits = [RPW(v, [ty, bl], []) for v, ty, bl in w.inputs]                    # scalarPairRPW' (Internal.hs:59-60)
+    n_coms = [st.com(nw) for nw in n_wits]
+    dm_wit = blind_witness(num_terms, 2, ms_shared, ds, tr.random); dm_com = st.com(dm_wit)
+    m_wit = blind_witness(num_terms, 1, [], ms_inline, tr.random); m_com = st.com(m_wit)
+
+    e, x, r0 = tr.oracle([dm_com, m_com] + n_coms, 3)
+    e_inv, r0_inv = batch_inverse([e, r0])
+
+    base_map = st.base_map(x)
+    ph2s = make_phase2s(e, e_inv, x, base_map, w.ph1s, private=True)
+    err7 = r0_inv * (-sum(2 * p.r * p.c for p in ph2s)) % N                      # err7Term (:209-211)
+    r_wit = blind_err_witness(num_terms, [err7], [], [p.r for p in ph2s], tr.random); r_com = st.com(r_wit)
+
+    q, xp, r1 = tr.oracle([r_com], 3)
+    q0 = st.q_powers(q, 1)[0]
+    q_inv, q0_inv, r1_inv = batch_inverse([q, q0, r1])
+    shared_cs = make_shared_coeffs(e, e_inv, m_bases, base_map)
+    tC = xp if st.has_types else 0
+
+    bls_lin = [tr.random() for _ in range(st.lin_len - 5)]
+    bls_nrm = [tr.random() for _ in range(st.nrm_len)]
+    bls_ms = bls_lin[1:]
+
+    n_wit_sum = RPW()
+    for c, nw in zip(input_coeffs(st.has_types, is_as, x, q0), n_wits):
+        n_wit_sum = n_wit_sum + nw.scale(c)
+    input_bl = n_wit_sum.lin[1]
+    ph3s = list(zip(ph2s, st.q_powers(q, len(ph2s)), bls_nrm))                  # the q^-2i of Ph3 are not used by makeErrorTerms
+    errs = make_error_terms(e, xp, shared_cs, bls_ms, ph3s)
+    bl_wit = blind_blinding_term(RPW(0, bls_lin, bls_nrm), tC, r0, r0_inv, r1, r1_inv, errs, [m_wit, dm_wit, r_wit], input_bl)
+    bl_com = st.com(bl_wit)
+    t = tr.oracle([bl_com], 1)[0]
+
+    pub = make_public_consts(e, e_inv, x, xp, q0, q0_inv, t, st.has_types, st.rds, st.pub_vt, ph2s)
+    tp = lambda k: pow(t, k, N)
+    wit = pub + bl_wit + m_wit.scale(t) + dm_wit.scale(tp(2)) + r_wit.scale(tp(3)) + n_wit_sum.scale(2 * tp(5) % N)
+    coms = [bl_com, r_com, dm_com, m_com] + n_coms
+    cs = make_bp_coeffs(st.has_types, xp, r0, r1, t, shared_cs)
+    return coms, SetupBP(q, cs, pub, _init_terms(st, coms, x, q0, t), st.rounds), wit
+
+
+def verify_rp(st: SetupTRRP, coms: Sequence[Point], tr: Transcript) -> SetupBP:
+    """verifyTRRPM (TypedReciprocal.hs:449-467)"""
+    if len(coms) != 4 + len(st.rds):
+        raise ValueError("wrong number of range-proof commitments")
+    ph1ss = [make_phase1s(i, rd, None)[0] for i, rd in enumerate(st.rds)]
+    types = [("typing", i, rd.is_output, rd.is_assumed, None, None) for i, rd in enumerate(st.rds)]
+    ph1s = (types if st.has_types else []) + [p for ps_ in ph1ss for p in ps_]
+    bl_com, r_com, dm_com, m_com = coms[:4]
+    e, x, r0 = tr.oracle([dm_com, m_com] + list(coms[4:]), 3)
+    q, xp, r1 = tr.oracle([r_com], 3)
+    q0 = st.q_powers(q, 1)[0]
+    t = tr.oracle([bl_com], 1)[0]
+    e_inv, _, q0_inv = batch_inverse([e, q, q0])
+    base_map = st.base_map(x)
+    ph2s = make_phase2s(e, e_inv, x, base_map, ph1s, private=False)
+    pub = make_public_consts(e, e_inv, x, xp, q0, q0_inv, t, st.has_types, st.rds, st.pub_vt, ph2s)
+    cs = make_bp_coeffs(st.has_types, xp, r0, r1, t, make_shared_coeffs(e, e_inv, st.m_bases, base_map))
+    return SetupBP(q, cs, pub, _init_terms(st, coms, x, q0, t), st.rounds)
+
+
+# ----------------------------------------------------------------------------- ZKP instance of RangeProof (src/RangeProof.hs:93-105)
+def prove(st: SetupTRRP, w: WitnessTRRP, oracle: OracleN, rand: RandFn) -> RangeProof:
+    """proveM: proveRP, then the norm-linear argument on the combined witness (proveBPM, src/Bulletproof.hs:357-359)."""
+    tr = Transcript(oracle, rand)
+    coms, sbp, wit = prove_rp(st, w, tr)
+    resps, nw, lw = st.backend.prove_bp(sbp.rounds, wit.sc, st.g, sbp.q, sbp.cs, wit.nrm, st.gs, wit.lin, st.hs, lambda xs: tr.oracle(xs, 1)[0])
+    return RangeProof(coms, resps, nw, lw)
+
+
+def verify_inputs(st: SetupTRRP, proof: RangeProof, oracle: OracleN) -> Optional[dict]:
+    """verifyRP plus the challenge derivation of verifyBPM (src/Bulletproof.hs:374): everything the (batch) verifier's MSM needs.
+    None if the proof is malformed (wrong lengths)."""
+    if len(proof.responses) != st.rounds or (len(proof.wit_nrm), len(proof.wit_lin)) != st.final_lens or len(proof.coms) != 4 + len(st.rds):
+        return None
+    tr = Transcript(oracle)
+    sbp = verify_rp(st, proof.coms, tr)
+    es: List[int] = []
+    for a, b in reversed(proof.responses):            # foldrM: first round first, consed => last round first
+        es.insert(0, tr.oracle([a, b], 1)[0])
+    pad = lambda xs, n: list(xs) + [0] * (n - len(xs))
+    return {"q": sbp.q, "sp": sbp.pub.sc, "pub_norm": pad(sbp.pub.nrm, st.nrm_len), "pub_lin_c": pad(sbp.cs, st.lin_len), "pub_lin_x": pad(sbp.pub.lin, st.lin_len),
+            "es": es, "responses": list(proof.responses), "wit_norm": list(proof.wit_nrm), "wit_lin": list(proof.wit_lin), "init_terms": sbp.init_terms}
+
+
+def verify(st: SetupTRRP, proof: RangeProof, oracle: OracleN) -> bool:
+    """verifyM (src/RangeProof.hs:103-105; src/Bulletproof.hs:343, :370-378)"""
+    v = verify_inputs(st, proof, oracle)
+    if v is None:
+        return False
+    return st.backend.verify_bp(v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"], v["responses"], v["wit_norm"],
+                                v["wit_lin"], v["init_terms"])

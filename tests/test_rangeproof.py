@@ -1,0 +1,144 @@
+"""Typed reciprocal range proofs (bulletproofspp_amd/rangeproof.py = RangeProof.TypedReciprocal of the reference) on the CPU
+backend: algebraic closure (honest proofs verify, tampered ones do not) over the structural cases of the reference's examples —
+shared and inline digits, a binary leading digit, non-zero minimum, typed/conserved amounts with public inputs, assumed ranges —
+and the shapes of SURVEY.md Appendix B.  The reference cannot be run here: parity with the Haskell proofs is unpinned."""
+import copy
+import random
+
+import pytest
+
+import pyoracle as O
+from bulletproofspp_amd import rangeproof as RP
+from rp_backends import OracleBackend
+
+
+def _points(n):
+    return O.hash_points(b"test points", n)
+
+
+def _mk(oracle_lib, rds, typed=False, pub=()):
+    be = OracleBackend(oracle_lib)
+    need = 2 + 6 + 600
+    st = RP.setup(be, _points(need) if not hasattr(_mk, "pts") else _mk.pts, typed, list(pub), rds)
+    return st
+
+
+@pytest.fixture(scope="module")
+def pts():
+    return _points(2 + 6 + 300)
+
+
+def _roundtrip(st, inputs, seed=b"default random seed"):
+    w = RP.witness(st, inputs)
+    proof = RP.prove(st, w, RP.sha256_oracle(), RP.hash_to_scalar(seed))
+    return proof, RP.verify(st, proof, RP.sha256_oracle())
+
+
+CASES = {
+    # name: (ranges [(base, lo, hi, shared, output, assumed)], typed, public [(isOutput, type, amount)], inputs [(amount, type)])
+    "shared_base4_x2": ([(4, 0, 256, True, True, False)] * 2, False, [], [(200, 0), (7, 0)]),
+    "inline_bit_base3": ([(3, 0, 100, False, True, False)], False, [], [(77, 0)]),
+    "inline_min_offset": ([(5, 10, 635, False, True, False)], False, [], [(300, 0)]),
+    "shared_two_bases": ([(4, 0, 256, True, True, False), (3, -20, 223, True, False, False)], False, [], [(255, 0), (-20, 0)]),
+    "typed_conserved": ([(4, 0, 256, True, True, False), (4, 0, 256, True, False, False), (4, 0, 256, True, False, False)], True,
+                        [(False, 15, 1)], [(124, 15), (1, 15), (122, 15)]),
+    "typed_with_assumed": ([(3, 0, 2**16, True, True, False), (16, -20, 2**12, True, False, False), (5, 1, 625, False, False, True)], True,
+                           [(False, 15, 1)], [(124, 15), (1, 15), (122, 15)]),
+    "mixed_inline_shared": ([(4, 0, 4**5, True, True, False), (6, 0, 6**6, False, True, False)], False, [], [(1000, 0), (46000, 0)]),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_prove_verify_closes(oracle_lib, pts, name):
+    ranges, typed, pub, vals = CASES[name]
+    rds = [RP.make_range_data(*r) for r in ranges]
+    assert all(rd is not None for rd in rds)
+    st = RP.setup(OracleBackend(oracle_lib), pts, typed, pub, rds)
+    rnd = random.Random(name)
+    inputs = [(v, ty, rnd.randrange(RP.N)) for v, ty in vals]
+    proof, ok = _roundtrip(st, inputs)
+    assert ok
+    assert len(proof.coms) == 4 + len(rds) and len(proof.responses) == st.rounds
+    assert (len(proof.wit_nrm), len(proof.wit_lin)) == st.final_lens
+    # tampering anywhere must break the final MSM = infinity check
+    for field, idx in (("wit_nrm", 0), ("wit_lin", -1)):
+        bad = copy.deepcopy(proof)
+        getattr(bad, field)[idx] = (getattr(bad, field)[idx] + 1) % RP.N
+        assert not RP.verify(st, bad, RP.sha256_oracle())
+    bad = copy.deepcopy(proof)
+    bad.coms[2], bad.coms[3] = bad.coms[3], bad.coms[2]
+    assert not RP.verify(st, bad, RP.sha256_oracle())
+    bad = copy.deepcopy(proof)
+    bad.responses[0] = (bad.responses[0][1], bad.responses[0][0])
+    assert not RP.verify(st, bad, RP.sha256_oracle())
+    bad = copy.deepcopy(proof)
+    bad.coms[4] = oracle_lib.add(bad.coms[4], pts[1])          # the input commitment of amount + 1
+    assert not RP.verify(st, bad, RP.sha256_oracle())
+
+
+def test_out_of_range_and_unbalanced_witnesses_are_refused(oracle_lib, pts):
+    rd = RP.make_range_data(4, 0, 256, True, True, False)
+    st = RP.setup(OracleBackend(oracle_lib), pts, False, [], [rd])
+    with pytest.raises(ValueError):
+        RP.witness(st, [(256, 0, 1)])
+    with pytest.raises(ValueError):
+        RP.witness(st, [(-1, 0, 1)])
+    st2 = RP.setup(OracleBackend(oracle_lib), pts, True, [(False, 0, 5)], [rd])
+    with pytest.raises(ValueError):
+        RP.witness(st2, [(6, 0, 1)])              # output 6 against public input 5
+    assert RP.witness(st2, [(5, 0, 1)]) is not None
+    assert RP.make_range_data(4, 5, 5) is None and RP.make_range_data(1, 0, 9) is None
+
+
+def test_a_wrong_amount_in_the_commitment_does_not_verify(oracle_lib, pts):
+    """soundness smoke test: prove for amount v, then claim the input commitment of v + 2^k"""
+    rd = RP.make_range_data(4, 0, 256, True, True, False)
+    st = RP.setup(OracleBackend(oracle_lib), pts, False, [], [rd, rd])
+    proof, ok = _roundtrip(st, [(3, 0, 11), (250, 0, 12)])
+    assert ok
+    bad = copy.deepcopy(proof)
+    bad.coms[5] = oracle_lib.add(bad.coms[5], oracle_lib.mul(256, pts[1]))
+    assert not RP.verify(st, bad, RP.sha256_oracle())
+
+
+def test_digit_decomposition_matches_the_range_rules():
+    """makeRangeData / digits (TypedReciprocal.hs:103-127): sum d_i * b_i = v - min, digits within their radix, and the
+    largest representable value is exactly max - min - 1"""
+    rnd = random.Random(5)
+    for base, lo, hi in [(256, 0, 2**64), (64, 0, 2**64), (9, 0, 2**32), (16, 0, 2**64), (3, 0, 2**64), (16, -20, 73786976294838206463), (5, 1, 625),
+                         (2, 3, 2**64), (7, 0, 100), (4, 0, 4**5), (10, 0, 12345)]:
+        rd = RP.make_range_data(base, lo, hi)
+        top = RP.digits(rd, hi - lo - 1)
+        assert sum(d * c for d, c in zip(top, rd.base_coeffs)) == hi - lo - 1
+        for v in [0, 1, hi - lo - 1] + [rnd.randrange(hi - lo) for _ in range(50)]:
+            ds = RP.digits(rd, v)
+            assert sum(d * c for d, c in zip(ds, rd.base_coeffs)) == v
+            for i, d in enumerate(ds):
+                assert 0 <= d < (2 if (rd.has_bit and i == 0) else base)
+
+
+@pytest.mark.parametrize("count,base,typed,nrm,lin,rounds,final,terms", [
+    (64, 256, False, 512, 261, 8, (2, 2), 858),       # examples/64by64   
+    (128, 256, False, 1024, 261, 9, (2, 1), 1436),    # examples/128by64
+    (128, 256, True, 1152, 261, 9, (3, 1), 1564),     # examples/128by64 + "typed"
+    (32, 64, False, 384, 70, 7, (3, 1), 505),         # examples/32by64 (binary leading digit: shared base 2 joins the linear part)
+    (96, 256, False, 768, 261, 8, (3, 2), 1146),      # examples/96by64
+])
+def test_example_shapes(count, base, typed, nrm, lin, rounds, final, terms):
+    rd = RP.make_range_data(base, 0, 2**64, True, True, False)
+    assert rd.has_bit == ((2**64 - 1) % (base - 1) != 0)
+    st = RP.setup(RP.Backend(), [None] * (2 + lin + nrm), typed, [], [rd] * count)
+    assert (st.nrm_len, st.lin_len, st.rounds, st.final_lens) == (nrm, lin, rounds, final)
+    if terms is not None:
+        # verifier MSM: shared basis (nrm + lin + g) + transcript (4 + count) + 2 per round
+        assert nrm + lin + 1 + 4 + count + 2 * rounds == terms
+
+
+def test_rec_test_example_lengths():
+    """examples/rec_test: typed, b = 3 and b = 16 shared (both with a binary leading digit, so base 2 is shared too), b = 5 assumed:
+    nrmLen 62, linLen 24"""
+    rds = [RP.make_range_data(3, 0, 2**64, True, True, False), RP.make_range_data(16, -20, 73786976294838206463, True, False, False),
+           RP.make_range_data(5, 1, 625, False, False, True)]
+    assert [len(r.base_coeffs) for r in rds] == [41, 18, 0] and rds[0].has_bit and rds[1].has_bit
+    st = RP.setup(RP.Backend(), [None] * 100, True, [(False, 15, 1)], rds)
+    assert (st.nrm_len, st.lin_len, st.m_bases) == (62, 24, [2, 3, 16])
