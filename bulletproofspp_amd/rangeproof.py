@@ -7,8 +7,9 @@ and the norm-linear argument's prover / verifier (src/Bulletproof.hs:346-378).  
 bppp_msm, bppp_nl_*); there is no CPU backend in the package — the tests inject one built from `oracle/` to check that the GPU
 path yields the same transcript bit for bit.
 
-Names follow the reference so the call sites read like src/RangeProof/TypedReciprocal.hs.  Only the NL argument flavour is
-wired (the `examples/{32by64,64by64,96by64,128by64}` schemas use it).  The reference cannot be run here (no GHC), so proofs are
+Names follow the reference so the call sites read like src/RangeProof/TypedReciprocal.hs.  Both argument flavours are wired:
+"NL" (Bulletproof.NormArgument; `examples/{32by64,64by64,96by64,128by64}`) and "IP" (Bulletproof.InnerProductArgument, the
+schema default, app/Parse.hs:100; `examples/{32bit,64bit,rec_test}`).  The reference cannot be run here (no GHC), so proofs are
 pinned by algebraic closure (prove -> verify accepts; any tampering rejects) and by the shapes of SURVEY.md Appendix B, not by
 reference-generated vectors: parity of this layer with the Haskell implementation is UNPINNED.
 """
@@ -335,11 +336,12 @@ class Backend:
     def commit(self, scalars: Sequence[int], points: Sequence[Point]) -> Point:
         raise NotImplementedError
 
-    def prove_bp(self, n_rounds: int, sc: int, g: Point, q: int, cs, nrm, gs, lin, hs, oracle1: Callable[[List[Point]], int]):
-        """proveBPM on PSV(sc, g, NormLinear 1 q cs nrm gs lin hs); returns (responses last round first, norm witness, linear witness)"""
+    def prove_bp(self, flavour: str, n_rounds: int, sc: int, g: Point, q: int, cs, nrm, gs, lin, hs, oracle1: Callable[[List[Point]], int]):
+        """proveBPM on PSV(sc, g, makeNormLinearBP q cs nrm gs lin hs) of the NL or IP flavour; returns (responses last round first,
+        norm witness, linear witness) = getWitness of the final opening"""
         raise NotImplementedError
 
-    def verify_bp(self, q: int, sp: int, g: Point, pub_nrm, gs, cs, pub_lin, hs, es, responses, wit_nrm, wit_lin, init_terms) -> bool:
+    def verify_bp(self, flavour: str, q: int, sp: int, g: Point, pub_nrm, gs, cs, pub_lin, hs, es, responses, wit_nrm, wit_lin, init_terms) -> bool:
         raise NotImplementedError
 
 
@@ -355,21 +357,21 @@ class GpuBackend(Backend):
             return None
         return self.gpu.msm(scalars_to_array([s % N for s in scalars]), points_to_array(list(points)))
 
-    def prove_bp(self, n_rounds, sc, g, q, cs, nrm, gs, lin, hs, oracle1):
-        from .bulletproof import NormLinearBP, proveBPM
-        com = NormLinearBP(self.gpu, sc, g, q, cs, nrm, gs, lin, hs)
+    def prove_bp(self, flavour, n_rounds, sc, g, q, cs, nrm, gs, lin, hs, oracle1):
+        from .bulletproof import NormLinearBP, NormLinearIP, proveBPM
+        com = (NormLinearBP if flavour == "NL" else NormLinearIP)(self.gpu, sc, g, q, cs, nrm, gs, lin, hs)
         try:
             resps, _ = proveBPM(n_rounds, com, oracle1)
-            nw, lw = com.getWitness()
+            wit = com.getWitness()
         finally:
             com.close()
-        return resps, nw, lw
+        return resps, wit[0], wit[1]
 
-    def verify_bp(self, q, sp, g, pub_nrm, gs, cs, pub_lin, hs, es, responses, wit_nrm, wit_lin, init_terms):
-        from .bulletproof import verifyBPM
+    def verify_bp(self, flavour, q, sp, g, pub_nrm, gs, cs, pub_lin, hs, es, responses, wit_nrm, wit_lin, init_terms):
+        from .bulletproof import verifyBPM, verifyBPM_IP
         pad = lambda xs, n: list(xs) + [0] * (n - len(xs))
-        return verifyBPM(self.gpu, q, sp, g, pad(pub_nrm, len(gs)), gs, pad(cs, len(hs)), pad(pub_lin, len(hs)), hs, es, responses, wit_nrm, wit_lin,
-                         init_terms)
+        fn = verifyBPM if flavour == "NL" else verifyBPM_IP
+        return fn(self.gpu, q, sp, g, pad(pub_nrm, len(gs)), gs, pad(cs, len(hs)), pad(pub_lin, len(hs)), hs, es, responses, wit_nrm, wit_lin, init_terms)
 
 
 # ----------------------------------------------------------------------------- transcript (src/ZKP.hs:73-101)
@@ -394,8 +396,16 @@ class Transcript:
 def sha256_oracle(tag: bytes = b"bppp") -> OracleN:
     """Stand-in for shaOracle (app/Main.hs:75-80): challenge n = SHA-256(tag, n, #commitments, decimal coordinates of the whole
     transcript).  The exact `Show` text the reference hashes cannot be confirmed offline — documented choice."""
+    enc: Dict[Point, bytes] = {}
+
+    def one(p: Point) -> bytes:
+        b = enc.get(p)
+        if b is None:
+            b = enc[p] = b"inf" if p is None else str(p[0]).encode() + str(p[1]).encode()
+        return b
+
     def fn(cs: List[Point], count: int) -> List[int]:
-        body = b"".join((b"inf" if p is None else str(p[0]).encode() + str(p[1]).encode()) for p in cs)
+        body = b"".join(one(p) for p in cs)
         return [int.from_bytes(hashlib.sha256(tag + str(n).encode() + str(len(cs)).encode() + body).digest(), "big") % N for n in range(1, count + 1)]
     return fn
 
@@ -421,6 +431,7 @@ class SetupTRRP:
     rounds: int
     final_lens: Tuple[int, int]
     backend: Backend
+    flavour: str = "NL"
 
     def base_map(self, x: int) -> Dict[int, int]:
         """makeBaseMap: sortedBases zipped with x^3, x^5, ... (powers'' (x^3) (x^2), :349)"""
@@ -431,8 +442,9 @@ class SetupTRRP:
         return out
 
     def q_powers(self, q: int, n: int) -> List[int]:
-        """qPowers' of the NL Norm: powers' (q^2) (Bulletproof/NormArgument.hs:148)"""
-        return powers1(q * q % N, n)
+        """qPowers': powers' (q^2) for the NL Norm (Bulletproof/NormArgument.hs:148), powers' (-q^2) for the IP one
+        (Bulletproof/InnerProductArgument.hs:231)"""
+        return powers1(q * q % N if self.flavour == "NL" else (-q * q) % N, n)
 
     def com(self, w: RPW) -> Point:
         """commitRPW sc g lin hs nrm gs (RangeProof/Internal.hs:45-50)"""
@@ -453,21 +465,29 @@ def number_rounds_reduce(n: int) -> Tuple[int, int]:
     return r, n
 
 
-def optimal_witness_size(n_len: int, l_len: int) -> Tuple[int, Tuple[int, int]]:
-    """optimalWitnessSize of the NL NormLinear (Bulletproof/NormArgument.hs:165-178)"""
-    nR, n1 = number_rounds_reduce(n_len)
+def optimal_witness_size(n_len: int, l_len: int, flavour: str = "NL") -> Tuple[int, Tuple[int, int]]:
+    """optimalWitnessSize of NormLinear: NL flavour Bulletproof/NormArgument.hs:165-178; IP flavour (the norm vector is paired up
+    first and reduced to <= 2 pairs) Bulletproof/InnerProductArgument.hs:253-267 with numberRoundsReduce' (Bulletproof.hs:307-308)"""
+    if flavour == "NL":
+        nR, n1 = number_rounds_reduce(n_len)
+    else:
+        nR, n1 = number_rounds_reduce((n_len + n_len % 2) // 2)
+        if n1 > 2:
+            nR, n1 = nR + 1, round_reduce(n1)
     lR, l1 = number_rounds_reduce(l_len)
     r = max(nR, lR)
     for _ in range(r - nR):
         n1 = round_reduce(n1)
     for _ in range(r - lR):
         l1 = round_reduce(l1)
-    if n1 + l1 > 5:
-        return r + 1, (round_reduce(n1), round_reduce(l1))
-    return r, (n1, l1)
+    w = 1 if flavour == "NL" else 2
+    if w * n1 + l1 > 5:
+        return r + 1, (w * round_reduce(n1), round_reduce(l1))
+    return r, (w * n1, l1)
 
 
-def setup(backend: Backend, points: Sequence[Point], has_types: bool, pub_vt: Sequence[Tuple[bool, int, int]], rds: Sequence[RangeData]) -> SetupTRRP:
+def setup(backend: Backend, points: Sequence[Point], has_types: bool, pub_vt: Sequence[Tuple[bool, int, int]], rds: Sequence[RangeData],
+          flavour: str = "NL") -> SetupTRRP:
     """setup (TypedReciprocal.hs:332-359): points = h : g : ps (h is not used by the proof, as in the reference)."""
     live = [rd for rd in rds if not rd.is_assumed]
     any_has_bit = any(rd.has_bit for rd in live)
@@ -480,9 +500,11 @@ def setup(backend: Backend, points: Sequence[Point], has_types: bool, pub_vt: Se
     ps = list(points[2:])
     if len(ps) < lin_len + nrm_len:
         raise ValueError("not enough basis points")
-    rounds, final = optimal_witness_size(nrm_len, lin_len)
+    if flavour not in ("NL", "IP"):
+        raise ValueError("argument flavour must be NL or IP")
+    rounds, final = optimal_witness_size(nrm_len, lin_len, flavour)
     return SetupTRRP(has_types, m_bases, sorted_bases, nrm_len, lin_len, list(pub_vt), list(rds), points[1], ps[:lin_len], ps[lin_len:lin_len + nrm_len],
-                     rounds, final, backend)
+                     rounds, final, backend, flavour)
 
 
 # ----------------------------------------------------------------------------- witness (TypedReciprocal.hs:361-389)
@@ -627,7 +649,7 @@ def prove(st: SetupTRRP, w: WitnessTRRP, oracle: OracleN, rand: RandFn) -> Range
     """proveM: proveRP, then the norm-linear argument on the combined witness (proveBPM, src/Bulletproof.hs:357-359)."""
     tr = Transcript(oracle, rand)
     coms, sbp, wit = prove_rp(st, w, tr)
-    resps, nw, lw = st.backend.prove_bp(sbp.rounds, wit.sc, st.g, sbp.q, sbp.cs, wit.nrm, st.gs, wit.lin, st.hs, lambda xs: tr.oracle(xs, 1)[0])
+    resps, nw, lw = st.backend.prove_bp(st.flavour, sbp.rounds, wit.sc, st.g, sbp.q, sbp.cs, wit.nrm, st.gs, wit.lin, st.hs, lambda xs: tr.oracle(xs, 1)[0])
     return RangeProof(coms, resps, nw, lw)
 
 
@@ -651,5 +673,68 @@ def verify(st: SetupTRRP, proof: RangeProof, oracle: OracleN) -> bool:
     v = verify_inputs(st, proof, oracle)
     if v is None:
         return False
-    return st.backend.verify_bp(v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"], v["responses"], v["wit_norm"],
+    return st.backend.verify_bp(st.flavour, v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"], v["responses"], v["wit_norm"],
                                 v["wit_lin"], v["init_terms"])
+
+
+# ----------------------------------------------------------------------------- schema files (app/Parse.hs, app/Main.hs)
+def approx_log_w(n: int) -> int:
+    """approxLogW (app/Parse.hs:202-206): the default base for a range of width n"""
+    l = integer_log(2, n)
+    return l // integer_log(2, l)
+
+
+def setup_from_schema(backend: Backend, schema: dict, points: Optional[Sequence[Point]] = None) -> SetupTRRP:
+    """The reciprocal branch of the CLI's schema handling (app/Parse.hs:100-186, app/Main.hs:262-285): defaults argument = IP,
+    count = 1, min = 0, max = 2^64, base = approxLogW (max - min), flags False; typed or conserved => hasTypes.  `points`
+    defaults to the try-and-increment stream over schema["basisSeed"] (getPoints, app/Main.hs:68-72; even-y root: this build's
+    documented choice).  Binary schemas ("binary": true) are a different protocol (RangeProof.Binary) and are refused."""
+    if schema.get("binary", False):
+        raise ValueError("binary range proofs (RangeProof.Binary) are not built")
+    arg = str(schema.get("argument", "IP")).lower()
+    flavour = {"ip": "IP", "innerproduct": "IP", "nl": "NL", "normlinear": "NL"}.get(arg)
+    if flavour is None:
+        raise ValueError("Unsupported Argument: " + arg)
+    has_types = bool(schema.get("typed", False)) or bool(schema.get("conserved", False))
+    rds: List[RangeData] = []
+    for r in schema["ranges"]:
+        lo, hi = int(r.get("min", 0)), int(r.get("max", 2**64))
+        base = int(r["base"]) if "base" in r else approx_log_w(hi - lo)
+        rd = make_range_data(base, lo, hi, bool(r.get("isShared", False)), bool(r.get("isOutput", False)), bool(r.get("isAssumed", False)))
+        if rd is None:
+            raise ValueError("Invalid range: %r" % (r,))
+        rds += [rd] * int(r.get("count", 1))
+    pubs = []
+    for pb in schema.get("public", []):
+        if pb.get("blind") is not None:
+            raise ValueError("Cannot have blinding on public value")
+        pubs.append((bool(pb.get("isOutput", False)), int(pb.get("type", 0)), int(pb["amount"])))
+    if points is None:
+        if "basisSeed" not in schema:
+            raise ValueError("no basis: pass points or give basisSeed")
+        nrm_len = sum(len(rd.base_coeffs) + (1 if has_types else 0) for rd in rds)
+        points = basis_points(str(schema["basisSeed"]).encode(), 2 + nrm_len + 6 + sum(rd.base for rd in rds if rd.is_shared) + 2)
+    return setup(backend, points, has_types, pubs, rds, flavour)
+
+
+def inputs_from_witness(witness_json: Sequence[dict], random_seed: bytes = b"default random seed") -> List[Tuple[int, int, int]]:
+    """(amount, type, blinding) per entry; missing blindings come from hashToScalars ("Blinding " <> seed) numbered from 1
+    (app/Main.hs:86-87, :252-253)"""
+    gen = hash_to_scalar(b"Blinding " + random_seed)
+    return [(int(w["amount"]), int(w.get("type", 0)), int(w["blind"]) if w.get("blind") is not None else gen(i + 1)) for i, w in enumerate(witness_json)]
+
+
+def basis_points(seed: bytes, count: int) -> List[Point]:
+    """getPoints (app/Main.hs:68-72): x = SHA-256(seed ++ show n) as a big-endian integer mod p for n = 0, 1, ...; kept when
+    x^3 + 7 is a square; the root taken is the even one (the reference's `sr` choice cannot be confirmed offline)."""
+    p = 2**256 - 2**32 - 977
+    out, n = [], 0
+    while len(out) < count:
+        x = int.from_bytes(hashlib.sha256(seed + str(n).encode()).digest(), "big") % p
+        n += 1
+        rhs = (x * x * x + 7) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p != rhs:
+            continue
+        out.append((x, p - y if y & 1 else y))
+    return out

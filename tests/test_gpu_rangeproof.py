@@ -20,15 +20,16 @@ def pts():
     return O.hash_points(b"test points", 2 + 261 + 512)
 
 
-@pytest.mark.parametrize("name", ["shared_base4_x2", "inline_bit_base3", "typed_with_assumed", "mixed_inline_shared"])
-def test_gpu_transcript_equals_cpu_transcript(gpu, oracle_lib, pts, name):
+@pytest.mark.parametrize("name,flavour", [("shared_base4_x2", "NL"), ("inline_bit_base3", "NL"), ("typed_with_assumed", "NL"), ("mixed_inline_shared", "NL"),
+                                          ("shared_two_bases", "IP"), ("typed_with_assumed", "IP"), ("inline_min_offset", "IP")])
+def test_gpu_transcript_equals_cpu_transcript(gpu, oracle_lib, pts, name, flavour):
     ranges, typed, pub, vals = CASES[name]
     rds = [RP.make_range_data(*r) for r in ranges]
     rnd = random.Random(name)
     inputs = [(v, ty, rnd.randrange(RP.N)) for v, ty in vals]
     out = {}
     for label, be in (("cpu", OracleBackend(oracle_lib)), ("gpu", RP.GpuBackend(gpu))):
-        st = RP.setup(be, pts, typed, pub, rds)
+        st = RP.setup(be, pts, typed, pub, rds, flavour)
         out[label] = (st, RP.prove(st, RP.witness(st, inputs), RP.sha256_oracle(), RP.hash_to_scalar(b"seed " + name.encode())))
     (st_c, pc), (st_g, pg) = out["cpu"], out["gpu"]
     assert pg.coms == pc.coms
@@ -69,7 +70,7 @@ def test_64by64_proofs_verify_on_gpu_and_cpu(gpu, oracle_lib, proofs_64by64):
         v = RP.verify_inputs(st, p, RP.sha256_oracle(b"p%d" % j))
         assert len(v["init_terms"]) == 68 and len(v["es"]) == 8
         # the reference's verifier: ONE 858-term commit must be the identity (src/Bulletproof.hs:377)
-        assert OracleBackend(oracle_lib).verify_bp(v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"],
+        assert OracleBackend(oracle_lib).verify_bp("NL", v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"],
                                                    v["responses"], v["wit_norm"], v["wit_lin"], v["init_terms"])
 
 
@@ -86,3 +87,18 @@ def test_batch_verifier_on_real_range_proofs(gpu, proofs_64by64):
     bad = copy.deepcopy(batch)
     bad[2]["sp"] = (bad[2]["sp"] + 1) % RP.N
     assert not verifyBatch(gpu, bad, st.g, st.gs, st.hs, rhos)
+
+
+@pytest.mark.parametrize("name", ["32bit", "64bit", "rec_test", "32by64", "64by64", "128by64"])
+def test_reference_examples_prove_and_verify_on_the_gpu(gpu, name):
+    """the CLI's `test` mode (app/Main.hs:169-205) for the reference's example schemas + witnesses, every group operation on the GPU"""
+    import json, os
+    from test_rangeproof import EXAMPLES, EXAMPLE_SHAPES
+    schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
+    st = RP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    assert (st.flavour, st.nrm_len, st.lin_len, st.rounds, st.final_lens) == EXAMPLE_SHAPES[name]
+    wit = RP.witness(st, RP.inputs_from_witness(json.load(open(os.path.join(EXAMPLES, name, "witness.json")))))
+    proof = RP.prove(st, wit, RP.sha256_oracle(), RP.hash_to_scalar(b"default random seed"))
+    assert RP.verify(st, proof, RP.sha256_oracle())
+    proof.wit_nrm[-1] = (proof.wit_nrm[-1] + 1) % RP.N
+    assert not RP.verify(st, proof, RP.sha256_oracle())

@@ -3,6 +3,8 @@ backend: algebraic closure (honest proofs verify, tampered ones do not) over the
 shared and inline digits, a binary leading digit, non-zero minimum, typed/conserved amounts with public inputs, assumed ranges —
 and the shapes of SURVEY.md Appendix B.  The reference cannot be run here: parity with the Haskell proofs is unpinned."""
 import copy
+import json
+import os
 import random
 
 import pytest
@@ -48,12 +50,13 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("flavour", ["NL", "IP"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_prove_verify_closes(oracle_lib, pts, name):
+def test_prove_verify_closes(oracle_lib, pts, name, flavour):
     ranges, typed, pub, vals = CASES[name]
     rds = [RP.make_range_data(*r) for r in ranges]
     assert all(rd is not None for rd in rds)
-    st = RP.setup(OracleBackend(oracle_lib), pts, typed, pub, rds)
+    st = RP.setup(OracleBackend(oracle_lib), pts, typed, pub, rds, flavour)
     rnd = random.Random(name)
     inputs = [(v, ty, rnd.randrange(RP.N)) for v, ty in vals]
     proof, ok = _roundtrip(st, inputs)
@@ -142,3 +145,38 @@ def test_rec_test_example_lengths():
     assert [len(r.base_coeffs) for r in rds] == [41, 18, 0] and rds[0].has_bit and rds[1].has_bit
     st = RP.setup(RP.Backend(), [None] * 100, True, [(False, 15, 1)], rds)
     assert (st.nrm_len, st.lin_len, st.m_bases) == (62, 24, [2, 3, 16])
+
+
+EXAMPLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "examples")
+# the reference's examples/ directory (schema.json + witness.json, data fixtures): (flavour, nrmLen, linLen, rounds, final) per SURVEY.md App. B
+EXAMPLE_SHAPES = {"32bit": ("IP", 11, 6, 3, (2, 1)), "64bit": ("IP", 16, 6, 3, (2, 1)), "rec_test": ("IP", 62, 24, 5, (2, 1)),
+                  "32by64": ("NL", 384, 70, 7, (3, 1)), "64by64": ("NL", 512, 261, 8, (2, 2)), "96by64": ("NL", 768, 261, 8, (3, 2)),
+                  "128by64": ("NL", 1024, 261, 9, (2, 1))}
+
+
+@pytest.mark.parametrize("name", list(EXAMPLE_SHAPES))
+def test_reference_example_schemas_parse_to_the_surveyed_shapes(name):
+    schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
+    st = RP.setup_from_schema(RP.Backend(), schema, points=[None] * 1400)
+    assert (st.flavour, st.nrm_len, st.lin_len, st.rounds, st.final_lens) == EXAMPLE_SHAPES[name]
+    wit = json.load(open(os.path.join(EXAMPLES, name, "witness.json")))
+    assert len(wit) == len(st.rds)
+    assert RP.witness(st, RP.inputs_from_witness(wit)) is not None
+
+
+@pytest.mark.parametrize("name", ["32bit", "64bit", "rec_test"])
+def test_small_reference_examples_prove_and_verify_on_the_cpu_backend(oracle_lib, name):
+    """the CLI's `test` mode (app/Main.hs:169-205) on the small examples: prove, verify = True (BASELINE config 1)"""
+    schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
+    st = RP.setup_from_schema(OracleBackend(oracle_lib), schema)
+    wit = RP.witness(st, RP.inputs_from_witness(json.load(open(os.path.join(EXAMPLES, name, "witness.json")))))
+    proof = RP.prove(st, wit, RP.sha256_oracle(), RP.hash_to_scalar(b"default random seed"))
+    assert RP.verify(st, proof, RP.sha256_oracle())
+    proof.wit_lin[0] = (proof.wit_lin[0] + 1) % RP.N
+    assert not RP.verify(st, proof, RP.sha256_oracle())
+
+
+def test_binary_schema_is_refused():
+    schema = json.load(open(os.path.join(EXAMPLES, "bin_test", "schema.json")))
+    with pytest.raises(ValueError):
+        RP.setup_from_schema(RP.Backend(), schema, points=[None] * 400)
