@@ -26,6 +26,7 @@ SYMBOLS = [
     "bppp_ip_create", "bppp_ip_destroy", "bppp_ip_lengths", "bppp_ip_round_commit", "bppp_ip_round_collapse", "bppp_ip_get_witness", "bppp_ip_verify",
     "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
     "bppp_profile_enable", "bppp_profile_read",
+    "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
 ]
 
 
@@ -65,6 +66,10 @@ def load_library() -> C.CDLL:
     lib.bppp_batch_inverse_device.argtypes = [vp, vp, sz, i, vp]
     lib.bppp_tensor_device.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     lib.bppp_lift_x_device.argtypes = [vp, vp, sz, vp]
+    lib.bppp_trrp_create.argtypes = [vp, i, i, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, C.POINTER(vp)]
+    lib.bppp_trrp_destroy.argtypes = [vp]
+    lib.bppp_trrp_destroy.restype = None
+    lib.bppp_trrp_public_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
     lib.bppp_nl_create.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, C.POINTER(vp)]
     lib.bppp_nl_destroy.argtypes = [vp]
     lib.bppp_nl_destroy.restype = None
@@ -146,7 +151,7 @@ def _ptr(a) -> C.c_void_p:
     if a is None:
         return C.c_void_p(0)
     if isinstance(a, np.ndarray):
-        assert a.flags["C_CONTIGUOUS"] and a.dtype == np.uint64
+        assert a.flags["C_CONTIGUOUS"] and a.dtype in (np.uint64, np.uint32)
         p = _Ptr(a.ctypes.data)
         p._keep = a
         return p

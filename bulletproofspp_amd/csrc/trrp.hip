@@ -1,0 +1,250 @@
+// trrp.hip — the verifier's public scalars of B typed-reciprocal range proofs, derived on the device from their challenges.
+//
+// Replaces, for a batch, the scalar work of verifyTRRPM (src/RangeProof/TypedReciprocal.hs:449-467): makePhase2s with the unit
+// witness (:185-205), makeSharedCoeffs (:213-216), makePublicConsts (:246-274), makeBpCoeffs (:391-396) and the opening scalars
+// of TranscriptTRRP (:293-297, inputCoeffs :325-328).  Inputs per proof: the seven Fiat-Shamir challenges (e, x, r0, q, x', r1, t)
+// — hashing stays with the injected oracle on the host (src/ZKP.hs:96-101).  Outputs are exactly the per-proof arrays
+// bppp_nl_verify_batch_device consumes (q, sp, pub_norm, pub_lin_c, initCom scalars), written where it will read them, so a
+// batch of fresh proofs goes from challenges to the combined MSM without its O(nrmLen + linLen) scalars crossing PCIe.
+//
+// One workgroup per proof.  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
+// inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 8x32 limbs (fe.cuh).
+#include <string.h>
+#include <vector>
+#include "ctx.hpp"
+#include "fe.cuh"
+#include "../../include/bppp.h"
+
+namespace bppp {
+
+struct TrrpDims { uint32_t nlen, llen, nr, nsyms, npub, has_types, flavour; };
+
+BPPP_DI fe fr_pow_u32(fe base, uint32_t e) {
+  fe acc = fe_one();
+  while (e) { if (e & 1u) acc = fe_mul<1>(acc, base); base = fe_sqr<1>(base); e >>= 1; }
+  return acc;
+}
+BPPP_DI fe lds_get(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8; k++) r.v[k] = p[i * 8 + k]; return r; }
+BPPP_DI void lds_put(uint32_t *p, uint32_t i, const fe &a) { for (int k = 0; k < 8; k++) p[i * 8 + k] = a.v[k]; }
+BPPP_DI fe fr_small(uint32_t k) { fe r = fe_zero(); r.v[0] = k; return r; }
+
+// position kinds (Phase1 constructors, TypedReciprocal.hs:56-60)
+static constexpr uint32_t K_TYPING = 0, K_INLINE = 1, F_IO = 1u << 8, F_IA = 1u << 9, NO_SYM = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(256) k_trrp_public(TrrpDims D, const uint32_t *__restrict__ pos_kind, const uint32_t *__restrict__ pos_range,
+                                                     const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ pos_sym,
+                                                     const uint32_t *__restrict__ pos_coeff, const uint32_t *__restrict__ range_min,
+                                                     const uint32_t *__restrict__ range_assumed, const uint32_t *__restrict__ syms,
+                                                     const uint32_t *__restrict__ cs_slot, const uint32_t *__restrict__ cs_sym,
+                                                     const uint32_t *__restrict__ pub_is_out, const uint32_t *__restrict__ pub_amount,
+                                                     const uint32_t *__restrict__ pub_sym, const uint32_t *__restrict__ ch,
+                                                     uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp, uint32_t *__restrict__ out_norm,
+                                                     uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t t = threadIdx.x, b = blockIdx.x, m = 2 + D.nsyms;
+  uint32_t *inv = lds;                         // [m] the inverted list: e, q0, e + sym_k
+  uint32_t *sa = inv + (size_t)m * 8;          // [256] scan scratch A
+  uint32_t *sb = sa + 256 * 8;                 // [256] scan scratch B
+  uint32_t *x2 = sb + 256 * 8;                 // [nr]  x^(2(j+1))
+  const uint32_t *c = ch + (size_t)b * 56;
+  const fe e = fe_load(c), x = fe_load(c + 8), r0 = fe_load(c + 16), q = fe_load(c + 24), xp = fe_load(c + 32), r1 = fe_load(c + 40), tt = fe_load(c + 48);
+  fe q0 = fe_sqr<1>(q);                         // qPowers' : q^2 (NL, NormArgument.hs:148) or -q^2 (IP, InnerProductArgument.hs:231)
+  if (D.flavour) q0 = fe_neg<1>(q0);
+
+  // ---- one inversion for the whole proof (batchInverse semantics: 0 -> 0)
+  fe own[4]; bool ownz[4]; int nown = 0;
+  fe local = fe_one();
+  for (uint32_t i = t; i < m && nown < 4; i += 256) {
+    fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));
+    ownz[nown] = fe_is_zero(a);
+    own[nown] = ownz[nown] ? fe_one() : a;
+    local = fe_mul<1>(local, own[nown]);
+    nown++;
+  }
+  lds_put(sa, t, local); lds_put(sb, t, local);
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {          // inclusive prefix (sa) and suffix (sb) products over the threads
+    fe pa = lds_get(sa, t), pb = lds_get(sb, t);
+    fe oa = (int)t - d >= 0 ? lds_get(sa, t - d) : fe_one();
+    fe ob = t + d < 256 ? lds_get(sb, t + d) : fe_one();
+    __syncthreads();
+    lds_put(sa, t, fe_mul<1>(pa, oa)); lds_put(sb, t, fe_mul<1>(pb, ob));
+    __syncthreads();
+  }
+  fe others = fe_mul<1>(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < 256 ? lds_get(sb, t + 1) : fe_one());
+  fe total = lds_get(sa, 255);
+  __syncthreads();
+  if (t == 0) lds_put(sa, 0, fe_inv<1>(total));
+  __syncthreads();
+  fe ginv = fe_mul<1>(lds_get(sa, 0), others);  // = 1 / (product of this thread's own elements)
+  for (int k = 0; k < nown; k++) {
+    fe r = ginv;
+    for (int j = 0; j < nown; j++) if (j != k) r = fe_mul<1>(r, own[j]);
+    lds_put(inv, t + 256 * k, ownz[k] ? fe_zero() : r);
+  }
+  // ---- x^(2(j+1)) per range
+  const fe xx = fe_sqr<1>(x), x3 = fe_mul<1>(xx, x);
+  for (uint32_t j = t; j < D.nr; j += 256) lds_put(x2, j, fr_pow_u32(xx, j + 1));
+  __syncthreads();
+  const fe e_inv = lds_get(inv, 0), q0_inv = lds_get(inv, 1);
+  const fe t2 = fe_sqr<1>(tt), t3 = fe_mul<1>(t2, tt), t4 = fe_sqr<1>(t2), t5 = fe_mul<1>(t4, tt), t6 = fe_sqr<1>(t3);
+  const fe two_t5 = fe_dbl<1>(t5);
+
+  // ---- norm positions: publicTerms (TypedReciprocal.hs:262-274) with u, v, c of makePhase2s (:193-205)
+  fe acc = fe_zero();
+  {
+    fe q2 = fr_pow_u32(q0, t + 1), qi2 = fr_pow_u32(q0_inv, t + 1);
+    const fe qs = fr_pow_u32(q0, 256), qis = fr_pow_u32(q0_inv, 256);
+    for (uint32_t i = t; i < D.nlen; i += 256) {
+      const uint32_t kf = pos_kind[i], kind = kf & 0xFFu, slot = pos_slot[i];
+      const fe xr = lds_get(x2, pos_range[i]);
+      fe u, v, cc = fe_zero();
+      const bool is_t = kind == K_TYPING;
+      if (is_t) {
+        u = (kf & F_IA) ? fe_zero() : xr;
+        v = (kf & F_IO) ? fe_neg<1>(x) : x;
+      } else {
+        u = fe_mul<1>(xr, fe_load(pos_coeff + (size_t)i * 8));
+        v = fe_mul<1>(x3, fr_pow_u32(xx, slot));                   // makeBaseMap: x^3, x^5, ... (:349)
+        const uint32_t sy = pos_sym[i];
+        if (kind == K_INLINE && sy != NO_SYM) {
+          const fe si = lds_get(inv, 2 + sy);                      // "if s == 0 then 0" is tested on the INVERTED value (:205): e + s = 0 gives c = 0
+          if (!fe_is_zero(si)) cc = fe_mul<1>(v, fe_sub<1>(e_inv, si));
+        }
+      }
+      fe rC = fe_mul<1>(qi2, u), p2C = fe_zero();
+      if (is_t) rC = fe_mul<1>(xp, fe_add<1>(rC, fe_one()));
+      else p2C = fe_dbl<1>(fe_add<1>(q2, fe_mul<1>(e_inv, v)));
+      fe p = fe_add<1>(fe_add<1>(fe_mul<1>(t2, fe_add<1>(e, fe_mul<1>(qi2, v))), fe_mul<1>(t3, rC)), fe_mul<1>(t4, fe_mul<1>(qi2, cc)));
+      fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
+      acc = fe_add<1>(acc, fe_add<1>(fe_mul<1>(q2, fe_sqr<1>(p)), fe_mul<1>(t5, p2C)));
+      q2 = fe_mul<1>(q2, qs); qi2 = fe_mul<1>(qi2, qis);
+    }
+  }
+  // z (:254): -2 t^5 sum_j min_j x^(2(j+1))  -  [typed] 2 t^5 x pubSum
+  for (uint32_t j = t; j < D.nr; j += 256)
+    if (!range_assumed[j]) acc = fe_sub<1>(acc, fe_mul<1>(two_t5, fe_mul<1>(fe_load(range_min + (size_t)j * 8), lds_get(x2, j))));
+  if (D.has_types)
+    for (uint32_t j = t; j < D.npub; j += 256) {
+      fe term = fe_mul<1>(fe_mul<1>(two_t5, x), fe_mul<1>(fe_load(pub_amount + (size_t)j * 8), lds_get(inv, 2 + pub_sym[j])));
+      acc = pub_is_out[j] ? fe_add<1>(acc, term) : fe_sub<1>(acc, term);
+    }
+  __syncthreads();
+  lds_put(sa, t, acc);
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)t < d) lds_put(sa, t, fe_add<1>(lds_get(sa, t), lds_get(sa, t + d)));
+    __syncthreads();
+  }
+  if (t == 0) { fe_store(out_sp + (size_t)b * 8, lds_get(sa, 0)); fe_store(out_q + (size_t)b * 8, q); }
+
+  // ---- linear weights: makeBpCoeffs (:391-396) over makeSharedCoeffs (:213-216)
+  const fe rs = fe_mul<1>(r0, r1), two_t3 = fe_dbl<1>(t3);
+  for (uint32_t j = t; j < D.llen; j += 256) {
+    fe v;
+    if (j == 0) v = D.has_types ? fe_neg<1>(xp) : fe_zero();
+    else if (j == 1) v = fe_mul<1>(rs, tt);
+    else if (j == 2) v = fe_mul<1>(rs, t2);
+    else if (j == 3) v = fe_mul<1>(rs, t3);
+    else if (j == 4) v = fe_mul<1>(r0, t4);
+    else if (j == 5) v = fe_mul<1>(rs, t6);
+    else {
+      fe xb = fe_mul<1>(x3, fr_pow_u32(xx, cs_slot[j - 6]));
+      v = fe_mul<1>(two_t3, fe_mul<1>(xb, fe_sub<1>(e_inv, lds_get(inv, 2 + cs_sym[j - 6]))));
+    }
+    fe_store(out_cs + ((size_t)b * D.llen + j) * 8, v);
+  }
+  // ---- initCom scalars in commitment order blCom : rCom : dmCom : mCom : nComs  (openWith of TranscriptTRRP, :293-297)
+  const uint32_t ninit = 4 + D.nr;
+  for (uint32_t j = t; j < ninit; j += 256) {
+    fe v;
+    if (j == 0) v = fe_one();
+    else if (j == 1) v = t3;
+    else if (j == 2) v = t2;
+    else if (j == 3) v = tt;
+    else {
+      const uint32_t r = j - 4;
+      fe ic = range_assumed[r] ? fe_zero() : lds_get(x2, r);                   // inputCoeffs (:325-328)
+      if (D.has_types) ic = fe_add<1>(ic, fr_pow_u32(q0, r + 1));
+      v = fe_mul<1>(two_t5, ic);
+    }
+    fe_store(out_init + ((size_t)b * ninit + j) * 8, v);
+  }
+}
+
+}  // namespace bppp
+
+using namespace bppp;
+
+struct bppp_trrp {
+  bppp_ctx *ctx;
+  TrrpDims D;
+  uint32_t *pos_kind, *pos_range, *pos_slot, *pos_sym, *pos_coeff, *range_min, *range_assumed, *syms, *cs_slot, *cs_sym, *pub_is_out, *pub_amount, *pub_sym;
+};
+
+extern "C" {
+
+void bppp_trrp_destroy(bppp_trrp *o) {
+  if (!o) return;
+  hipSetDevice(o->ctx->device);
+  for (uint32_t *p : {o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min, o->range_assumed, o->syms, o->cs_slot, o->cs_sym, o->pub_is_out,
+                      o->pub_amount, o->pub_sym})
+    if (p) hipFree(p);
+  delete o;
+}
+
+int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, size_t llen, size_t nranges, const uint32_t *pos_kind, const uint32_t *pos_range,
+                     const uint32_t *pos_slot, const uint32_t *pos_sym, const uint64_t *pos_coeff, const uint64_t *range_min, const uint32_t *range_assumed,
+                     size_t nsyms, const uint64_t *syms, const uint32_t *cs_slot, const uint32_t *cs_sym, size_t npub, const uint32_t *pub_is_out,
+                     const uint64_t *pub_amount, const uint32_t *pub_sym, bppp_trrp **out) {
+  if (!ctx || !out) return BPPP_ERR_ARG;
+  if (!nlen || llen < 6 || !nranges || nlen >= (1u << 24) || llen >= (1u << 24) || nranges >= (1u << 20) || nsyms + 2 > 1024 || npub >= (1u << 20) ||
+      !pos_kind || !pos_range || !pos_slot || !pos_sym || !pos_coeff || !range_min || !range_assumed || (nsyms && !syms) || (llen > 6 && (!cs_slot || !cs_sym)) ||
+      (npub && (!pub_is_out || !pub_amount || !pub_sym)))
+    return fail(ctx, BPPP_ERR_ARG, "trrp_create: bad arguments (at most 1022 distinct reciprocal symbols)");
+  for (size_t i = 0; i < nlen; i++)
+    if (pos_range[i] >= nranges || (pos_kind[i] & 0xFFu) > 2 || (pos_sym[i] != 0xFFFFFFFFu && pos_sym[i] >= nsyms) || pos_slot[i] > 64)
+      return fail(ctx, BPPP_ERR_ARG, "trrp_create: position table out of range");
+  for (size_t j = 0; j + 6 < llen; j++)
+    if (cs_sym[j] >= nsyms || cs_slot[j] > 64) return fail(ctx, BPPP_ERR_ARG, "trrp_create: shared-coefficient table out of range");
+  for (size_t j = 0; j < npub; j++)
+    if (pub_sym[j] >= nsyms) return fail(ctx, BPPP_ERR_ARG, "trrp_create: public-amount table out of range");
+  hipSetDevice(ctx->device);
+  bppp_trrp *o = new bppp_trrp();
+  memset(o, 0, sizeof *o);
+  o->ctx = ctx;
+  o->D = TrrpDims{(uint32_t)nlen, (uint32_t)llen, (uint32_t)nranges, (uint32_t)nsyms, (uint32_t)npub, has_types ? 1u : 0u, flavour ? 1u : 0u};
+  bool bad = false;
+  auto up = [&](uint32_t **dst, const void *src, size_t bytes) {
+    if (!bytes) bytes = 4, src = nullptr;
+    if (hipMalloc(dst, bytes) != hipSuccess) { bad = true; *dst = nullptr; return; }
+    if (src && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) bad = true;
+  };
+  up(&o->pos_kind, pos_kind, nlen * 4); up(&o->pos_range, pos_range, nlen * 4); up(&o->pos_slot, pos_slot, nlen * 4); up(&o->pos_sym, pos_sym, nlen * 4);
+  up(&o->pos_coeff, pos_coeff, nlen * 32); up(&o->range_min, range_min, nranges * 32); up(&o->range_assumed, range_assumed, nranges * 4);
+  up(&o->syms, syms, nsyms * 32); up(&o->cs_slot, cs_slot, (llen - 6) * 4); up(&o->cs_sym, cs_sym, (llen - 6) * 4);
+  up(&o->pub_is_out, pub_is_out, npub * 4); up(&o->pub_amount, pub_amount, npub * 32); up(&o->pub_sym, pub_sym, npub * 4);
+  if (bad) { bppp_trrp_destroy(o); return fail(ctx, BPPP_ERR_HIP, "trrp_create: device allocation or upload failed"); }
+  *out = o;
+  return BPPP_OK;
+}
+
+int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges, void *d_q, void *d_sp, void *d_pub_norm, void *d_pub_lin_c,
+                            void *d_init_scalars) {
+  if (!o) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = o->ctx;
+  if (!batch) return BPPP_OK;
+  if (!d_challenges || !d_q || !d_sp || !d_pub_norm || !d_pub_lin_c || !d_init_scalars || batch >= (1u << 24)) return fail(ctx, BPPP_ERR_ARG, "trrp_public: bad arguments");
+  hipSetDevice(ctx->device);
+  const size_t lds = ((size_t)(2 + o->D.nsyms) + 512 + o->D.nr) * 32;
+  if (lds > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "trrp_public: too many ranges for one workgroup's LDS");
+  if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_trrp_public, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_trrp_public<<<dim3((unsigned)batch), dim3(256), lds, ctx->stream>>>(o->D, o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min,
+                                                                        o->range_assumed, o->syms, o->cs_slot, o->cs_sym, o->pub_is_out, o->pub_amount, o->pub_sym,
+                                                                        (const uint32_t *)d_challenges, (uint32_t *)d_q, (uint32_t *)d_sp, (uint32_t *)d_pub_norm,
+                                                                        (uint32_t *)d_pub_lin_c, (uint32_t *)d_init_scalars);
+  BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
+
+}  // extern "C"

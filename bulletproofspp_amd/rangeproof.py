@@ -677,6 +677,114 @@ def verify(st: SetupTRRP, proof: RangeProof, oracle: OracleN) -> bool:
                                 v["wit_lin"], v["init_terms"])
 
 
+# ----------------------------------------------------------------------------- device-side verifier scalars (csrc/trrp.hip)
+def verifier_challenges(st: SetupTRRP, proof: RangeProof, oracle: OracleN) -> Optional[Tuple[List[int], List[int]]]:
+    """The oracle calls of verifyTRRPM (TypedReciprocal.hs:459-462) and of verifyBPM (Bulletproof.hs:374), nothing else:
+    ((e, x, r0, q, x', r1, t), [e_k ... e_1])  — the host's whole share of a device-derived verification."""
+    if len(proof.responses) != st.rounds or (len(proof.wit_nrm), len(proof.wit_lin)) != st.final_lens or len(proof.coms) != 4 + len(st.rds):
+        return None
+    tr = Transcript(oracle)
+    bl_com, r_com, dm_com, m_com = proof.coms[:4]
+    e, x, r0 = tr.oracle([dm_com, m_com] + list(proof.coms[4:]), 3)
+    q, xp, r1 = tr.oracle([r_com], 3)
+    t = tr.oracle([bl_com], 1)[0]
+    es: List[int] = []
+    for a, b in reversed(proof.responses):
+        es.insert(0, tr.oracle([a, b], 1)[0])
+    return [e, x, r0, q, xp, r1, t], es
+
+
+class DeviceVerifierTables:
+    """The static structure of one setup uploaded for bppp_trrp_public_device: from then on a proof's public scalars
+    (makePublicConsts, makeBpCoeffs, the initCom scalars) are computed on the GPU from its seven challenges."""
+
+    def __init__(self, gpu, st: SetupTRRP):
+        import ctypes as C
+        import numpy as np
+        from .capi import _ptr, scalars_to_array
+        self.gpu, self.st, self.h = gpu, st, None
+        ph1ss = [make_phase1s(i, rd, None)[0] for i, rd in enumerate(st.rds)]
+        types = [("typing", i, rd.is_output, rd.is_assumed, None, None) for i, rd in enumerate(st.rds)]
+        ph1s = (types if st.has_types else []) + [p for ps_ in ph1ss for p in ps_]
+        if len(ph1s) != st.nrm_len:
+            raise ValueError("phase-1 layout does not match the setup's norm length")
+        slot_of = {b: k for k, b in enumerate(st.sorted_bases)}
+        syms: List[int] = []
+        sym_idx: Dict[int, int] = {}
+
+        def sym(v: int) -> int:
+            v %= N
+            if v not in sym_idx:
+                sym_idx[v] = len(syms)
+                syms.append(v)
+            return sym_idx[v]
+        kind, rng_, slot, psym, coeff = [], [], [], [], []
+        for p in ph1s:
+            if p[0] == "typing":
+                kind.append(0 | (0x100 if p[2] else 0) | (0x200 if p[3] else 0)); rng_.append(p[1]); slot.append(0); psym.append(0xFFFFFFFF); coeff.append(0)
+            elif p[0] == "inline":
+                kind.append(1); rng_.append(p[1]); slot.append(slot_of[p[2]]); psym.append(sym(p[6]) if p[6] else 0xFFFFFFFF); coeff.append(p[3])
+            else:
+                kind.append(2); rng_.append(p[1]); slot.append(slot_of[p[2]]); psym.append(0xFFFFFFFF); coeff.append(p[3])
+        cs_slot, cs_sym = [], []
+        for b in st.m_bases:
+            for s_ in range(1, b):
+                cs_slot.append(slot_of[b]); cs_sym.append(sym(s_))
+        if 6 + len(cs_slot) != st.lin_len:
+            raise ValueError("shared-base layout does not match the setup's linear length")
+        pub_out = [1 if io else 0 for io, _, _ in st.pub_vt]
+        pub_sym = [sym(ty) for _, ty, _ in st.pub_vt]
+        pub_amt = [v % N for _, _, v in st.pub_vt]
+        u32 = lambda xs: np.ascontiguousarray(np.array(list(xs) or [0], dtype=np.uint32))
+        sc = lambda xs: scalars_to_array(list(xs) or [0])
+        self._keep = [u32(kind), u32(rng_), u32(slot), u32(psym), sc(coeff), sc([rd.lo % N for rd in st.rds]), u32([1 if rd.is_assumed else 0 for rd in st.rds]),
+                      sc(syms), u32(cs_slot), u32(cs_sym), u32(pub_out), sc(pub_amt), u32(pub_sym)]
+        k = self._keep
+        h = C.c_void_p()
+        rc = gpu.lib.bppp_trrp_create(gpu.h, 0 if st.flavour == "NL" else 1, int(st.has_types), st.nrm_len, st.lin_len, len(st.rds), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]),
+                                      _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), _ptr(k[6]), len(syms), _ptr(k[7]), _ptr(k[8]), _ptr(k[9]), len(st.pub_vt), _ptr(k[10]),
+                                      _ptr(k[11]), _ptr(k[12]), C.byref(h))
+        gpu._check(rc, "bppp_trrp_create")
+        self.h = h
+        self.ninit = 4 + len(st.rds)
+
+    def close(self):
+        if self.h:
+            self.gpu.lib.bppp_trrp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def public_device(self, batch: int, d_challenges: int, d_q: int, d_sp: int, d_pub_norm: int, d_pub_lin_c: int, d_init_scalars: int):
+        """device pointers in, device arrays out (see include/bppp.h); asynchronous on the context's stream"""
+        from .capi import _ptr
+        self.gpu._check(self.gpu.lib.bppp_trrp_public_device(self.h, batch, _ptr(d_challenges), _ptr(d_q), _ptr(d_sp), _ptr(d_pub_norm), _ptr(d_pub_lin_c),
+                                                             _ptr(d_init_scalars)), "bppp_trrp_public_device")
+
+    def public(self, challenges: Sequence[Sequence[int]]) -> List[dict]:
+        """host convenience (tests): the derived scalars of each proof as Python integers"""
+        import numpy as np
+        from .capi import array_to_scalars, scalars_to_array
+        B, st, gpu = len(challenges), self.st, self.gpu
+        d_ch = gpu.to_device(np.concatenate([scalars_to_array([c % N for c in ch]) for ch in challenges]))
+        sizes = {"q": B, "sp": B, "pn": B * st.nrm_len, "cs": B * st.lin_len, "init": B * self.ninit}
+        bufs = {k: gpu.to_device(np.zeros((n, 4), dtype=np.uint64)) for k, n in sizes.items()}
+        try:
+            self.public_device(B, d_ch, bufs["q"], bufs["sp"], bufs["pn"], bufs["cs"], bufs["init"])
+            host = {k: array_to_scalars(gpu.download(bufs[k], (n, 4))) for k, n in sizes.items()}
+        finally:
+            gpu.free(d_ch)
+            for p in bufs.values():
+                gpu.free(p)
+        cut = lambda xs, n, b: xs[b * n:(b + 1) * n]
+        return [{"q": host["q"][b], "sp": host["sp"][b], "pub_norm": cut(host["pn"], st.nrm_len, b), "pub_lin_c": cut(host["cs"], st.lin_len, b),
+                 "init_scalars": cut(host["init"], self.ninit, b)} for b in range(B)]
+
+
 # ----------------------------------------------------------------------------- schema files (app/Parse.hs, app/Main.hs)
 def approx_log_w(n: int) -> int:
     """approxLogW (app/Parse.hs:202-206): the default base for a range of width n"""

@@ -213,6 +213,32 @@ int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t
                                 const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
                                 const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
 
+/* ---- range-proof verifier: public scalars from challenges, on the device ----------------------------------------------
+ * The scalar work of verifyTRRPM (src/RangeProof/TypedReciprocal.hs:449-467) for a batch of proofs of ONE setup: makePhase2s on
+ * the unit witness (:185-205), makeSharedCoeffs (:213-216), makePublicConsts (:246-274), makeBpCoeffs (:391-396) and the opening
+ * scalars of TranscriptTRRP (:293-297).  bppp_trrp_create uploads the setup's static structure:
+ *   per norm position i < nlen (the verifier's Phase1 list, types first when has_types):
+ *     pos_kind[i]  = 0 typing | 1 inline | 2 shared, | 0x100 if the range is an output (typing) | 0x200 if it is assumed (typing)
+ *     pos_range[i] = index of the range;  pos_slot[i] = index of the digit's base in the sorted base list (base map x^(3+2 slot));
+ *     pos_sym[i]   = index into syms of the inline symbol, or 0xFFFFFFFF;  pos_coeff[i] = the digit coefficient b (4 limbs)
+ *   per range: range_min (4 limbs, canonical mod n), range_assumed;  syms: the distinct values s whose 1/(e+s) is needed
+ *   cs_slot / cs_sym [llen - 6]: base slot and symbol of each shared-digit linear weight;  public amounts: is_out, amount, type symbol.
+ * flavour 0 = NL (q0 = q^2), 1 = IP (q0 = -q^2).
+ * bppp_trrp_public_device: d_challenges is [batch][7][4] = (e, x, r0, q, x', r1, t) per proof; outputs, all in HBM:
+ *   d_q [batch][4], d_sp [batch][4], d_pub_norm [batch][nlen][4], d_pub_lin_c [batch][llen][4] and
+ *   d_init_scalars [batch][4 + nranges][4] in the proof's commitment order blCom, rCom, dmCom, mCom, nComs...
+ * — exactly the arrays bppp_nl_verify_batch_device reads (its pub_lin_x is all zero for these proofs).  Asynchronous on the
+ * context's stream. */
+typedef struct bppp_trrp bppp_trrp;
+int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, size_t llen, size_t nranges, const uint32_t *pos_kind,
+                     const uint32_t *pos_range, const uint32_t *pos_slot, const uint32_t *pos_sym, const uint64_t *pos_coeff,
+                     const uint64_t *range_min, const uint32_t *range_assumed, size_t nsyms, const uint64_t *syms, const uint32_t *cs_slot,
+                     const uint32_t *cs_sym, size_t npub, const uint32_t *pub_is_out, const uint64_t *pub_amount, const uint32_t *pub_sym,
+                     bppp_trrp **out);
+void bppp_trrp_destroy(bppp_trrp *t);
+int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges, void *d_q, void *d_sp, void *d_pub_norm, void *d_pub_lin_c,
+                            void *d_init_scalars);
+
 /* ---- harness utility: pointX of getPoints (app/Main.hs:68-72) -------------------------------
  * For each candidate x (n x 4 uint64 in HBM) writes the affine point (x, y) with y the EVEN root of
  * x^3 + 7, or the infinity encoding when x^3 + 7 is a non-residue or x >= p.  (Which root

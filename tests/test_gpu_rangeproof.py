@@ -102,3 +102,80 @@ def test_reference_examples_prove_and_verify_on_the_gpu(gpu, name):
     assert RP.verify(st, proof, RP.sha256_oracle())
     proof.wit_nrm[-1] = (proof.wit_nrm[-1] + 1) % RP.N
     assert not RP.verify(st, proof, RP.sha256_oracle())
+
+
+@pytest.mark.parametrize("name,flavour", [("shared_base4_x2", "NL"), ("typed_with_assumed", "NL"), ("mixed_inline_shared", "NL"), ("inline_bit_base3", "IP"),
+                                          ("typed_conserved", "IP"), ("shared_two_bases", "NL")])
+def test_device_derived_verifier_scalars_equal_the_host_derivation(gpu, pts, name, flavour):
+    """bppp_trrp_public_device vs verify_rp (the Python restatement of verifyTRRPM): sp, the public norm vector, the linear
+    weights and the initCom scalars, bit for bit, for random challenges and for a real proof's challenges"""
+    ranges, typed, pub, vals = CASES[name]
+    rds = [RP.make_range_data(*r) for r in ranges]
+    st = RP.setup(RP.GpuBackend(gpu), pts, typed, pub, rds, flavour)
+    tabs = RP.DeviceVerifierTables(gpu, st)
+    rnd = random.Random(name + flavour)
+    proof = RP.prove(st, RP.witness(st, [(v, ty, rnd.randrange(RP.N)) for v, ty in vals]), RP.sha256_oracle(), RP.hash_to_scalar(b"d"))
+    ch_real, es = RP.verifier_challenges(st, proof, RP.sha256_oracle())
+    want_real = RP.verify_inputs(st, proof, RP.sha256_oracle())
+    assert es == want_real["es"]
+    chs = [ch_real] + [[rnd.randrange(RP.N) for _ in range(7)] for _ in range(4)] + [[1, 2, 3, 4, 5, 6, 7], [RP.N - 1] * 7]
+    got = tabs.public(chs)
+    for ch, g_ in zip(chs, got):
+        e, x, r0, q, xp, r1, t = ch
+        # host derivation for arbitrary challenges: replay verify_rp with an oracle that returns them
+        seq = iter([[e, x, r0], [q, xp, r1], [t]])
+        sbp = RP.verify_rp(st, proof.coms, RP.Transcript(lambda cs, n: next(seq)))
+        pad = lambda xs, n: list(xs) + [0] * (n - len(xs))
+        assert g_["q"] == q % RP.N and g_["sp"] == sbp.pub.sc
+        assert g_["pub_norm"] == pad(sbp.pub.nrm, st.nrm_len)
+        assert g_["pub_lin_c"] == pad(sbp.cs, st.lin_len)
+        by_point = {}
+        for s_, p_ in sbp.init_terms:
+            by_point[p_] = (by_point.get(p_, 0) + s_) % RP.N
+        assert len(by_point) == len(proof.coms)
+        assert g_["init_scalars"] == [by_point[p_] for p_ in proof.coms]
+    tabs.close()
+
+
+def test_batch_verification_from_challenges_on_the_device(gpu, proofs_64by64):
+    """challenges -> (device) public scalars -> (device) combined MSM: the whole verifier's arithmetic on the GPU"""
+    import numpy as np
+    from bulletproofspp_amd.capi import points_to_array, scalars_to_array, _ptr, array_to_point
+    st, proofs = proofs_64by64
+    tabs = RP.DeviceVerifierTables(gpu, st)
+    rnd = random.Random(2)
+    B = 9
+    sel = [proofs[i % len(proofs)] for i in range(B)]
+    chs = [RP.verifier_challenges(st, p, RP.sha256_oracle(b"p%d" % (i % len(proofs)))) for i, p in enumerate(sel)]
+
+    def run(mutate=None):
+        ws = [list(p.wit_nrm) for p in sel]
+        if mutate:
+            mutate(ws)
+        up = lambda a: gpu.to_device(a)
+        d = {"ch": up(np.concatenate([scalars_to_array(c[0]) for c in chs])), "es": up(np.concatenate([scalars_to_array(c[1]) for c in chs])),
+             "wn": up(np.concatenate([scalars_to_array(w) for w in ws])), "wl": up(np.concatenate([scalars_to_array(p.wit_lin) for p in sel])),
+             "ip": up(np.concatenate([points_to_array(p.coms) for p in sel])),
+             "rp": up(np.concatenate([points_to_array([q_ for xr in p.responses for q_ in xr]) for p in sel])),
+             "rho": up(scalars_to_array([1] + [rnd.randrange(RP.N) for _ in range(B - 1)])),
+             "g": up(points_to_array([st.g])), "G": up(points_to_array(st.gs)), "H": up(points_to_array(st.hs)),
+             "q": up(np.zeros((B, 4), dtype=np.uint64)), "sp": up(np.zeros((B, 4), dtype=np.uint64)), "pn": up(np.zeros((B * st.nrm_len, 4), dtype=np.uint64)),
+             "cs": up(np.zeros((B * st.lin_len, 4), dtype=np.uint64)), "plx": up(np.zeros((B * st.lin_len, 4), dtype=np.uint64)),
+             "is": up(np.zeros((B * tabs.ninit, 4), dtype=np.uint64))}
+        out = np.zeros(8, dtype=np.uint64)
+        try:
+            tabs.public_device(B, d["ch"], d["q"], d["sp"], d["pn"], d["cs"], d["is"])
+            rc = gpu.lib.bppp_nl_verify_batch_device(gpu.h, B, st.nrm_len, st.lin_len, st.rounds, st.final_lens[0], st.final_lens[1], tabs.ninit,
+                                                     *[_ptr(d[k]) for k in ("g", "G", "H", "rho", "q", "sp", "pn", "cs", "plx", "es", "wn", "wl", "is", "ip", "rp")], _ptr(out))
+            gpu._check(rc, "bppp_nl_verify_batch_device")
+        finally:
+            for p_ in d.values():
+                gpu.free(p_)
+        return array_to_point(out) is None
+
+    assert run()
+
+    def bump(ws):
+        ws[5][0] = (ws[5][0] + 1) % RP.N
+    assert not run(bump)
+    tabs.close()
