@@ -108,9 +108,10 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
     linLen 261, 8 rounds, 68 transcript commitments + 16 responses per proof) per GPU with ONE combined MSM
     (bppp_nl_verify_batch_device).  The proofs are REAL typed-reciprocal range proofs: produced here by
     bulletproofspp_amd.rangeproof (host protocol logic; every commitment and the whole norm-linear argument on the GPU) with a
-    SHA-256 stand-in oracle, `n_real` distinct ones tiled to `batch` with fresh random rho.  Timed: the verifier's group work
-    (challenge expansion, shared-basis merge, the combined MSM) with its inputs resident in HBM.  Not timed: the host derivation of
-    each proof's public scalars from its Fiat-Shamir challenges (verifyTRRPM, TypedReciprocal.hs:449-467; reported separately)."""
+    SHA-256 stand-in oracle, `n_real` distinct ones tiled to `batch` with fresh random rho.  Timed, with the proofs (points, final
+    witness scalars) and their challenges resident in HBM: the derivation of every proof's public scalars from its challenges
+    (verifyTRRPM's arithmetic, TypedReciprocal.hs:449-467, as bppp_trrp_public_device), challenge expansion, shared-basis merge and
+    the combined MSM.  Not timed: the Fiat-Shamir hashing that produces the challenges (the injected oracle; reported separately)."""
     from bulletproofspp_amd import rangeproof as RP
     from bulletproofspp_amd.bulletproof import N_ORDER
     from bulletproofspp_amd.capi import scalars_to_array, points_to_array, array_to_point, _ptr
@@ -145,12 +146,10 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
         orc = RP.sha256_oracle(b"bench%d-%d" % (rank, j))
         prf = RP.prove(st, wit, orc, RP.hash_to_scalar(b"bench rand %d-%d" % (rank, j)))
         t1 = time.perf_counter()
-        v = RP.verify_inputs(st, prf, orc)
+        ch, es_ = RP.verifier_challenges(st, prf, orc)                  # the host's whole share: the oracle calls
         derive_s += time.perf_counter() - t1
-        assert v is not None and len(v["init_terms"]) == ninit and len(v["es"]) == k
-        proofs.append({"q": v["q"], "sp": v["sp"], "pn": v["pub_norm"], "cs": v["pub_lin_c"], "pl": v["pub_lin_x"], "es": v["es"],
-                       "resp": [p_ for xr in v["responses"] for p_ in xr], "nw": v["wit_norm"], "lw": v["wit_lin"],
-                       "ts": [s_ for s_, _ in v["init_terms"]], "init": [p_ for _, p_ in v["init_terms"]]})
+        assert len(prf.coms) == ninit and len(es_) == k
+        proofs.append({"ch": ch, "es": es_, "resp": [p_ for xr in prf.responses for p_ in xr], "nw": prf.wit_nrm, "lw": prf.wit_lin, "init": list(prf.coms)})
     prove_s = (time.perf_counter() - t_prove0 - derive_s) / max(n_real, 1)
     derive_s /= max(n_real, 1)
 
@@ -162,16 +161,21 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
     d = {
         "g": up(points_to_array([g])), "G": up(points_to_array(gs)), "H": up(points_to_array(hs)),
-        "rho": up(scalars_to_array([1] + rand_fr(batch - 1))), "q": up(tile([scalars_to_array([p["q"]]) for p in proofs])),
-        "sp": up(tile([scalars_to_array([p["sp"]]) for p in proofs])), "pub_norm": up(tile([scalars_to_array(p["pn"]) for p in proofs])),
-        "pub_lin_c": up(tile([scalars_to_array(p["cs"]) for p in proofs])), "pub_lin_x": up(tile([scalars_to_array(p["pl"]) for p in proofs])),
+        "rho": up(scalars_to_array([1] + rand_fr(batch - 1))), "ch": up(tile([scalars_to_array(p["ch"]) for p in proofs])),
+        # written by bppp_trrp_public_device every step (the verifier's public scalars, derived from the challenges on the GPU)
+        "q": up(np.zeros((batch, 4), dtype=np.uint64)), "sp": up(np.zeros((batch, 4), dtype=np.uint64)),
+        "pub_norm": up(np.zeros((batch * nlen, 4), dtype=np.uint64)), "pub_lin_c": up(np.zeros((batch * llen, 4), dtype=np.uint64)),
+        "pub_lin_x": up(np.zeros((batch * llen, 4), dtype=np.uint64)), "is": up(np.zeros((batch * ninit, 4), dtype=np.uint64)),
         "es": up(tile([scalars_to_array(p["es"]) for p in proofs])), "wn": up(tile([scalars_to_array(p["nw"]) for p in proofs])),
-        "wl": up(tile([scalars_to_array(p["lw"]) for p in proofs])), "is": up(tile([scalars_to_array(p["ts"]) for p in proofs])),
+        "wl": up(tile([scalars_to_array(p["lw"]) for p in proofs])),
         "ip": up(tile([points_to_array(p["init"]) for p in proofs])), "rp": up(tile([points_to_array(p["resp"]) for p in proofs])),
     }
     out = np.zeros(8, dtype=np.uint64)
+    tabs = RP.DeviceVerifierTables(gpu, st)
 
     def step():
+        tabs.public_device(batch, d["ch"].data_ptr(), d["q"].data_ptr(), d["sp"].data_ptr(), d["pub_norm"].data_ptr(), d["pub_lin_c"].data_ptr(),
+                           d["is"].data_ptr())
         rc = gpu.lib.bppp_nl_verify_batch_device(gpu.h, batch, nlen, llen, k, fn, fl, ninit, *[_ptr(d[x].data_ptr()) for x in
                                                  ("g", "G", "H", "rho", "q", "sp", "pub_norm", "pub_lin_c", "pub_lin_x", "es", "wn", "wl", "is", "ip", "rp")],
                                                  _ptr(out))
@@ -198,6 +202,7 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
         dt = float(t.item())
     assert res is None
     terms = nlen + llen + 1 + batch * (ninit + 2 * k)
+    tabs.close()
     # algorithmic bytes per proof: (ninit + 2k) per-proof pairs x 96 B + (nlen + llen + 1) shared-basis scalars x 32 B
     bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
     res_d = {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
@@ -207,9 +212,10 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
             "shape": f"{shape}: nrmLen {nlen}, linLen {llen}, {k} rounds, {ninit}+{2 * k} per-proof points (SURVEY.md App. B)",
             "proofs": f"{n_real} real range proofs ({count} x 64-bit values each{', typed/conserved' if typed else ''}) from the GPU-backed prover, "
                       f"tiled to {batch}; all verify (combined MSM = infinity)",
-            "scope": "verifyM of RangeProof (src/RangeProof.hs:103-105): the group work is timed; the host derivation of the public scalars "
-                     "(verifyTRRPM + challenge hashing, Python) is reported as host_derive_ms_per_proof",
-            "gpu_prove_ms_per_proof": prove_s * 1e3, "host_derive_ms_per_proof": derive_s * 1e3}
+            "scope": "verifyM of RangeProof (src/RangeProof.hs:103-105) from the challenges on: public scalars (verifyTRRPM's arithmetic, "
+                     "bppp_trrp_public_device) + challenge expansion + shared-basis merge + the combined MSM, all timed, all on the GPU; the "
+                     "Fiat-Shamir hashing (injected oracle, host Python stand-in) is reported as host_hash_ms_per_proof",
+            "gpu_prove_ms_per_proof": prove_s * 1e3, "host_hash_ms_per_proof": derive_s * 1e3}
     if cpu_baseline_leg and rank == 0:
         # the reference verifies ONE proof with ONE 256-row Straus MSM over nlen + llen + 1 + ninit + 2k terms
         # (src/Bulletproof.hs:377): time the oracle's restatement of that on this host (single thread)

@@ -12,6 +12,7 @@ template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
     case BPPP_FE_MUL: return fe_mul<MOD>(a, b);
     case BPPP_FE_SQR: return fe_sqr<MOD>(a);
     case BPPP_FE_INV: return fe_inv<MOD>(a);
+    case 7: return fe_inv_vartime<MOD>(a);       // binary extended Euclid (fe.cuh)
     default: return fe_neg<MOD>(a);
   }
 }

@@ -7,7 +7,7 @@
 // bppp_nl_verify_batch_device consumes (q, sp, pub_norm, pub_lin_c, initCom scalars), written where it will read them, so a
 // batch of fresh proofs goes from challenges to the combined MSM without its O(nrmLen + linLen) scalars crossing PCIe.
 //
-// One workgroup per proof.  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
+// One wavefront per proof.  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
 // inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 8x32 limbs (fe.cuh).
 #include <string.h>
 #include <vector>
@@ -17,11 +17,15 @@
 
 namespace bppp {
 
+// Fr multiply / square as real functions: ~80 call sites would otherwise inline to 37 k instructions (220 KB of code, several
+// times the instruction cache) for a kernel whose wavefronts all sit in different phases
+__device__ __noinline__ fe frm(fe a, fe b) { return fe_mul<1>(a, b); }
+__device__ __noinline__ fe frs(fe a) { return fe_sqr<1>(a); }
 struct TrrpDims { uint32_t nlen, llen, nr, nsyms, npub, has_types, flavour; };
 
 BPPP_DI fe fr_pow_u32(fe base, uint32_t e) {
   fe acc = fe_one();
-  while (e) { if (e & 1u) acc = fe_mul<1>(acc, base); base = fe_sqr<1>(base); e >>= 1; }
+  while (e) { if (e & 1u) acc = frm(acc, base); base = frs(base); e >>= 1; }
   return acc;
 }
 BPPP_DI fe lds_get(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8; k++) r.v[k] = p[i * 8 + k]; return r; }
@@ -31,145 +35,153 @@ BPPP_DI fe fr_small(uint32_t k) { fe r = fe_zero(); r.v[0] = k; return r; }
 // position kinds (Phase1 constructors, TypedReciprocal.hs:56-60)
 static constexpr uint32_t K_TYPING = 0, K_INLINE = 1, F_IO = 1u << 8, F_IA = 1u << 9, NO_SYM = 0xFFFFFFFFu;
 
-__global__ void __launch_bounds__(256) k_trrp_public(TrrpDims D, const uint32_t *__restrict__ pos_kind, const uint32_t *__restrict__ pos_range,
-                                                     const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ pos_sym,
-                                                     const uint32_t *__restrict__ pos_coeff, const uint32_t *__restrict__ range_min,
-                                                     const uint32_t *__restrict__ range_assumed, const uint32_t *__restrict__ syms,
-                                                     const uint32_t *__restrict__ cs_slot, const uint32_t *__restrict__ cs_sym,
-                                                     const uint32_t *__restrict__ pub_is_out, const uint32_t *__restrict__ pub_amount,
-                                                     const uint32_t *__restrict__ pub_sym, const uint32_t *__restrict__ ch,
-                                                     uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp, uint32_t *__restrict__ out_norm,
-                                                     uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
+static constexpr int TRRP_MAX_SLOTS = 16;      // distinct digit bases of one setup (base map x^3, x^5, ...)
+
+// One WAVEFRONT per proof (64 lanes): lane t owns the contiguous chunks [t*C, (t+1)*C) of every list, so the running powers of
+// q0 advance by one multiplication per position.  ~9 k Fr multiplications per 64by64-shaped proof, half of them start-up
+// (per-lane first powers, the inversion scan); a 256-lane workgroup per proof spent three times that on start-up alone.
+__global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *__restrict__ pos_kind, const uint32_t *__restrict__ pos_range,
+                                                    const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ pos_sym,
+                                                    const uint32_t *__restrict__ pos_coeff, const uint32_t *__restrict__ range_min,
+                                                    const uint32_t *__restrict__ range_assumed, const uint32_t *__restrict__ syms,
+                                                    const uint32_t *__restrict__ cs_slot, const uint32_t *__restrict__ cs_sym,
+                                                    const uint32_t *__restrict__ pub_is_out, const uint32_t *__restrict__ pub_amount,
+                                                    const uint32_t *__restrict__ pub_sym, const uint32_t *__restrict__ ch,
+                                                    uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp, uint32_t *__restrict__ out_norm,
+                                                    uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
   extern __shared__ uint32_t lds[];
   const uint32_t t = threadIdx.x, b = blockIdx.x, m = 2 + D.nsyms;
   uint32_t *inv = lds;                         // [m] the inverted list: e, q0, e + sym_k
-  uint32_t *sa = inv + (size_t)m * 8;          // [256] scan scratch A
-  uint32_t *sb = sa + 256 * 8;                 // [256] scan scratch B
-  uint32_t *x2 = sb + 256 * 8;                 // [nr]  x^(2(j+1))
+  uint32_t *pre = inv + (size_t)m * 8;         // [m] products of a lane's own elements before each one
+  uint32_t *sa = pre + (size_t)m * 8;          // [64] scan scratch A
+  uint32_t *sb = sa + 64 * 8;                  // [64] scan scratch B
+  uint32_t *x2 = sb + 64 * 8;                  // [nr]  x^(2(j+1))
+  uint32_t *sl = x2 + (size_t)D.nr * 8;        // [3][TRRP_MAX_SLOTS] per base slot: t^2 v, 2 t^5 v / e, 2 t^3 v   (v = x^(3+2 slot))
   const uint32_t *c = ch + (size_t)b * 56;
   const fe e = fe_load(c), x = fe_load(c + 8), r0 = fe_load(c + 16), q = fe_load(c + 24), xp = fe_load(c + 32), r1 = fe_load(c + 40), tt = fe_load(c + 48);
-  fe q0 = fe_sqr<1>(q);                         // qPowers' : q^2 (NL, NormArgument.hs:148) or -q^2 (IP, InnerProductArgument.hs:231)
+  fe q0 = frs(q);                         // qPowers' : q^2 (NL, NormArgument.hs:148) or -q^2 (IP, InnerProductArgument.hs:231)
   if (D.flavour) q0 = fe_neg<1>(q0);
 
   // ---- one inversion for the whole proof (batchInverse semantics: 0 -> 0)
-  fe own[4]; bool ownz[4]; int nown = 0;
+  const uint32_t K = (m + 63) / 64, lo = min(m, t * K), hi = min(m, lo + K);
   fe local = fe_one();
-  for (uint32_t i = t; i < m && nown < 4; i += 256) {
+  for (uint32_t i = lo; i < hi; i++) {
     fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));
-    ownz[nown] = fe_is_zero(a);
-    own[nown] = ownz[nown] ? fe_one() : a;
-    local = fe_mul<1>(local, own[nown]);
-    nown++;
+    lds_put(inv, i, a);
+    lds_put(pre, i, local);
+    if (!fe_is_zero(a)) local = frm(local, a);
   }
   lds_put(sa, t, local); lds_put(sb, t, local);
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {          // inclusive prefix (sa) and suffix (sb) products over the threads
+  for (int d = 1; d < 64; d <<= 1) {           // inclusive prefix (sa) and suffix (sb) products over the lanes
     fe pa = lds_get(sa, t), pb = lds_get(sb, t);
     fe oa = (int)t - d >= 0 ? lds_get(sa, t - d) : fe_one();
-    fe ob = t + d < 256 ? lds_get(sb, t + d) : fe_one();
+    fe ob = t + d < 64 ? lds_get(sb, t + d) : fe_one();
     __syncthreads();
-    lds_put(sa, t, fe_mul<1>(pa, oa)); lds_put(sb, t, fe_mul<1>(pb, ob));
+    lds_put(sa, t, frm(pa, oa)); lds_put(sb, t, frm(pb, ob));
     __syncthreads();
   }
-  fe others = fe_mul<1>(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < 256 ? lds_get(sb, t + 1) : fe_one());
-  fe total = lds_get(sa, 255);
+  fe others = frm(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < 64 ? lds_get(sb, t + 1) : fe_one());
+  fe total = lds_get(sa, 63);
   __syncthreads();
-  if (t == 0) lds_put(sa, 0, fe_inv<1>(total));
+  if (t == 0) lds_put(sa, 0, fe_inv_vartime<1>(total));   // one active lane: the cheap variable-time inverse
   __syncthreads();
-  fe ginv = fe_mul<1>(lds_get(sa, 0), others);  // = 1 / (product of this thread's own elements)
-  for (int k = 0; k < nown; k++) {
-    fe r = ginv;
-    for (int j = 0; j < nown; j++) if (j != k) r = fe_mul<1>(r, own[j]);
-    lds_put(inv, t + 256 * k, ownz[k] ? fe_zero() : r);
+  {
+    fe suf = frm(lds_get(sa, 0), others);  // 1 / (product of this lane's own elements), then times the ones already passed
+    for (uint32_t i = hi; i-- > lo;) {
+      fe a = lds_get(inv, i);
+      if (fe_is_zero(a)) continue;               // stays 0
+      lds_put(inv, i, frm(suf, lds_get(pre, i)));
+      suf = frm(suf, a);
+    }
   }
-  // ---- x^(2(j+1)) per range
-  const fe xx = fe_sqr<1>(x), x3 = fe_mul<1>(xx, x);
-  for (uint32_t j = t; j < D.nr; j += 256) lds_put(x2, j, fr_pow_u32(xx, j + 1));
+  // ---- per-range and per-base-slot tables
+  const fe xx = frs(x), x3 = frm(xx, x);
+  const fe t2 = frs(tt), t3 = frm(t2, tt), t4 = frs(t2), t5 = frm(t4, tt), t6 = frs(t3);
+  const fe two_t5 = fe_dbl<1>(t5), two_t3 = fe_dbl<1>(t3);
+  for (uint32_t j = t; j < D.nr; j += 64) lds_put(x2, j, fr_pow_u32(xx, j + 1));
   __syncthreads();
   const fe e_inv = lds_get(inv, 0), q0_inv = lds_get(inv, 1);
-  const fe t2 = fe_sqr<1>(tt), t3 = fe_mul<1>(t2, tt), t4 = fe_sqr<1>(t2), t5 = fe_mul<1>(t4, tt), t6 = fe_sqr<1>(t3);
-  const fe two_t5 = fe_dbl<1>(t5);
+  if (t < TRRP_MAX_SLOTS) {
+    fe v = frm(x3, fr_pow_u32(xx, t));                       // makeBaseMap: x^3, x^5, ... (:349)
+    lds_put(sl, t, frm(t2, v));
+    lds_put(sl, TRRP_MAX_SLOTS + t, frm(frm(two_t5, e_inv), v));
+    lds_put(sl, 2 * TRRP_MAX_SLOTS + t, frm(two_t3, v));
+  }
+  __syncthreads();
 
-  // ---- norm positions: publicTerms (TypedReciprocal.hs:262-274) with u, v, c of makePhase2s (:193-205)
+  // ---- norm positions: publicTerms (TypedReciprocal.hs:262-274) with u, v, c of makePhase2s (:193-205), regrouped:
+  //   digit:  p = t^2 e + q^-2i (t^2 v + t^3 u + t^4 c),        ts0 = q^2i (p^2 + 2 t^5) + 2 t^5 v / e
+  //   type:   p = t^2 e + t^3 x' + q^-2i (t^2 v + t^3 x' u),     ts0 = q^2i p^2
   fe acc = fe_zero();
   {
-    fe q2 = fr_pow_u32(q0, t + 1), qi2 = fr_pow_u32(q0_inv, t + 1);
-    const fe qs = fr_pow_u32(q0, 256), qis = fr_pow_u32(q0_inv, 256);
-    for (uint32_t i = t; i < D.nlen; i += 256) {
-      const uint32_t kf = pos_kind[i], kind = kf & 0xFFu, slot = pos_slot[i];
+    const uint32_t C = (D.nlen + 63) / 64, plo = min(D.nlen, t * C), phi = min(D.nlen, plo + C);
+    fe q2 = fr_pow_u32(q0, plo + 1), qi2 = fr_pow_u32(q0_inv, plo + 1);
+    const fe t2e = frm(t2, e), t3xp = frm(t3, xp), t2e_t = fe_add<1>(t2e, t3xp);
+    for (uint32_t i = plo; i < phi; i++) {
+      const uint32_t kf = pos_kind[i], kind = kf & 0xFFu;
       const fe xr = lds_get(x2, pos_range[i]);
-      fe u, v, cc = fe_zero();
-      const bool is_t = kind == K_TYPING;
-      if (is_t) {
-        u = (kf & F_IA) ? fe_zero() : xr;
-        v = (kf & F_IO) ? fe_neg<1>(x) : x;
+      fe p, ts0;
+      if (kind == K_TYPING) {
+        fe A = frm(t2, (kf & F_IO) ? fe_neg<1>(x) : x);
+        if (!(kf & F_IA)) A = fe_add<1>(A, frm(t3xp, xr));
+        p = fe_add<1>(t2e_t, frm(qi2, A));
+        ts0 = frm(q2, frs(p));
       } else {
-        u = fe_mul<1>(xr, fe_load(pos_coeff + (size_t)i * 8));
-        v = fe_mul<1>(x3, fr_pow_u32(xx, slot));                   // makeBaseMap: x^3, x^5, ... (:349)
-        const uint32_t sy = pos_sym[i];
+        const uint32_t slot = pos_slot[i], sy = pos_sym[i];
+        fe A = fe_add<1>(lds_get(sl, slot), frm(t3, frm(xr, fe_load(pos_coeff + (size_t)i * 8))));
         if (kind == K_INLINE && sy != NO_SYM) {
           const fe si = lds_get(inv, 2 + sy);                      // "if s == 0 then 0" is tested on the INVERTED value (:205): e + s = 0 gives c = 0
-          if (!fe_is_zero(si)) cc = fe_mul<1>(v, fe_sub<1>(e_inv, si));
+          if (!fe_is_zero(si)) A = fe_add<1>(A, frm(frm(t4, frm(x3, fr_pow_u32(xx, slot))), fe_sub<1>(e_inv, si)));
         }
+        p = fe_add<1>(t2e, frm(qi2, A));
+        ts0 = fe_add<1>(frm(q2, fe_add<1>(frs(p), two_t5)), lds_get(sl, TRRP_MAX_SLOTS + slot));
       }
-      fe rC = fe_mul<1>(qi2, u), p2C = fe_zero();
-      if (is_t) rC = fe_mul<1>(xp, fe_add<1>(rC, fe_one()));
-      else p2C = fe_dbl<1>(fe_add<1>(q2, fe_mul<1>(e_inv, v)));
-      fe p = fe_add<1>(fe_add<1>(fe_mul<1>(t2, fe_add<1>(e, fe_mul<1>(qi2, v))), fe_mul<1>(t3, rC)), fe_mul<1>(t4, fe_mul<1>(qi2, cc)));
       fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
-      acc = fe_add<1>(acc, fe_add<1>(fe_mul<1>(q2, fe_sqr<1>(p)), fe_mul<1>(t5, p2C)));
-      q2 = fe_mul<1>(q2, qs); qi2 = fe_mul<1>(qi2, qis);
+      acc = fe_add<1>(acc, ts0);
+      q2 = frm(q2, q0); qi2 = frm(qi2, q0_inv);
     }
   }
   // z (:254): -2 t^5 sum_j min_j x^(2(j+1))  -  [typed] 2 t^5 x pubSum
-  for (uint32_t j = t; j < D.nr; j += 256)
-    if (!range_assumed[j]) acc = fe_sub<1>(acc, fe_mul<1>(two_t5, fe_mul<1>(fe_load(range_min + (size_t)j * 8), lds_get(x2, j))));
+  for (uint32_t j = t; j < D.nr; j += 64)
+    if (!range_assumed[j]) acc = fe_sub<1>(acc, frm(two_t5, frm(fe_load(range_min + (size_t)j * 8), lds_get(x2, j))));
   if (D.has_types)
-    for (uint32_t j = t; j < D.npub; j += 256) {
-      fe term = fe_mul<1>(fe_mul<1>(two_t5, x), fe_mul<1>(fe_load(pub_amount + (size_t)j * 8), lds_get(inv, 2 + pub_sym[j])));
+    for (uint32_t j = t; j < D.npub; j += 64) {
+      fe term = frm(frm(two_t5, x), frm(fe_load(pub_amount + (size_t)j * 8), lds_get(inv, 2 + pub_sym[j])));
       acc = pub_is_out[j] ? fe_add<1>(acc, term) : fe_sub<1>(acc, term);
     }
   __syncthreads();
   lds_put(sa, t, acc);
   __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
+  for (int d = 32; d >= 1; d >>= 1) {
     if ((int)t < d) lds_put(sa, t, fe_add<1>(lds_get(sa, t), lds_get(sa, t + d)));
     __syncthreads();
   }
   if (t == 0) { fe_store(out_sp + (size_t)b * 8, lds_get(sa, 0)); fe_store(out_q + (size_t)b * 8, q); }
 
   // ---- linear weights: makeBpCoeffs (:391-396) over makeSharedCoeffs (:213-216)
-  const fe rs = fe_mul<1>(r0, r1), two_t3 = fe_dbl<1>(t3);
-  for (uint32_t j = t; j < D.llen; j += 256) {
+  const fe rs = frm(r0, r1);
+  for (uint32_t j = t; j < D.llen; j += 64) {
     fe v;
     if (j == 0) v = D.has_types ? fe_neg<1>(xp) : fe_zero();
-    else if (j == 1) v = fe_mul<1>(rs, tt);
-    else if (j == 2) v = fe_mul<1>(rs, t2);
-    else if (j == 3) v = fe_mul<1>(rs, t3);
-    else if (j == 4) v = fe_mul<1>(r0, t4);
-    else if (j == 5) v = fe_mul<1>(rs, t6);
-    else {
-      fe xb = fe_mul<1>(x3, fr_pow_u32(xx, cs_slot[j - 6]));
-      v = fe_mul<1>(two_t3, fe_mul<1>(xb, fe_sub<1>(e_inv, lds_get(inv, 2 + cs_sym[j - 6]))));
-    }
+    else if (j == 1) v = frm(rs, tt);
+    else if (j == 2) v = frm(rs, t2);
+    else if (j == 3) v = frm(rs, t3);
+    else if (j == 4) v = frm(r0, t4);
+    else if (j == 5) v = frm(rs, t6);
+    else v = frm(lds_get(sl, 2 * TRRP_MAX_SLOTS + cs_slot[j - 6]), fe_sub<1>(e_inv, lds_get(inv, 2 + cs_sym[j - 6])));
     fe_store(out_cs + ((size_t)b * D.llen + j) * 8, v);
   }
   // ---- initCom scalars in commitment order blCom : rCom : dmCom : mCom : nComs  (openWith of TranscriptTRRP, :293-297)
   const uint32_t ninit = 4 + D.nr;
-  for (uint32_t j = t; j < ninit; j += 256) {
-    fe v;
-    if (j == 0) v = fe_one();
-    else if (j == 1) v = t3;
-    else if (j == 2) v = t2;
-    else if (j == 3) v = tt;
-    else {
-      const uint32_t r = j - 4;
-      fe ic = range_assumed[r] ? fe_zero() : lds_get(x2, r);                   // inputCoeffs (:325-328)
-      if (D.has_types) ic = fe_add<1>(ic, fr_pow_u32(q0, r + 1));
-      v = fe_mul<1>(two_t5, ic);
-    }
-    fe_store(out_init + ((size_t)b * ninit + j) * 8, v);
+  fe qr = D.has_types ? fr_pow_u32(q0, t + 1) : fe_zero();
+  const fe q64 = D.has_types ? fr_pow_u32(q0, 64) : fe_zero();
+  for (uint32_t r = t; r < D.nr; r += 64) {
+    fe ic = range_assumed[r] ? fe_zero() : lds_get(x2, r);                     // inputCoeffs (:325-328)
+    if (D.has_types) { ic = fe_add<1>(ic, qr); qr = frm(qr, q64); }
+    fe_store(out_init + ((size_t)b * ninit + 4 + r) * 8, frm(two_t5, ic));
   }
+  if (t < 4) fe_store(out_init + ((size_t)b * ninit + t) * 8, t == 0 ? fe_one() : t == 1 ? t3 : t == 2 ? t2 : tt);
 }
 
 }  // namespace bppp
@@ -203,10 +215,10 @@ int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, siz
       (npub && (!pub_is_out || !pub_amount || !pub_sym)))
     return fail(ctx, BPPP_ERR_ARG, "trrp_create: bad arguments (at most 1022 distinct reciprocal symbols)");
   for (size_t i = 0; i < nlen; i++)
-    if (pos_range[i] >= nranges || (pos_kind[i] & 0xFFu) > 2 || (pos_sym[i] != 0xFFFFFFFFu && pos_sym[i] >= nsyms) || pos_slot[i] > 64)
+    if (pos_range[i] >= nranges || (pos_kind[i] & 0xFFu) > 2 || (pos_sym[i] != 0xFFFFFFFFu && pos_sym[i] >= nsyms) || pos_slot[i] >= (uint32_t)TRRP_MAX_SLOTS)
       return fail(ctx, BPPP_ERR_ARG, "trrp_create: position table out of range");
   for (size_t j = 0; j + 6 < llen; j++)
-    if (cs_sym[j] >= nsyms || cs_slot[j] > 64) return fail(ctx, BPPP_ERR_ARG, "trrp_create: shared-coefficient table out of range");
+    if (cs_sym[j] >= nsyms || cs_slot[j] >= (uint32_t)TRRP_MAX_SLOTS) return fail(ctx, BPPP_ERR_ARG, "trrp_create: shared-coefficient table out of range");
   for (size_t j = 0; j < npub; j++)
     if (pub_sym[j] >= nsyms) return fail(ctx, BPPP_ERR_ARG, "trrp_create: public-amount table out of range");
   hipSetDevice(ctx->device);
@@ -236,10 +248,10 @@ int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges
   if (!batch) return BPPP_OK;
   if (!d_challenges || !d_q || !d_sp || !d_pub_norm || !d_pub_lin_c || !d_init_scalars || batch >= (1u << 24)) return fail(ctx, BPPP_ERR_ARG, "trrp_public: bad arguments");
   hipSetDevice(ctx->device);
-  const size_t lds = ((size_t)(2 + o->D.nsyms) + 512 + o->D.nr) * 32;
+  const size_t lds = ((size_t)2 * (2 + o->D.nsyms) + 128 + o->D.nr + 3 * TRRP_MAX_SLOTS) * 32;
   if (lds > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "trrp_public: too many ranges for one workgroup's LDS");
   if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_trrp_public, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_trrp_public<<<dim3((unsigned)batch), dim3(256), lds, ctx->stream>>>(o->D, o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min,
+  k_trrp_public<<<dim3((unsigned)batch), dim3(64), lds, ctx->stream>>>(o->D, o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min,
                                                                         o->range_assumed, o->syms, o->cs_slot, o->cs_sym, o->pub_is_out, o->pub_amount, o->pub_sym,
                                                                         (const uint32_t *)d_challenges, (uint32_t *)d_q, (uint32_t *)d_sp, (uint32_t *)d_pub_norm,
                                                                         (uint32_t *)d_pub_lin_c, (uint32_t *)d_init_scalars);
