@@ -241,6 +241,26 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
     return res_d
 
 
+def prove_cpu_baseline(shape: str, reps: int = 2):
+    """The reference's proveBPM for one argument of this shape through the oracle (oracle/pyoracle.py driving the C restatement's
+    256-row Straus commits and 129-row pair folds), single thread: a reported baseline for the prove leg."""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as O
+    nlen, llen, k, _, _, _ = SHAPES[shape]
+    ec = O.CEC()
+    pts = O.hash_points(b"cpu prove", 1 + nlen + llen)
+    rnd = random.Random(7)
+    r = lambda n: [rnd.randrange(O.N) for _ in range(n)]
+    t0 = time.perf_counter()
+    for j in range(reps):
+        com = O.PSV(rnd.randrange(O.N), pts[0], O.NormLinear.make(1, rnd.randrange(O.N), r(llen), r(nlen), pts[1:1 + nlen], r(llen), pts[1 + nlen:]))
+        O.prove_bp(k, com, O.Transcript(O.sha_oracle_fn(b"cpu%d" % j)), ec)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} arguments of the same shape, proveBPM through the oracle restatement (Straus commits, 129-row pair folds), single thread"}
+
+
 def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64", pipelines: int = 2):
     """Lockstep batch prover (bppp_nlb_*): `batch` norm-linear arguments of the examples/64by64 shape advanced round by round
     together (proveBPM, src/Bulletproof.hs:357-359).  The injected oracle is a SHA-256 stand-in over the raw 128 bytes of each
@@ -443,6 +463,8 @@ def main():
     prove = None
     if args.prove_batch > 0 and world == 1:
         prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2, pipelines=args.prove_pipelines)
+        if not args.no_cpu_baseline:
+            prove["cpu_baseline"] = prove_cpu_baseline("64by64")
 
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
