@@ -179,3 +179,29 @@ def test_batch_verification_from_challenges_on_the_device(gpu, proofs_64by64):
         ws[5][0] = (ws[5][0] + 1) % RP.N
     assert not run(bump)
     tabs.close()
+
+
+def test_binary_range_proofs_gpu_equals_cpu_and_bin_test_example(gpu, oracle_lib, pts):
+    """RangeProof.Binary: same transcript on both backends; examples/bin_test proves and verifies with the group work on the GPU"""
+    import json, os
+    from bulletproofspp_amd import rangeproof_binary as BRP
+    from test_rangeproof import BIN_CASES, EXAMPLES
+    for name in ("odd_width", "with_assumed"):
+        ranges, net, vals = BIN_CASES[name]
+        rds = [BRP.make_range_data(*r) for r in ranges]
+        rnd = random.Random(name)
+        inputs = [(v, rnd.randrange(RP.N)) for v in vals]
+        got = {}
+        for label, be in (("cpu", OracleBackend(oracle_lib)), ("gpu", RP.GpuBackend(gpu))):
+            st = BRP.setup(be, pts, True, rds, net, "NL")
+            got[label] = (st, BRP.prove(st, BRP.witness(st, inputs), RP.sha256_oracle(), RP.hash_to_scalar(b"bin " + name.encode())))
+        (sc, pc), (sg, pg) = got["cpu"], got["gpu"]
+        assert (pg.coms, pg.responses, pg.wit_nrm, pg.wit_lin) == (pc.coms, pc.responses, pc.wit_nrm, pc.wit_lin)
+        assert BRP.verify(sg, pc, RP.sha256_oracle()) and BRP.verify(sc, pg, RP.sha256_oracle())
+    schema = json.load(open(os.path.join(EXAMPLES, "bin_test", "schema.json")))
+    st = BRP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    inputs = RP.inputs_from_witness(json.load(open(os.path.join(EXAMPLES, "bin_test", "witness.json"))))
+    proof = BRP.prove(st, BRP.witness(st, [(v, bl) for v, _, bl in inputs]), RP.sha256_oracle(), RP.hash_to_scalar(b"default random seed"))
+    assert BRP.verify(st, proof, RP.sha256_oracle())
+    proof.wit_nrm[0] = (proof.wit_nrm[0] + 1) % RP.N
+    assert not BRP.verify(st, proof, RP.sha256_oracle())

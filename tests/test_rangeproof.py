@@ -11,6 +11,7 @@ import pytest
 
 import pyoracle as O
 from bulletproofspp_amd import rangeproof as RP
+from bulletproofspp_amd import rangeproof_binary as BRP
 from rp_backends import OracleBackend
 
 
@@ -176,7 +177,67 @@ def test_small_reference_examples_prove_and_verify_on_the_cpu_backend(oracle_lib
     assert not RP.verify(st, proof, RP.sha256_oracle())
 
 
-def test_binary_schema_is_refused():
+def test_binary_schema_is_refused_by_the_reciprocal_parser():
     schema = json.load(open(os.path.join(EXAMPLES, "bin_test", "schema.json")))
     with pytest.raises(ValueError):
         RP.setup_from_schema(RP.Backend(), schema, points=[None] * 400)
+
+
+# ----------------------------------------------------------------------------- RangeProof.Binary
+BIN_CASES = {
+    # ranges [(lo, hi, output, assumed)], net public, inputs [amount]
+    "one_output_8bit": ([(0, 256, True, False)], 200, [200]),
+    "odd_width": ([(3, 1000, True, False), (0, 77, False, False)], 500, [510, 10]),
+    "with_assumed": ([(3, 2**16, True, False), (2, 2**16, False, True), (2, 2**16, False, True)], 2, [124, 1, 121]),
+    "top_digit_boundaries": ([(0, 96, True, False), (0, 96, True, False), (0, 96, True, False), (0, 256, False, False)], 0, [32, 33, 95, 160]),
+}
+
+
+@pytest.mark.parametrize("name", list(BIN_CASES))
+def test_binary_prove_verify_closes(oracle_lib, pts, name):
+    ranges, net, vals = BIN_CASES[name]
+    rds = [BRP.make_range_data(*r) for r in ranges]
+    st = BRP.setup(OracleBackend(oracle_lib), pts, True, rds, net, "NL")
+    rnd = random.Random(name)
+    wit = BRP.witness(st, [(v, rnd.randrange(RP.N)) for v in vals])
+    proof = BRP.prove(st, wit, RP.sha256_oracle(), RP.hash_to_scalar(b"bin"))
+    assert BRP.verify(st, proof, RP.sha256_oracle())
+    for field, idx in (("wit_nrm", 0), ("wit_lin", 0)):
+        bad = copy.deepcopy(proof)
+        getattr(bad, field)[idx] = (getattr(bad, field)[idx] + 1) % RP.N
+        assert not BRP.verify(st, bad, RP.sha256_oracle())
+    bad = copy.deepcopy(proof)
+    bad.coms[2] = oracle_lib.add(bad.coms[2], pts[1])
+    assert not BRP.verify(st, bad, RP.sha256_oracle())
+    assert not BRP.verify(st, proof, RP.sha256_oracle(b"another oracle"))
+
+
+def test_binary_digits_and_witness_rules():
+    rnd = random.Random(9)
+    for lo, hi in [(0, 256), (3, 2**64), (0, 96), (5, 6), (0, 3), (10, 1000)]:
+        rd = BRP.make_range_data(lo, hi)
+        for v in [lo, hi - 1, lo + rd.base_coeffs[0], lo + rd.base_coeffs[0] + 1] + [rnd.randrange(lo, hi) for _ in range(40)]:
+            if not lo <= v < hi:
+                continue
+            ds = BRP.make_digits(rd, v)
+            assert len(ds) == len(rd.base_coeffs) and set(ds) <= {0, 1}
+            assert sum(d * c for d, c in zip(ds, rd.base_coeffs)) == v - lo
+    rd = BRP.make_range_data(0, 256, True)
+    st = BRP.setup(RP.Backend(), [None] * 20, True, [rd], 5)
+    with pytest.raises(ValueError):
+        BRP.witness(st, [(6, 1)])                  # does not balance the public amount
+    with pytest.raises(ValueError):
+        BRP.witness(BRP.setup(RP.Backend(), [None] * 20, False, [rd], 5), [(5, 1)])      # unconserved: the reference has no witness either
+
+
+def test_bin_test_example(oracle_lib):
+    """examples/bin_test: binary, conserved, NL — nrmLen 192, linLen 2, 6 rounds, final (3, 1); proves and verifies"""
+    schema = json.load(open(os.path.join(EXAMPLES, "bin_test", "schema.json")))
+    st = BRP.setup_from_schema(OracleBackend(oracle_lib), schema)
+    assert (st.flavour, st.nrm_len, st.lin_len, st.rounds, st.final_lens) == ("NL", 192, 2, 6, (3, 1))
+    inputs = RP.inputs_from_witness(json.load(open(os.path.join(EXAMPLES, "bin_test", "witness.json"))))
+    wit = BRP.witness(st, [(v, bl) for v, _, bl in inputs])
+    proof = BRP.prove(st, wit, RP.sha256_oracle(), RP.hash_to_scalar(b"default random seed"))
+    assert len(proof.coms) == 2 + 3 and BRP.verify(st, proof, RP.sha256_oracle())
+    # verifier MSM of the reference: 192 + 2 + 1 shared + 5 commitments + 12 responses = 212 terms (App. B)
+    assert st.nrm_len + 2 + 1 + len(proof.coms) + 2 * st.rounds == 212
