@@ -1,0 +1,83 @@
+"""Wire format (bulletproofspp_amd/encoding.py = src/Encoding.hs + RangeProof.hs:60-85): byte layout known answers derived from
+the reference's Binary instances, round trips, malformed input, and proof sizes of the example shapes."""
+import random
+
+import pytest
+
+import pyoracle as O
+from bulletproofspp_amd import encoding as E
+from bulletproofspp_amd import rangeproof as RP
+from rp_backends import OracleBackend
+
+
+def _cpu_lift(ec):
+    return lambda xs: [ec.lift_x(x) for x in xs]
+
+
+def test_field_element_layout():
+    # four 64-bit words, least-significant word first, each big-endian (Encoding.hs:75-86)
+    assert E.put_field(1) == bytes([0] * 7 + [1] + [0] * 24)
+    assert E.put_field(2**64) == bytes([0] * 8 + [0] * 7 + [1] + [0] * 16)
+    assert E.put_field(0x0102030405060708_1112131415161718_2122232425262728_3132333435363738) == bytes.fromhex(
+        "3132333435363738" "2122232425262728" "1112131415161718" "0102030405060708")
+    rnd = random.Random(1)
+    for _ in range(100):
+        v = rnd.randrange(O.N)
+        assert E.get_field(E.put_field(v), O.N) == v
+    assert E.get_field(b"\xff" * 32, O.N) == (2**256 - 1) % O.N          # toP reduces
+
+
+def test_commitment_list_layout(oracle_lib):
+    pts = O.hash_points(b"enc", 11)
+    neg = lambda p: (p[0], O.P - p[1])
+    big = lambda p: p if p[1] > O.P - p[1] else neg(p)
+    small = lambda p: neg(big(p))
+    lst = [big(pts[0]), small(pts[1]), small(pts[2]), big(pts[3]), small(pts[4]), small(pts[5]), small(pts[6]), big(pts[7]), big(pts[8]), small(pts[9]),
+           big(pts[10])]
+    data = E.encode_commitments(lst)
+    assert len(data) == 2 + 11 * 32
+    assert data[0] == 0b10001001 and data[1] == 0b00000101            # bit k of byte j = sign of point 8j + k (bitPack, :105-110)
+    assert data[2:34] == E.put_field(lst[0][0])
+    got, used = E.decode_commitments(11, data + b"trailing", _cpu_lift(oracle_lib))
+    assert got == lst and used == len(data)
+    assert E.decode_commitments(11, data[:-1], _cpu_lift(oracle_lib)) is None
+    # an x that is not on the curve
+    x_bad = next(x for x in range(2, 100) if oracle_lib.lift_x(x) is None)
+    assert E.decode_commitments(1, b"\x00" + E.put_field(x_bad), _cpu_lift(oracle_lib)) is None
+    with pytest.raises(ValueError):
+        E.encode_commitments([None])
+
+
+@pytest.mark.parametrize("flavour", ["NL", "IP"])
+def test_proof_round_trip_and_verify(oracle_lib, flavour):
+    pts = O.hash_points(b"test points", 80)
+    rds = [RP.make_range_data(4, 0, 256, True, True, False), RP.make_range_data(3, 0, 100, False, False, False)]
+    st = RP.setup(OracleBackend(oracle_lib), pts, False, [], rds, flavour)
+    proof = RP.prove(st, RP.witness(st, [(200, 0, 5), (77, 0, 6)]), RP.sha256_oracle(), RP.hash_to_scalar(b"enc"))
+    coms_file, proof_file = E.encode_proof(4, proof)
+    assert len(coms_file) == 1 + 2 * 32
+    n_pts = 4 + 2 * st.rounds
+    assert len(proof_file) == 32 * sum(st.final_lens) + (n_pts + 7) // 8 + 32 * n_pts
+    n_coms, _ = E.decode_commitments(2, coms_file, _cpu_lift(oracle_lib))
+    back = E.decode_proof(4, st.rounds, st.final_lens, n_coms, proof_file, _cpu_lift(oracle_lib))
+    assert back == proof
+    assert RP.verify(st, back, RP.sha256_oracle())
+    # flipping one sign bit gives a well-formed but different proof that must not verify
+    flipped = bytearray(proof_file)
+    flipped[32 * sum(st.final_lens)] ^= 1
+    other = E.decode_proof(4, st.rounds, st.final_lens, n_coms, bytes(flipped), _cpu_lift(oracle_lib))
+    assert other is not None and other != proof and not RP.verify(st, other, RP.sha256_oracle())
+    assert E.decode_proof(4, st.rounds, st.final_lens, n_coms, proof_file[:-5], _cpu_lift(oracle_lib)) is None
+
+
+@pytest.mark.parametrize("name,rp_coms,points,scalars", [("64bit", 4, 10, 3), ("32bit", 4, 10, 3), ("64by64", 4, 20, 4), ("128by64", 4, 22, 3), ("96by64", 4, 20, 5),
+                                                         ("32by64", 4, 18, 4), ("rec_test", 4, 14, 3)])
+def test_proof_sizes_of_the_examples(name, rp_coms, points, scalars):
+    """SURVEY.md App. B's "proof" column: points = range-proof commitments + 2 per round, scalars = final witness"""
+    import json, os
+    from test_rangeproof import EXAMPLES
+    st = RP.setup_from_schema(RP.Backend(), json.load(open(os.path.join(EXAMPLES, name, "schema.json"))), points=[None] * 1400)
+    assert (rp_coms + 2 * st.rounds, sum(st.final_lens)) == (points, scalars)
+    size = 32 * scalars + (points + 7) // 8 + 32 * points
+    if name == "64bit":
+        assert size == 418        # 10 points + 3 scalars = 416 B (the paper's figure) + 2 sign bytes

@@ -205,3 +205,19 @@ def test_binary_range_proofs_gpu_equals_cpu_and_bin_test_example(gpu, oracle_lib
     assert BRP.verify(st, proof, RP.sha256_oracle())
     proof.wit_nrm[0] = (proof.wit_nrm[0] + 1) % RP.N
     assert not BRP.verify(st, proof, RP.sha256_oracle())
+
+
+def test_wire_format_round_trip_with_gpu_decompression(gpu, oracle_lib, proofs_64by64):
+    """encodeProof' / decodeProof' (RangeProof.hs:60-85) on a 64by64 proof: 771-byte proof file, point decompression by
+    bppp_lift_x_device equal to the CPU's, decoded proof identical and verifying"""
+    from bulletproofspp_amd import encoding as E
+    st, proofs = proofs_64by64
+    p = proofs[1]
+    coms_file, proof_file = E.encode_proof(4, p)
+    assert len(proof_file) == 4 * 32 + 3 + 20 * 32 and len(coms_file) == 8 + 64 * 32
+    lift = E.gpu_lift_x(gpu)
+    n_coms, used = E.decode_commitments(64, coms_file, lift)
+    assert used == len(coms_file) and n_coms == p.coms[4:]
+    assert n_coms == E.decode_commitments(64, coms_file, lambda xs: [oracle_lib.lift_x(x) for x in xs])[0]
+    back = E.decode_proof(4, st.rounds, st.final_lens, n_coms, proof_file, lift)
+    assert back == p and RP.verify(st, back, RP.sha256_oracle(b"p1"))
