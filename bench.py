@@ -420,7 +420,7 @@ def main():
     def combine(part):
         """all-gather one 64-B partial point per rank (RCCL has no mod-p reduction) and add them with the library"""
         allp = all_gather_points(points_to_array([part])[0], dist, coll_dev)
-        return gpu.msm(ones_np, np.ascontiguousarray(allp))
+        return gpu.sum_points(allp)
 
     def step():
         part = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), n, args.window)

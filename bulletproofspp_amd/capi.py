@@ -15,7 +15,7 @@ STAGE_NAMES = ["digits", "sort", "acc_points", "acc_records", "reduce", "finish"
 # every symbol include/bppp.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bppp_ctx_create", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_last_error", "bppp_version",
-    "bppp_msm", "bppp_msm_device", "bppp_msm_batch_device", "bppp_rational_reduce",
+    "bppp_msm", "bppp_msm_device", "bppp_msm_batch_device", "bppp_sum_points", "bppp_rational_reduce",
     "bppp_fold_points", "bppp_fold_points_device",
     "bppp_norm_round_sums_device", "bppp_lin_round_sums_device",
     "bppp_norm_round_openings_device", "bppp_lin_round_openings_device",
@@ -55,6 +55,7 @@ def load_library() -> C.CDLL:
     lib.bppp_msm.argtypes = [vp, vp, vp, sz, vp]
     lib.bppp_msm_device.argtypes = [vp, vp, vp, sz, i, vp]
     lib.bppp_msm_batch_device.argtypes = [vp, vp, vp, sz, sz, i, i, vp]
+    lib.bppp_sum_points.argtypes = [vp, vp, sz, vp]
     lib.bppp_rational_reduce.argtypes = [vp, vp, C.POINTER(i), vp, C.POINTER(i)]
     lib.bppp_fold_points.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
     lib.bppp_fold_points_device.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
@@ -207,6 +208,13 @@ class Bppp:
         self._check(self.lib.bppp_msm_batch_device(self.h, _ptr(d_scalars), _ptr(d_points), n, batch, int(shared_points), window_bits, _ptr(out)),
                     "bppp_msm_batch_device")
         return [array_to_point(out[b]) for b in range(batch)]
+
+    def sum_points(self, points: np.ndarray):
+        """sum of a few affine points ((n, 8) uint64): the combine step after the all-gather of a sharded MSM"""
+        pts = np.ascontiguousarray(points)
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.bppp_sum_points(self.h, _ptr(pts), pts.shape[0] if pts.size else 0, _ptr(out)), "bppp_sum_points")
+        return array_to_point(out)
 
     # ---- reduced scalars / folds
     def rational_reduce(self, x: int) -> Tuple[int, int]:

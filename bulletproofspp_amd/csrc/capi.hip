@@ -135,6 +135,25 @@ int bppp_msm(bppp_ctx *ctx, const uint64_t *scalars, const uint64_t *points_xy, 
   return rc;
 }
 
+// The tail of a sharded MSM: the N partial points that the ranks all-gathered (one 64-B affine point each; RCCL has no mod-p
+// reduction) are added here, on the host, with the complete group law — the same place and for the same reason as the MSM's
+// final Horner combine: a handful of dependent additions is latency, not throughput.
+int bppp_sum_points(bppp_ctx *ctx, const uint64_t *points_xy, size_t n, uint64_t out_xy[8]) {
+  using namespace bppp_host;
+  if (!ctx) return BPPP_ERR_ARG;
+  if (!out_xy || (n && !points_xy)) return fail(ctx, BPPP_ERR_ARG, "sum_points: null pointer");
+  if (n > 65536) return fail(ctx, BPPP_ERR_ARG, "sum_points: meant for a few partial points; use bppp_msm for more");
+  HJac acc = hj_inf();
+  for (size_t i = 0; i < n; i++) {
+    HAff a{U256::load(points_xy + 8 * i), U256::load(points_xy + 8 * i + 4)};
+    if (cmp(a.x, FQ().m) >= 0 || cmp(a.y, FQ().m) >= 0) return fail(ctx, BPPP_ERR_ARG, "sum_points: coordinate not canonical");
+    acc = hj_add(acc, hj_from_aff(a));
+  }
+  HAff r = hj_to_aff(acc);
+  r.x.store(out_xy); r.y.store(out_xy + 4);
+  return BPPP_OK;
+}
+
 int bppp_rational_reduce(const uint64_t x[4], uint64_t a_mag[3], int *a_neg, uint64_t b_mag[3], int *b_neg) {
   if (!x || !a_mag || !a_neg || !b_mag || !b_neg) return BPPP_ERR_ARG;
   bppp_host::U256 v = bppp_host::U256::load(x);

@@ -65,6 +65,9 @@ int bppp_msm_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_x
  * commitments of one proof) when shared_points == d >= 2.  out_xy is [batch][8] on the host. */
 int bppp_msm_batch_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, size_t batch,
                           int shared_points, int window_bits, uint64_t *out_xy);
+/* Sum of n affine points (complete group law): the local tail of a sharded MSM after the ranks all-gathered their partial points
+ * (SURVEY.md 8e).  Host arithmetic, microseconds for the 2..64 points it is meant for. */
+int bppp_sum_points(bppp_ctx *ctx, const uint64_t *points_xy, size_t n, uint64_t out_xy[8]);
 
 /* ---- a7: SplitScalar.rationalReduceScalar (host) ------------------------------------------
  * Replaces rationalReduceScalar for `Prime p` (src/Commitment.hs:242-255, instance :269-288):

@@ -138,3 +138,19 @@ def test_msm_equals_reference_glv_path(gpu):
     sc, pts = _rand_case(40, 4040, zero_every=9, inf_every=13)
     want = O.glv_inner_product(list(zip(sc, pts)), O.PyEC())
     assert gpu.msm(scalars_to_array(sc), points_to_array(pts)) == want
+
+
+def test_sum_points_is_the_group_sum(gpu, oracle_lib):
+    """bppp_sum_points (the combine step of a sharded MSM): complete group law incl. infinity, repeated and opposite points"""
+    h = O.hash_points(b"sum", 9)
+    neg = lambda p: (p[0], O.P - p[1])
+    for pts in ([h[0]], [], [None, None], [h[0], h[0]], [h[1], neg(h[1])], [h[2], None, h[3], h[2], neg(h[3]), h[4]], h):
+        want = None
+        for p in pts:
+            want = oracle_lib.add(want, p)
+        got = gpu.sum_points(points_to_array(pts) if pts else np.zeros((0, 8), dtype=np.uint64))
+        assert got == want
+    bad = points_to_array([h[0]])
+    bad[0, 3] = np.uint64(0xFFFFFFFFFFFFFFFF); bad[0, 2] = bad[0, 3]; bad[0, 1] = bad[0, 3]; bad[0, 0] = bad[0, 3]
+    with pytest.raises(Exception):
+        gpu.sum_points(bad)
