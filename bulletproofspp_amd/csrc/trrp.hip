@@ -30,7 +30,6 @@ BPPP_DI fe fr_pow_u32(fe base, uint32_t e) {
 }
 BPPP_DI fe lds_get(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8; k++) r.v[k] = p[i * 8 + k]; return r; }
 BPPP_DI void lds_put(uint32_t *p, uint32_t i, const fe &a) { for (int k = 0; k < 8; k++) p[i * 8 + k] = a.v[k]; }
-BPPP_DI fe fr_small(uint32_t k) { fe r = fe_zero(); r.v[0] = k; return r; }
 
 // position kinds (Phase1 constructors, TypedReciprocal.hs:56-60)
 static constexpr uint32_t K_TYPING = 0, K_INLINE = 1, F_IO = 1u << 8, F_IA = 1u << 9, NO_SYM = 0xFFFFFFFFu;
