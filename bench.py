@@ -405,7 +405,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     coll_dev = dev if args.backend == "nccl" else None      # gloo rehearsal gathers through host tensors
-    from bulletproofspp_amd.dist import all_gather_points
+    from bulletproofspp_amd.dist import all_gather_points, all_gather_points_async
 
     n = 1 << args.log2n
     gpu = b.Bppp(local)
@@ -439,8 +439,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    if world == 1:
+        for _ in range(args.steps):
+            res = step()
+    else:
+        # every step's 64-B all-gather is issued without blocking and overlaps the next step's kernels; all K sums are
+        # completed (waited for and added) before the clock stops
+        pend = []
+        for _ in range(args.steps):
+            part = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), n, args.window)
+            pend.append(all_gather_points_async(points_to_array([part])[0], dist, coll_dev))
+        sums = [gpu.sum_points(p.result()) for p in pend]
+        assert all(s_ == sums[0] for s_ in sums), "sharded MSM results differ between steps"
+        res = sums[-1]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -38,7 +38,12 @@ def _worker(rank, world, port, n, q):
 
     total = bd.sharded_msm(n, rank, world, local_msm, sum_points, dist)
     want = ec.inner_product(list(zip(sc, pts)))
-    q.put((rank, array_to_point(total) == want, bd.shard_range(n, rank, world)))
+    # the non-blocking exchange used by bench.py for N > 1: several gathers in flight, results in issue order
+    lo, hi = bd.shard_range(n, rank, world)
+    part = local_msm(lo, hi)
+    pend = [bd.all_gather_points_async(part, dist) for _ in range(3)]
+    ok_async = all(array_to_point(sum_points(p.result())) == want for p in pend)
+    q.put((rank, array_to_point(total) == want and ok_async, bd.shard_range(n, rank, world)))
     dist.destroy_process_group()
 
 
