@@ -376,6 +376,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=4096, help="proofs per GPU in the batch-verify leg (0 = skip)")
     ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
+    ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--prove-pipelines", type=int, default=2, help="contexts (stream + host thread) the prover batch is split over")
     ap.add_argument("--prove-batch", type=int, default=2048, help="proofs advanced in lockstep in the prover leg (0 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -463,6 +464,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # throughput with several MSMs in flight (one context = one stream + one host thread each): the latency-bound stages of one
+    # (bucket reduction, window combine, the host round trip) overlap the accumulate kernel of another.  Reported beside the
+    # single-stream headline, whose per-kernel durations are what the roofline and the rocprof summaries refer to.
+    concurrent = None
+    if world == 1 and args.msm_streams > 1:
+        import threading
+        ctxs = [b.Bppp(local) for _ in range(args.msm_streams)]
+        for c_ in ctxs:
+            c_.msm_device(dsc.data_ptr(), dpts.data_ptr(), n, args.window)
+        per = max(2, args.steps // 2)
+        outs = [None] * len(ctxs)
+
+        def work(i):
+            for _ in range(per):
+                outs[i] = ctxs[i].msm_device(dsc.data_ptr(), dpts.data_ptr(), n, args.window)
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        cdt = time.perf_counter() - tc0
+        assert all(o == res for o in outs), "concurrent MSMs disagree with the single-stream result"
+        for c_ in ctxs:
+            c_.close()
+        concurrent = {"streams": len(ctxs), "value": n * per * len(ctxs) / cdt, "unit": "pairs/s", "ms_per_msm": cdt / (per * len(ctxs)) * 1e3,
+                      "msms": per * len(ctxs)}
+
     verify = None
     if args.verify_batch > 0:
         vsteps = max(3, args.steps // 2)
@@ -537,6 +567,8 @@ def main():
             mt_rate, mt_cores, mt_dt = cpu_baseline_threads(sc_np, pts_np, per_thread)
             out["cpu_baseline_all_cores"] = {"value": mt_rate, "unit": "pairs/s", "cores": mt_cores, "kind": "port",
                                              "sample": f"{mt_cores} threads x {per_thread} pairs, same restatement, one slice per thread", "seconds": mt_dt}
+        if concurrent is not None:
+            out["concurrent"] = concurrent
         if verify is not None:
             out["verify"] = verify
         if prove is not None:
