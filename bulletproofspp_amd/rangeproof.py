@@ -336,6 +336,10 @@ class Backend:
     def commit(self, scalars: Sequence[int], points: Sequence[Point]) -> Point:
         raise NotImplementedError
 
+    def commit_rows(self, rows: Sequence[Sequence[int]], points: Sequence[Point]) -> List[Point]:
+        """one commitment per row of scalars, all over the same points (the input commitments of a proof); default: one MSM each"""
+        return [self.commit(r, points) for r in rows]
+
     def prove_bp(self, flavour: str, n_rounds: int, sc: int, g: Point, q: int, cs, nrm, gs, lin, hs, oracle1: Callable[[List[Point]], int]):
         """proveBPM on PSV(sc, g, makeNormLinearBP q cs nrm gs lin hs) of the NL or IP flavour; returns (responses last round first,
         norm witness, linear witness) = getWitness of the final opening"""
@@ -356,6 +360,20 @@ class GpuBackend(Backend):
         if not len(scalars):
             return None
         return self.gpu.msm(scalars_to_array([s % N for s in scalars]), points_to_array(list(points)))
+
+    def commit_rows(self, rows, points):
+        """all rows in ONE batched MSM over the shared points (bppp_msm_batch_device, shared_points = 1)"""
+        import numpy as np
+        from .capi import points_to_array, scalars_to_array
+        if not rows:
+            return []
+        n = len(points)
+        d_s = self.gpu.to_device(np.concatenate([scalars_to_array([s % N for s in r]) for r in rows]))
+        d_p = self.gpu.to_device(points_to_array(list(points)))
+        try:
+            return self.gpu.msm_batch_device(d_s, d_p, n, len(rows), shared_points=True)
+        finally:
+            self.gpu.free(d_s); self.gpu.free(d_p)
 
     def prove_bp(self, flavour, n_rounds, sc, g, q, cs, nrm, gs, lin, hs, oracle1):
         from .bulletproof import NormLinearBP, NormLinearIP, proveBPM
@@ -584,7 +602,7 @@ def prove_rp(st: SetupTRRP, w: WitnessTRRP, tr: Transcript) -> Tuple[List[Point]
     ds, ms_inline = get_ds_ms(w.ph1s)
 
     n_wits = [RPW(v, [ty, bl], []) for v, ty, bl in w.inputs]                    # scalarPairRPW' (Internal.hs:59-60)
-    n_coms = [st.com(nw) for nw in n_wits]
+    n_coms = st.backend.commit_rows([[nw.sc] + nw.lin for nw in n_wits], [st.g] + st.hs[:2])   # = [st.com(nw) ...], one launch
     dm_wit = blind_witness(num_terms, 2, ms_shared, ds, tr.random); dm_com = st.com(dm_wit)
     m_wit = blind_witness(num_terms, 1, [], ms_inline, tr.random); m_com = st.com(m_wit)
 

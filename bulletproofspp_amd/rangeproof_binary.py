@@ -131,7 +131,7 @@ def prove_rp(st: SetupBRP, wit, tr: Transcript):
     """proveBRPM (Binary.hs:169-204)"""
     ns, ds = wit
     n_wits = [RPW(v, [bl], []) for v, bl in ns]                       # scalarRPW' (Internal.hs:56-57)
-    n_coms = [st.com(w) for w in n_wits]
+    n_coms = st.backend.commit_rows([[w.sc] + w.lin for w in n_wits], [st.g] + st.hs[:1])    # = [st.com(w) ...], one launch
     s_bl, l_bl0 = tr.random(), tr.random()
     d_wit = RPW(s_bl, [l_bl0, 0], list(ds)); d_com = st.com(d_wit)
     q, x, r = tr.oracle([d_com] + n_coms, 3)
