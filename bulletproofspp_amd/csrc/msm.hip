@@ -506,6 +506,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
   if (!d_scalars || !d_points) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
   if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "msm: n must be < 2^31");
   int c = window_bits ? window_bits : choose_window(n, batch);
+  if (!window_bits) if (const char *e = getenv("BPPP_WINDOW_BATCHED")) { int v = atoi(e); if (batch > 4 && v >= 2 && v <= 16) c = v; }   // tuning sweeps
   if (c < 2 || c > 16) return fail(ctx, BPPP_ERR_ARG, "msm: window_bits must be in [2,16]");
   MsmPlan p = make_plan(n, batch, c);
   if (p.FB >= (1ull << 32) - 1 || p.total_max >= (1ull << 32) - 1)
