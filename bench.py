@@ -540,7 +540,7 @@ def main():
             "metric": "msm_scalar_point_pairs_per_sec", "value": world * n * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u256 (8x32-bit limbs, modular integer)", "data": "synthetic",
+            "dtype": "u256 modular integer (Fq: 10x26-bit lazy limbs, Fr: 8x32-bit limbs)", "data": "synthetic",
             "config": {"workload": f"pedersen_msm_2^{args.log2n}_secp256k1", "pairs_per_gpu": n, "window_bits": args.window or "auto",
                        "algorithm": "signed-digit Pippenger, affine in / XYZZ buckets", "sharding": f"terms/{world}" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_acc_points", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
