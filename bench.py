@@ -504,7 +504,7 @@ def main():
         for _ in range(reps):
             gpu.msm(sc_h, pt_h)
         hdt = (time.perf_counter() - th0) / reps
-        host_call = {"entry": "bppp_msm (pageable host buffers in, 96 B per pair over PCIe, allocation included)", "ms_per_call": hdt * 1e3,
+        host_call = {"entry": "bppp_msm (pageable host buffers in, 96 B per pair over PCIe)", "ms_per_call": hdt * 1e3,
                      "value": n / hdt, "unit": "pairs/s"}
         del sc_h, pt_h
 

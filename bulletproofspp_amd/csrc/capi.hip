@@ -117,21 +117,30 @@ int bppp_msm_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_x
   CTX_ENTER(ctx);
   return msm_run(ctx, d_scalars, d_points_xy, n, 1, 1, window_bits, out_xy);
 }
+namespace {
+struct PointUpload { bppp_ctx *ctx; void *dst; const void *src; size_t bytes; };
+int upload_points_now(void *arg) {
+  PointUpload *u = (PointUpload *)arg;
+  if (hipMemcpyAsync(u->dst, u->src, u->bytes, hipMemcpyHostToDevice, u->ctx->stream) != hipSuccess) return fail(u->ctx, BPPP_ERR_HIP, "msm: point upload failed");
+  return BPPP_OK;
+}
+}  // namespace
 int bppp_msm(bppp_ctx *ctx, const uint64_t *scalars, const uint64_t *points_xy, size_t n, uint64_t out_xy[8]) {
   CTX_ENTER(ctx);
   if (!out_xy) return fail(ctx, BPPP_ERR_ARG, "msm: null output");
   if (n == 0) { memset(out_xy, 0, 64); return BPPP_OK; }
   if (!scalars || !points_xy) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
-  void *ds = nullptr, *dp = nullptr;
-  BPPP_HIP(ctx, hipMalloc(&ds, n * 32));
-  if (hipMalloc(&dp, n * 64) != hipSuccess) { hipFree(ds); return fail(ctx, BPPP_ERR_HIP, "hipMalloc(points) failed"); }
-  int rc = BPPP_OK;
-  if (hipMemcpyAsync(ds, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-      hipMemcpyAsync(dp, points_xy, n * 64, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-    rc = fail(ctx, BPPP_ERR_HIP, "msm: upload failed");
-  if (!rc) rc = msm_run(ctx, ds, dp, n, 1, 1, 0, out_xy);
+  // inputs staged in the context's second grow-only buffer (no hipMalloc per call); the scalars go first, the points are
+  // copied by the hook msm_run calls just before its accumulate kernel: the host-side copy of 64 B/pair then runs while the
+  // GPU recodes and sorts the digits
+  { int rc0 = ensure_scratch(ctx, n * 96 + 256); if (rc0) return rc0; }
+  char *ds = (char *)ctx->ws2, *dp = ds + ((n * 32 + 255) & ~(size_t)255);
+  if (hipMemcpyAsync(ds, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(ctx, BPPP_ERR_HIP, "msm: scalar upload failed");
+  PointUpload up{ctx, dp, points_xy, n * 64};
+  ctx->pre_acc = upload_points_now; ctx->pre_acc_arg = &up;
+  int rc = msm_run(ctx, ds, dp, n, 1, 1, 0, out_xy);
+  ctx->pre_acc = nullptr;
   hipStreamSynchronize(ctx->stream);
-  hipFree(ds); hipFree(dp);
   return rc;
 }
 

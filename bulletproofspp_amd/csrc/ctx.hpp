@@ -17,6 +17,10 @@ struct bppp_ctx {
   // second grow-only device buffer for callers that also run an MSM (which carves `ws`)
   void *ws2 = nullptr;
   size_t ws2_bytes = 0;
+  // one-shot hook run by msm_run right before the accumulate kernel (the first consumer of the points): bppp_msm uploads the
+  // points there, so the 64 B/pair host copy overlaps the digit and sort kernels that need only the scalars
+  int (*pre_acc)(void *) = nullptr;
+  void *pre_acc_arg = nullptr;
   // pinned host staging for small results
   void *pinned = nullptr;
   size_t pinned_bytes = 0;

@@ -559,6 +559,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * XYZZ_WORDS * 4, st));
     BPPP_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     prof_mark(ctx, 2);
+    if (ctx->pre_acc) { auto f = ctx->pre_acc; ctx->pre_acc = nullptr; int rc_ = f(ctx->pre_acc_arg); if (rc_) return rc_; }
     // 3. accumulate
     k_acc_points<<<dim3((unsigned)((p.G + 255) / 256)), dim3(256), 0, st>>>(sorted, start + p.FB, (const uint32_t *)d_points, (uint32_t)n,
                                                                            (uint32_t)(p.W * p.M), shared_points, p.L, p.G, buckets, rec_pt);
