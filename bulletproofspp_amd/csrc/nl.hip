@@ -198,7 +198,7 @@ int bppp_nl_round_collapse(bppp_nl *nl, const uint64_t e_[4]) {
   nl->s = madd(nl->s, madd(mmul(e, nl->sX, M), mmul(e1, nl->sR, M), M), M);
   NL_HIP(nl, hipMemsetAsync(nl->P[d], 0, nl->cap * 64, st));
   uint64_t u[4], v[4];
-  // the basis folds of both sub-arguments go out as ONE launch (their 129-row chains then run side by side)
+  // the basis folds of both sub-arguments go out as ONE launch (their 130-row dependency chains then run side by side)
   std::pair<SInt, SInt> abn, abl;
   const uint64_t *bm[2], *am[2]; int bn[2], an[2]; const void *src[2]; void *dst[2]; size_t cnt[2]; int nseg = 0;
   if (nl->n) {   // Norm.collapse (NormArgument.hs:123-129)

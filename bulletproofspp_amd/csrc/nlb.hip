@@ -2,7 +2,7 @@
 //
 // Same functions as nl.hip (proveRoundM, src/Bulletproof.hs:346-355; makeScalarsComs, src/Bulletproof/NormArgument.hs:113-118,
 // :56-59; collapse :123-129, :64-71) applied to `batch` independent proofs of one shape at once.  One proof's round is far
-// too small to fill 256 CUs (its MSMs have < 800 terms and its 129-row basis fold is a ~1.5 ms dependency chain), so a
+// too small to fill 256 CUs (its MSMs have < 800 terms and its 130-row basis fold is a ~1 ms dependency chain), so a
 // single proof is latency-bound; B proofs share the launches: 2B round commitments are ONE batched MSM (each proof's X and R
 // share that proof's basis), B x ceil(n/2) basis folds are ONE launch with per-proof reduced scalars, and the Fr vector work
 // is one workgroup per proof.  The bases diverge after the first collapse (different challenges), so they are stored per proof.
