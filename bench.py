@@ -261,7 +261,7 @@ def prove_cpu_baseline(shape: str, reps: int = 2):
             "sample": f"{reps} arguments of the same shape, proveBPM through the oracle restatement (Straus commits, 129-row pair folds), single thread"}
 
 
-def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64", pipelines: int = 2):
+def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64", pipelines: int = 2, world: int = 1, dist=None):
     """Lockstep batch prover (bppp_nlb_*): `batch` norm-linear arguments of the examples/64by64 shape advanced round by round
     together (proveBPM, src/Bulletproof.hs:357-359).  The injected oracle is a SHA-256 stand-in over the raw 128 bytes of each
     proof's (X, R) chained with that proof's previous digest; hashing runs on the host inside the timed region (it is part of
@@ -346,15 +346,23 @@ def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64b
     torch.cuda.synchronize()
     for kk in tm:
         tm[kk] = 0.0
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         one_batch()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    if dist is not None:                       # the prover does not shard (sequential challenges): N independent replicas, max time over ranks
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     for g in ctxs[1:]:
         g.close()
-    return {"metric": "norm_linear_arguments_proved_per_sec", "value": batch * steps / dt, "unit": "proofs/s", "ms_per_batch": dt / steps * 1e3,
-            "batch": batch, "pipelines": pipelines, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
+    return {"metric": "norm_linear_arguments_proved_per_sec", "value": world * batch * steps / dt, "unit": "proofs/s", "ms_per_batch": dt / steps * 1e3,
+            "batch_per_gpu": batch, "replicas": world, "pipelines": pipelines, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
             "host_call_ms_per_batch": {kk: v / steps * 1e3 for kk, v in tm.items()},
             "note": "lockstep batch prover (bppp_nlb_*): 2*batch round commitments per round as one batched MSM, all basis folds as one launch; "
                     "host SHA-256 stand-in oracle inside the timed region; state upload + final opening download included; "
@@ -378,7 +386,7 @@ def main():
     ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--prove-pipelines", type=int, default=2, help="contexts (stream + host thread) the prover batch is split over")
-    ap.add_argument("--prove-batch", type=int, default=2048, help="proofs advanced in lockstep in the prover leg (0 = skip; N = 1 only)")
+    ap.add_argument("--prove-batch", type=int, default=2048, help="proofs advanced in lockstep per GPU in the prover leg (0 = skip); N > 1 runs N independent replicas")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -517,9 +525,9 @@ def main():
                                                vsteps, 1, "128by64+typed")]
 
     prove = None
-    if args.prove_batch > 0 and world == 1:
-        prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2, pipelines=args.prove_pipelines)
-        if not args.no_cpu_baseline:
+    if args.prove_batch > 0:
+        prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2, pipelines=args.prove_pipelines, world=world, dist=dist)
+        if world == 1 and not args.no_cpu_baseline:
             prove["cpu_baseline"] = prove_cpu_baseline("64by64")
 
     if rank == 0:
