@@ -27,6 +27,7 @@ SYMBOLS = [
     "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
+    "bppp_glv_decompose_device", "bppp_msm_glv_device",
 ]
 
 
@@ -56,6 +57,8 @@ def load_library() -> C.CDLL:
     lib.bppp_msm_device.argtypes = [vp, vp, vp, sz, i, vp]
     lib.bppp_msm_batch_device.argtypes = [vp, vp, vp, sz, sz, i, i, vp]
     lib.bppp_sum_points.argtypes = [vp, vp, sz, vp]
+    lib.bppp_glv_decompose_device.argtypes = [vp, vp, sz, vp, vp, vp]
+    lib.bppp_msm_glv_device.argtypes = [vp, vp, vp, sz, vp]
     lib.bppp_rational_reduce.argtypes = [vp, vp, C.POINTER(i), vp, C.POINTER(i)]
     lib.bppp_fold_points.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
     lib.bppp_fold_points_device.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
@@ -208,6 +211,27 @@ class Bppp:
         self._check(self.lib.bppp_msm_batch_device(self.h, _ptr(d_scalars), _ptr(d_points), n, batch, int(shared_points), window_bits, _ptr(out)),
                     "bppp_msm_batch_device")
         return [array_to_point(out[b]) for b in range(batch)]
+
+    def msm_glv_device(self, d_scalars: int, d_points: int, n: int):
+        """the MSM through the reference's endomorphism decomposition (same group element as msm_device)"""
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.bppp_msm_glv_device(self.h, _ptr(d_scalars), _ptr(d_points), n, _ptr(out)), "bppp_msm_glv_device")
+        return array_to_point(out)
+
+    def glv_decompose(self, scalars):
+        """decomposeFastPrimeEis for a list of scalars: [(a, b)] as signed Python integers"""
+        n = len(scalars)
+        d_s = self.to_device(scalars_to_array([s for s in scalars]))
+        d_a, d_b, d_g = self.alloc(max(n, 1) * 32), self.alloc(max(n, 1) * 32), self.alloc(max(n, 1) * 4 + 16)
+        try:
+            self._check(self.lib.bppp_glv_decompose_device(self.h, _ptr(d_s), n, _ptr(d_a), _ptr(d_b), _ptr(d_g)), "bppp_glv_decompose_device")
+            a, b = array_to_scalars(self.download(d_a, (n, 4))), array_to_scalars(self.download(d_b, (n, 4)))
+            g = self.download(d_g, (n,), dtype=np.uint32)
+        finally:
+            for p_ in (d_s, d_a, d_b, d_g):
+                self.free(p_)
+        assert not any(int(x) & 4 for x in g)
+        return [(-x if int(f) & 1 else x, -y if int(f) & 2 else y) for x, y, f in zip(a, b, g)]
 
     def sum_points(self, points: np.ndarray):
         """sum of a few affine points ((n, 8) uint64): the combine step after the all-gather of a sharded MSM"""

@@ -216,6 +216,16 @@ int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t
                                 const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
                                 const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
 
+/* ---- the optional endomorphism (GLV) path ---------------------------------------------------------------
+ * bppp_glv_decompose_device: decomposeFastPrimeEis (src/Data/Field/Galois/FastPrime.hs:186-205) for n canonical scalars:
+ * x = a + b*lambda (mod n), the reference's own (a, b) including its one-step rounding.  d_a_mag / d_b_mag: [n][4] magnitudes,
+ * d_signs: [n] uint32, bit 0 = a negative, bit 1 = b negative (bit 2 would flag a magnitude over 256 bits; it cannot happen).
+ * bppp_msm_glv_device: the same group element as bppp_msm_device through that decomposition — 2n half-length terms
+ * |a| * (+-P), |b| * (+-(beta x, y)) (SplitScalar / FastInnerProduct of FastPrime, src/Commitment.hs:293-306, :374-398; cmConj,
+ * src/Data/Curve/CM.hs:25-27).  Not faster at 2^20 (same number of bucket additions); provided for parity with that option. */
+int bppp_glv_decompose_device(bppp_ctx *ctx, const void *d_scalars, size_t n, void *d_a_mag, void *d_b_mag, void *d_signs);
+int bppp_msm_glv_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, uint64_t out_xy[8]);
+
 /* ---- range-proof verifier: public scalars from challenges, on the device ----------------------------------------------
  * The scalar work of verifyTRRPM (src/RangeProof/TypedReciprocal.hs:449-467) for a batch of proofs of ONE setup: makePhase2s on
  * the unit witness (:185-205), makeSharedCoeffs (:213-216), makePublicConsts (:246-274), makeBpCoeffs (:391-396) and the opening

@@ -154,3 +154,37 @@ def test_sum_points_is_the_group_sum(gpu, oracle_lib):
     bad[0, 3] = np.uint64(0xFFFFFFFFFFFFFFFF); bad[0, 2] = bad[0, 3]; bad[0, 1] = bad[0, 3]; bad[0, 0] = bad[0, 3]
     with pytest.raises(Exception):
         gpu.sum_points(bad)
+
+
+def test_glv_decomposition_is_the_references(gpu):
+    """bppp_glv_decompose_device vs the oracle's restatement of decomposeFastPrimeEis (FastPrime.hs:186-205): the SAME (a, b),
+    not just a valid pair, on edge scalars and 3000 random ones; and a + b*lambda = x (mod n), |a|, |b| < 2^129"""
+    rnd = random.Random(606)
+    edge = [0, 1, 2, O.N - 1, O.N - 2, (O.N - 1) // 2, (O.N + 1) // 2, 2**128, 2**128 - 1, 2**255, 2**255 + 12345, O.LAMBDA, O.N - O.LAMBDA, O.LAMBDA * 7 % O.N,
+            2**192, 3**160 % O.N]
+    xs = edge + [rnd.randrange(O.N) for _ in range(3000)]
+    got = gpu.glv_decompose(xs)
+    for x, (a, b) in zip(xs, got):
+        assert (a, b) == O.decompose_eis(x), x
+        assert (a + b * O.LAMBDA - x) % O.N == 0 and abs(a) < 2**129 and abs(b) < 2**129
+
+
+@pytest.mark.parametrize("n", [1, 5, 300, 4099])
+def test_msm_glv_equals_plain_msm(gpu, oracle_lib, n):
+    """the endomorphism route (2n half-length terms, lambda P = (beta x, y)) gives the group element of the plain route and of
+    the oracle; zero scalars and infinity points included"""
+    rnd = random.Random(n)
+    base = O.hash_points(b"glvdev", min(n, 128))
+    pts = [base[i % len(base)] for i in range(n)]
+    sc = [rnd.randrange(O.N) for _ in range(n)]
+    if n > 4:
+        sc[1] = 0; pts[2] = None; sc[3] = O.N - 1; sc[4] = 1
+    ds, dp = gpu.to_device(scalars_to_array(sc)), gpu.to_device(points_to_array(pts))
+    try:
+        g1 = gpu.msm_glv_device(ds, dp, n)
+        g0 = gpu.msm_device(ds, dp, n, 0)
+    finally:
+        gpu.free(ds); gpu.free(dp)
+    assert g1 == g0
+    if n <= 300:
+        assert g1 == oracle_lib.inner_product(list(zip(sc, pts)))
