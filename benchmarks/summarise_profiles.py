@@ -66,7 +66,8 @@ def main():
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py MSM leg, 2^20 pairs, auto window (c = 16)",
             "k_acc_points_FETCH_SIZE_KB_raw": fk,
             "k_acc_points_WRITE_SIZE_KB": wk,
-            "correction": "gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 (MI355X_MICROARCH.md, HBM section)",
+            "correction": "gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 (MI355X_MICROARCH.md, HBM section); the accumulate kernel's point gathers are "
+                          "64-B requests, for which the x2 may overstate (raw: 17.8 M entries x ~82 B)",
             "k_acc_points_bytes_per_launch": fk * 1024 * 2 + wk * 1024,
             "bytes_per_launch_by_kernel": per_kernel,
         }
