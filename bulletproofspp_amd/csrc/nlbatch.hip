@@ -64,72 +64,63 @@ __global__ void __launch_bounds__(256) k_vb_shared1(const uint32_t *__restrict__
   }
   fe_store(partial + ((size_t)kt * len + i) * 8, acc);
 }
-// Same sums with 8 consecutive basis positions i0..i0+7 per lane (k >= 3): they share the tensor factors of rounds >= 3,
-// so the lane multiplies those once and expands the three low rounds by doubling in registers (2.4 multiplications per
-// output instead of k); rho is folded into the base value.
-#define VB_LVL(R, N)                                                   \
-  {                                                                    \
-    fe eq = fe_load(f + (size_t)(k + (R)) * 8), qq = fe_load(f + (size_t)(R) * 8); \
-    _Pragma("unroll") for (int j = 0; j < (N); j++) {                  \
-      t[j + (N)] = frm(eq, t[j]);                                      \
-      if (use_q) t[j] = frm(qq, t[j]);                                 \
-    }                                                                  \
-  }
-__global__ void __launch_bounds__(64) k_vb_shared8(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
+// Same sums with 4 consecutive basis positions i0..i0+3 per lane (k >= 2): they share the tensor factors of rounds >= 2, so the
+// lane multiplies those once and expands the two low rounds in registers; rho is folded into the base value.  (8 positions per
+// lane halved the multiplications again but left one wavefront per SIMD: 160 us per launch here against 240 us.)
+__global__ void __launch_bounds__(64) k_vb_shared4(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
                                                    uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
                                                    uint32_t *__restrict__ partial) {
-  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8, kt = blockIdx.y;
+  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, kt = blockIdx.y;
   if (i0 >= len) return;
-  fe acc[8];
-#pragma unroll
-  for (int o = 0; o < 8; o++) acc[o] = fe_zero();
+  fe a0 = fe_zero(), a1 = a0, a2 = a0, a3 = a0;          // named scalars, not arrays: arrays of fe end up in scratch here
   uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
   for (uint32_t b = b0; b < b1; b++) {
     const uint32_t *f = fac + (size_t)b * 2 * k * 8;
     const fe r = fe_load(rho + (size_t)b * 8);
-    fe t[8];
+    fe t0 = fe_zero(), t1 = t0, t2 = t0, t3 = t0;
     uint32_t hi = i0 >> k;
-    bool live = hi < nvs;                                  // zipWithDef' default 0 beyond the tensor (src/Utils.hs:182-184)
-#pragma unroll
-    for (int o = 0; o < 8; o++) t[o] = fe_zero();
-    if (live) {
+    if (hi < nvs) {                                        // zipWithDef' default 0 beyond the tensor (src/Utils.hs:182-184)
       fe base = frm(r, fe_load(wit + ((size_t)b * nvs + hi) * 8));
-      for (int rr = 3; rr < k; rr++) {
+      for (int rr = 2; rr < k; rr++) {
         bool bit = (i0 >> rr) & 1u;
         if (bit) base = frm(base, fe_load(f + (size_t)(k + rr) * 8));
         else if (use_q) base = frm(base, fe_load(f + (size_t)rr * 8));
       }
-      t[0] = base;
-      VB_LVL(0, 1)
-      VB_LVL(1, 2)
-      VB_LVL(2, 4)
+      t0 = base;
+      { fe eq = fe_load(f + (size_t)(k + 0) * 8), qq = fe_load(f);
+        t1 = frm(eq, t0); if (use_q) t0 = frm(qq, t0); }
+      { fe eq = fe_load(f + (size_t)(k + 1) * 8), qq = fe_load(f + 8);
+        t2 = frm(eq, t0); t3 = frm(eq, t1); if (use_q) { t0 = frm(qq, t0); t1 = frm(qq, t1); } }
     }
-#pragma unroll
-    for (int o = 0; o < 8; o++) {
-      if (i0 + o < len) {
-        fe d = frm(r, fe_load(pub + ((size_t)b * len + i0 + o) * 8));
-        acc[o] = fe_add<1>(acc[o], fe_sub<1>(d, t[o]));
-      }
-    }
+    const uint32_t *pb = pub + ((size_t)b * len + i0) * 8;
+#define VB_ACC(O, A, T) if (i0 + (O) < len) A = fe_add<1>(A, fe_sub<1>(frm(r, fe_load(pb + (O) * 8)), T));
+    VB_ACC(0, a0, t0) VB_ACC(1, a1, t1) VB_ACC(2, a2, t2) VB_ACC(3, a3, t3)
+#undef VB_ACC
   }
-#pragma unroll
-  for (int o = 0; o < 8; o++)
-    if (i0 + o < len) fe_store(partial + ((size_t)kt * len + i0 + o) * 8, acc[o]);
+  uint32_t *po = partial + ((size_t)kt * len + i0) * 8;
+#define VB_ST(O, A) if (i0 + (O) < len) fe_store(po + (O) * 8, A);
+  VB_ST(0, a0) VB_ST(1, a1) VB_ST(2, a2) VB_ST(3, a3)
+#undef VB_ST
 }
 
-// column sums of partial[ntiles][len]: blockIdx.y strides over the tiles, the 4 wavefronts of a block take every 4th tile
-__global__ void __launch_bounds__(256) k_vb_sum_partials(const uint32_t *__restrict__ partial, uint32_t ntiles, uint32_t len, uint32_t *__restrict__ out) {
+// column sums of partial[ntiles][len]: block (x, y) adds the tiles [y*per, (y+1)*per) of 64 columns (its 4 wavefronts take
+// every 4th tile) into out[y][len].  Called twice: ntiles -> SUM_GROUPS rows -> 1 row; a single pass over all tiles had only
+// len/64 workgroups walking 1024 dependent loads each (100-150 us for 17 MB).
+static constexpr uint32_t SUM_GROUPS = 32;
+__global__ void __launch_bounds__(256) k_vb_sum_partials(const uint32_t *__restrict__ partial, uint32_t ntiles, uint32_t per, uint32_t len,
+                                                         uint32_t *__restrict__ out) {
   __shared__ uint32_t lds[256 * 8];
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t i = blockIdx.x * 64 + lane;
+  const uint32_t t0 = blockIdx.y * per, t1 = min(ntiles, t0 + per);
   fe acc = fe_zero();
   if (i < len)
-    for (uint32_t t = wv; t < ntiles; t += 4) acc = fe_add<1>(acc, fe_load(partial + ((size_t)t * len + i) * 8));
+    for (uint32_t t = t0 + wv; t < t1; t += 4) acc = fe_add<1>(acc, fe_load(partial + ((size_t)t * len + i) * 8));
   for (int q = 0; q < 8; q++) lds[threadIdx.x * 8 + q] = acc.v[q];
   __syncthreads();
   if (wv == 0 && i < len) {
     for (int w = 1; w < 4; w++) { fe o; for (int q = 0; q < 8; q++) o.v[q] = lds[(w * 64 + lane) * 8 + q]; acc = fe_add<1>(acc, o); }
-    fe_store(out + (size_t)i * 8, acc);
+    fe_store(out + ((size_t)blockIdx.y * len + i) * 8, acc);
   }
 }
 
@@ -223,23 +214,27 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
   const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
   const size_t maxlen = nlen > llen ? nlen : llen;
   // scratch (separate from the MSM workspace, which msm_run carves from ctx->ws)
-  size_t words = (batch * 2 * (k ? k : 1) + batch + (size_t)ntiles * maxlen + batch + T + 64) * 8 + T * 16;
+  size_t words = (batch * 2 * (k ? k : 1) + batch + (size_t)ntiles * maxlen + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16;
   { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
   uint32_t *buf = (uint32_t *)ctx->ws2;
-  uint32_t *fac = buf, *qf2 = fac + batch * 2 * (k ? k : 1) * 8, *partial = qf2 + batch * 8, *gs = partial + (size_t)ntiles * maxlen * 8,
+  uint32_t *fac = buf, *qf2 = fac + batch * 2 * (k ? k : 1) * 8, *partial = qf2 + batch * 8, *partial2 = partial + (size_t)ntiles * maxlen * 8, *gs = partial2 + (size_t)SUM_GROUPS * maxlen * 8,
            *sc = gs + batch * 8, *pts = sc + (T + 32) * 8;
   int rc = BPPP_OK;
   do {
     k_vb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_q, (const uint32_t *)d_es, (uint32_t)batch, (int)k, fac, qf2);
     if (nlen) {
-      if (k >= 3) k_vb_shared8<<<dim3((unsigned)((nlen + 511) / 512), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
+      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
       else k_vb_shared1<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
-      k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)nlen, sc);
+      { const uint32_t per = (ntiles + SUM_GROUPS - 1) / SUM_GROUPS, groups = (ntiles + per - 1) / per;
+        k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, per, (uint32_t)nlen, partial2);
+        k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)nlen, sc); }
     }
     if (llen) {
-      if (k >= 3) k_vb_shared8<<<dim3((unsigned)((llen + 511) / 512), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
       else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
-      k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64)), dim3(256), 0, st>>>(partial, ntiles, (uint32_t)llen, sc + nlen * 8);
+      { const uint32_t per = (ntiles + SUM_GROUPS - 1) / SUM_GROUPS, groups = (ntiles + per - 1) / per;
+        k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, per, (uint32_t)llen, partial2);
+        k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)llen, sc + nlen * 8); }
     }
     k_vb_proof<<<dim3((unsigned)batch), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf2, (const uint32_t *)d_wit_norm, (uint32_t)fn,
                                                             (const uint32_t *)d_wit_lin, (uint32_t)fl, (const uint32_t *)d_pub_lin_c, (uint32_t)llen, fac, (int)k,
