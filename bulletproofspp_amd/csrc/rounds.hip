@@ -10,6 +10,7 @@
 // (src/Bulletproof.hs:77-90).  All values are canonical integers mod n.
 #include "ctx.hpp"
 #include "fe.cuh"
+#include "modinv.cuh"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -133,7 +134,7 @@ template <int MOD> __global__ void __launch_bounds__(64) k_batch_inverse(const u
     pre[k] = acc;
     if (!fe_is_zero(v[k])) acc = fe_mul<MOD>(acc, v[k]);          // rec0 skips zeros (BatchInverse.hs:18)
   }
-  fe y = fe_inv<MOD>(acc);
+  fe y = fe_modinv<MOD>(acc);      // division steps (modinv.cuh): every lane inverts here, and their stream is input-independent
 #pragma unroll
   for (int k = BI_RUN - 1; k >= 0; k--) {
     fe r = fe_zero();

@@ -3,6 +3,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "ec.cuh"
+#include "modinv.cuh"
 
 namespace bppp {
 template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
@@ -13,6 +14,7 @@ template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
     case BPPP_FE_SQR: return fe_sqr<MOD>(a);
     case BPPP_FE_INV: return fe_inv<MOD>(a);
     case 7: return fe_inv_vartime<MOD>(a);       // binary extended Euclid (fe.cuh)
+    case 8: return fe_modinv<MOD>(a);            // safegcd division steps (modinv.cuh)
     default: return fe_neg<MOD>(a);
   }
 }
@@ -24,7 +26,8 @@ BPPP_DI fe apply_op_fq(int op, const fe &a, const fe &b) {
     case BPPP_FE_SUB: return fq_to_fe(fq_sub<1>(x, y));
     case BPPP_FE_MUL: return fq_to_fe(fq_mul(x, y));
     case BPPP_FE_SQR: return fq_to_fe(fq_sqr(x));
-    case BPPP_FE_INV: return fq_to_fe(fq_inv(x));
+    case BPPP_FE_INV: return fq_to_fe(fq_inv(x));            // production: safegcd
+    case 9: return fq_to_fe(fq_inv_fermat(x));               // the addition chain, kept as a cross-check
     default: return fq_to_fe(fq_neg<1>(x));
   }
 }

@@ -13,6 +13,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "fe.cuh"
+#include "modinv.cuh"
 #include "../../include/bppp.h"
 
 namespace bppp {
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   fe others = frm(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < 64 ? lds_get(sb, t + 1) : fe_one());
   fe total = lds_get(sa, 63);
   __syncthreads();
-  if (t == 0) lds_put(sa, 0, fe_inv_vartime<1>(total));   // one active lane: the cheap variable-time inverse
+  if (t == 0) lds_put(sa, 0, fe_modinv<1>(total));        // one active lane: division steps (~14 k instructions)
   __syncthreads();
   {
     fe suf = frm(lds_get(sa, 0), others);  // 1 / (product of this lane's own elements), then times the ones already passed

@@ -10,7 +10,7 @@ from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_
 
 pytestmark = pytest.mark.gpu
 
-OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5, "mag8mul": 6, "inv_vartime": 7}
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5, "mag8mul": 6, "inv_vartime": 7, "inv_safegcd": 8, "inv_fermat": 9}
 # modulus selector of bppp_test_fe_op: 0 = Fq via the production 10x26 limbs, 1 = Fr (8x32), 2 = Fq via the 8x32 code path
 
 
@@ -42,8 +42,12 @@ def test_field_ops_match_python(gpu, mod, m):
     assert _fe_op(gpu, "neg", mod, a, b) == [(-x) % m for x in a]
     small = a[:300]
     assert _fe_op(gpu, "inv", mod, small, small) == [O.inv_mod(x, m) for x in small]
-    if mod:          # the binary-Euclid inverse (8 x 32 code path only): every edge value and 1000 random ones
+    if mod:          # the binary-Euclid and the division-step inverses (8 x 32 code path): every edge value and 1000 random ones
         assert _fe_op(gpu, "inv_vartime", mod, a[:1000], a[:1000]) == [O.inv_mod(x, m) for x in a[:1000]]
+        assert _fe_op(gpu, "inv_safegcd", mod, a[:1500], a[:1500]) == [O.inv_mod(x, m) for x in a[:1500]]
+    else:            # Fq production path: fq_inv is the division-step inverse; the addition chain must agree with it
+        assert _fe_op(gpu, "inv", mod, a[:1500], a[:1500]) == [O.inv_mod(x, m) for x in a[:1500]]
+        assert _fe_op(gpu, "inv_fermat", mod, small, small) == [O.inv_mod(x, m) for x in small]
 
 
 def test_fq26_worst_case_magnitudes(gpu):
