@@ -51,9 +51,8 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
                                                     uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
   extern __shared__ uint32_t lds[];
   const uint32_t t = threadIdx.x, b = blockIdx.x, m = 2 + D.nsyms;
-  uint32_t *inv = lds;                         // [m] the inverted list: e, q0, e + sym_k
-  uint32_t *pre = inv + (size_t)m * 8;         // [m] products of a lane's own elements before each one
-  uint32_t *sa = pre + (size_t)m * 8;          // [64] scan scratch A
+  uint32_t *inv = lds;                         // [m] the inverted list: e, q0, e + sym_k (holds the lanes' running products first)
+  uint32_t *sa = inv + (size_t)m * 8;          // [64] scan scratch A
   uint32_t *sb = sa + 64 * 8;                  // [64] scan scratch B
   uint32_t *x2 = sb + 64 * 8;                  // [nr]  x^(2(j+1))
   uint32_t *sl = x2 + (size_t)D.nr * 8;        // [3][TRRP_MAX_SLOTS] per base slot: t^2 v, 2 t^5 v / e, 2 t^3 v   (v = x^(3+2 slot))
@@ -67,8 +66,7 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   fe local = fe_one();
   for (uint32_t i = lo; i < hi; i++) {
     fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));
-    lds_put(inv, i, a);
-    lds_put(pre, i, local);
+    lds_put(inv, i, local);                      // product of this lane's elements before element i
     if (!fe_is_zero(a)) local = frm(local, a);
   }
   lds_put(sa, t, local); lds_put(sb, t, local);
@@ -89,9 +87,9 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   {
     fe suf = frm(lds_get(sa, 0), others);  // 1 / (product of this lane's own elements), then times the ones already passed
     for (uint32_t i = hi; i-- > lo;) {
-      fe a = lds_get(inv, i);
-      if (fe_is_zero(a)) continue;               // stays 0
-      lds_put(inv, i, frm(suf, lds_get(pre, i)));
+      fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));   // recomputed: one LDS array instead of two
+      if (fe_is_zero(a)) { lds_put(inv, i, fe_zero()); continue; }
+      lds_put(inv, i, frm(suf, lds_get(inv, i)));
       suf = frm(suf, a);
     }
   }
@@ -248,7 +246,7 @@ int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges
   if (!batch) return BPPP_OK;
   if (!d_challenges || !d_q || !d_sp || !d_pub_norm || !d_pub_lin_c || !d_init_scalars || batch >= (1u << 24)) return fail(ctx, BPPP_ERR_ARG, "trrp_public: bad arguments");
   hipSetDevice(ctx->device);
-  const size_t lds = ((size_t)2 * (2 + o->D.nsyms) + 128 + o->D.nr + 3 * TRRP_MAX_SLOTS) * 32;
+  const size_t lds = ((size_t)(2 + o->D.nsyms) + 128 + o->D.nr + 3 * TRRP_MAX_SLOTS) * 32;
   if (lds > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "trrp_public: too many ranges for one workgroup's LDS");
   if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_trrp_public, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_trrp_public<<<dim3((unsigned)batch), dim3(64), lds, ctx->stream>>>(o->D, o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min,
