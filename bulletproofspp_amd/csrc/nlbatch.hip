@@ -19,7 +19,7 @@
 namespace bppp {
 int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
 
-static constexpr int KT = 4;    // proofs per partial sum
+static constexpr int KT = 2;    // proofs per partial sum (more, shorter wavefronts: these kernels are latency-bound)
 BPPP_DI fe frm(const fe &a, const fe &b) { return fe_mul<1>(a, b); }
 
 // factor table per proof: fac[b][r] = q_b^(2^r) (r < k), fac[b][k + r] = e_{b, first-round-first r}, and qF2 = (q^(2^k))^2
