@@ -78,23 +78,26 @@ __global__ void __launch_bounds__(64) k_vb_shared4(const uint32_t *__restrict__ 
     const uint32_t *f = fac + (size_t)b * 2 * k * 8;
     const fe r = fe_load(rho + (size_t)b * 8);
     fe t0 = fe_zero(), t1 = t0, t2 = t0, t3 = t0;
+    const uint32_t *pb = pub + ((size_t)b * len + i0) * 8;
+    const fe p0 = fe_load(pb), p1 = i0 + 1 < len ? fe_load(pb + 8) : fe_zero(), p2 = i0 + 2 < len ? fe_load(pb + 16) : fe_zero(),
+             p3 = i0 + 3 < len ? fe_load(pb + 24) : fe_zero();
     uint32_t hi = i0 >> k;
     if (hi < nvs) {                                        // zipWithDef' default 0 beyond the tensor (src/Utils.hs:182-184)
-      fe base = frm(r, fe_load(wit + ((size_t)b * nvs + hi) * 8));
+      // every load of this proof is issued before the first multiplication (the factor of round rr is e or q by the bit of i0:
+      // the address is computed, not branched on), so the wavefront waits for memory once per proof instead of once per factor
+      const fe w0 = fe_load(wit + ((size_t)b * nvs + hi) * 8);
+      const fe e0 = fe_load(f + (size_t)k * 8), q0 = fe_load(f), e1 = fe_load(f + (size_t)(k + 1) * 8), q1 = fe_load(f + 8);
+      fe base = frm(r, w0);
       for (int rr = 2; rr < k; rr++) {
-        bool bit = (i0 >> rr) & 1u;
-        if (bit) base = frm(base, fe_load(f + (size_t)(k + rr) * 8));
-        else if (use_q) base = frm(base, fe_load(f + (size_t)rr * 8));
+        const bool bit = (i0 >> rr) & 1u;
+        if (bit || use_q) base = frm(base, fe_load(f + (size_t)((bit ? k : 0) + rr) * 8));
       }
       t0 = base;
-      { fe eq = fe_load(f + (size_t)(k + 0) * 8), qq = fe_load(f);
-        t1 = frm(eq, t0); if (use_q) t0 = frm(qq, t0); }
-      { fe eq = fe_load(f + (size_t)(k + 1) * 8), qq = fe_load(f + 8);
-        t2 = frm(eq, t0); t3 = frm(eq, t1); if (use_q) { t0 = frm(qq, t0); t1 = frm(qq, t1); } }
+      t1 = frm(e0, t0); if (use_q) t0 = frm(q0, t0);
+      t2 = frm(e1, t0); t3 = frm(e1, t1); if (use_q) { t0 = frm(q1, t0); t1 = frm(q1, t1); }
     }
-    const uint32_t *pb = pub + ((size_t)b * len + i0) * 8;
-#define VB_ACC(O, A, T) if (i0 + (O) < len) A = fe_add<1>(A, fe_sub<1>(frm(r, fe_load(pb + (O) * 8)), T));
-    VB_ACC(0, a0, t0) VB_ACC(1, a1, t1) VB_ACC(2, a2, t2) VB_ACC(3, a3, t3)
+#define VB_ACC(O, A, P, T) if (i0 + (O) < len) A = fe_add<1>(A, fe_sub<1>(frm(r, P), T));
+    VB_ACC(0, a0, p0, t0) VB_ACC(1, a1, p1, t1) VB_ACC(2, a2, p2, t2) VB_ACC(3, a3, p3, t3)
 #undef VB_ACC
   }
   uint32_t *po = partial + ((size_t)kt * len + i0) * 8;
