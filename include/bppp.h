@@ -168,7 +168,7 @@ int bppp_nl_verify_challenges(bppp_oracle_fn oracle, void *user, const uint64_t 
 
 /* ---- lockstep batch prover: `batch` norm-linear arguments of one shape advance round by round together ----------------
  * Same functions as bppp_nl_* (proveRoundM, src/Bulletproof.hs:346-355) with a leading batch dimension on every array:
- * one proof cannot fill the chip (its MSMs have < 800 terms, its basis fold is one ~1.5 ms dependency chain), B proofs
+ * one proof cannot fill the chip (its MSMs have < 800 terms, its basis fold is one ~1 ms dependency chain), B proofs
  * share every launch.  The starting basis (g, G, H) is shared; q, s and the vectors are per proof ([batch][...]). */
 typedef struct bppp_nlb bppp_nlb;
 int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
