@@ -195,8 +195,11 @@ class Ph2:
 def make_phase2s(e: int, e_inv: int, x: int, base_map: Dict[int, int], ph1s, private: bool) -> List[Ph2]:
     """makePhase2s (TypedReciprocal.hs:185-205).  private=False is the verifier's `b ~ ()` instantiation."""
     dens, ss, ps, vs, rec = [], [], [], [], []
+    xpow: Dict[int, int] = {}
     for p in ph1s:
-        xi = pow(x, 2 * (p[1] + 1), N)
+        xi = xpow.get(p[1])
+        if xi is None:
+            xi = xpow[p[1]] = pow(x, 2 * (p[1] + 1), N)
         if p[0] == "typing":
             _, _, io, ia, v, t = p
             x2 = (-x) % N if io else x % N
@@ -260,21 +263,21 @@ def make_bp_coeffs(has_types: bool, xp: int, r0: int, r1: int, t: int, cs: Seque
 def make_public_consts(e: int, e_inv: int, x: int, xp: int, q0: int, q0_inv: int, t: int, has_types: bool, rds: Sequence[RangeData],
                        pub_vt: Sequence[Tuple[bool, int, int]], ph2s: Sequence[Ph2]) -> RPW:
     """makePublicConsts (TypedReciprocal.hs:246-274); pub_vt entries are (isOutput, type, amount) as destructured at :258."""
-    tp = lambda k: pow(t, k, N)
+    t2, t3, t4, t5 = (pow(t, k, N) for k in (2, 3, 4, 5))
     mins = [0 if rd.is_assumed else rd.lo % N for rd in rds]
     pub_rs = batch_inverse([(e + ty) % N for _, ty, _ in pub_vt])
     pub_sum = sum(((-r * v) if is_out else (r * v)) for (is_out, _, v), r in zip(pub_vt, pub_rs)) % N
-    z = -2 * tp(5) * sum(a * b for a, b in zip(mins, powers1(x * x % N, len(mins))))
+    z = -2 * t5 * sum(a * b for a, b in zip(mins, powers1(x * x % N, len(mins))))
     if has_types:
-        z -= 2 * tp(5) * x * pub_sum
+        z -= 2 * t5 * x * pub_sum
     ts0, ts1 = [], []
     for p, q2, qi2 in zip(ph2s, powers1(q0, len(ph2s)), powers1(q0_inv, len(ph2s))):
         if p.is_t:
             rC, p2C = xp * (qi2 * p.u + 1) % N, 0
         else:
             rC, p2C = qi2 * p.u % N, (2 * q2 + 2 * e_inv * p.v) % N
-        pv = (tp(2) * (e + qi2 * p.v) + tp(3) * rC + tp(4) * (qi2 * p.c)) % N
-        ts0.append((q2 * pv * pv + tp(5) * p2C) % N)
+        pv = (t2 * (e + qi2 * p.v) + t3 * rC + t4 * (qi2 * p.c)) % N
+        ts0.append((q2 * pv * pv + t5 * p2C) % N)
         ts1.append(pv)
     return RPW((z + sum(ts0)) % N, [], ts1)
 
