@@ -188,3 +188,27 @@ def test_msm_glv_equals_plain_msm(gpu, oracle_lib, n):
     assert g1 == g0
     if n <= 300:
         assert g1 == oracle_lib.inner_product(list(zip(sc, pts)))
+
+
+def test_new_entry_points_reject_bad_arguments(gpu):
+    """argument validation of the later entry points: errors come back as status codes with a message, nothing is launched"""
+    import ctypes as C
+    lib = gpu.lib
+    out = np.zeros(8, dtype=np.uint64)
+    assert lib.bppp_sum_points(gpu.h, None, 3, out.ctypes.data) != 0
+    assert lib.bppp_sum_points(gpu.h, out.ctypes.data, 1 << 20, out.ctypes.data) != 0
+    assert b"sum_points" in lib.bppp_last_error(gpu.h)
+    assert lib.bppp_msm_glv_device(gpu.h, None, None, 5, out.ctypes.data) != 0
+    assert lib.bppp_glv_decompose_device(gpu.h, None, 5, None, None, None) != 0
+    assert lib.bppp_msm_glv_device(gpu.h, None, None, 0, out.ctypes.data) == 0 and not out.any()      # empty MSM: infinity
+    h = C.c_void_p()
+    u32 = lambda xs: np.array(xs, dtype=np.uint32)
+    kind, rng_, slot, sym = u32([2, 2]), u32([0, 5]), u32([0, 0]), u32([0xFFFFFFFF, 0xFFFFFFFF])      # range index 5 of 1 range
+    coeff, mins, assumed = np.zeros((2, 4), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64), u32([0])
+    rc = lib.bppp_trrp_create(gpu.h, 0, 0, 2, 6, 1, kind.ctypes.data, rng_.ctypes.data, slot.ctypes.data, sym.ctypes.data, coeff.ctypes.data,
+                              mins.ctypes.data, assumed.ctypes.data, 0, None, None, None, 0, None, None, None, C.byref(h))
+    assert rc != 0 and b"out of range" in lib.bppp_last_error(gpu.h)
+    rc = lib.bppp_trrp_create(gpu.h, 0, 0, 2, 3, 1, kind.ctypes.data, rng_.ctypes.data, slot.ctypes.data, sym.ctypes.data, coeff.ctypes.data,
+                              mins.ctypes.data, assumed.ctypes.data, 0, None, None, None, 0, None, None, None, C.byref(h))
+    assert rc != 0                                                                                      # llen < 6
+    assert lib.bppp_trrp_public_device(None, 1, None, None, None, None, None, None) != 0
