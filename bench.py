@@ -561,9 +561,9 @@ def main():
         # measured rate of a multiply-only kernel on this chip (test hook bppp_test_mulmod_rate)
         try:
             import ctypes as C
+            from bulletproofspp_amd.capi import load_test_library
             rate = C.c_double(0.0)
-            gpu.lib.bppp_test_mulmod_rate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-            if gpu.lib.bppp_test_mulmod_rate(gpu.h, 2000, C.byref(rate)) == 0 and rate.value > 0 and acc_ms > 0:
+            if load_test_library().bppp_test_mulmod_rate(gpu.h, 2000, C.byref(rate)) == 0 and rate.value > 0 and acc_ms > 0:
                 c_eff = args.window or 16
                 full, r = 254 // c_eff, 255 - c_eff * (254 // c_eff)
                 adds = n * (full + 1 + (0.5 if r == c_eff else 0.0))

@@ -1,6 +1,8 @@
 """Build recipe for the in-tree native libraries (hipcc cross-compiles gfx950 without a GPU).
 
-  libbppp_hip.so   the product: HIP kernels + C ABI (include/bppp.h)
+  libbppp_hip.so        the product: HIP kernels + C ABI (include/bppp.h)
+  libbppp_hip_test.so   test-only hooks (include/bppp_test.h): device field / group primitives for the parity tests and the
+                        multiply-rate microbenchmark bench.py quotes; NOT linked into the product library
 """
 from __future__ import annotations
 
@@ -12,7 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
-HIP_SOURCES = ["msm.hip", "fold.hip", "rounds.hip", "nl.hip", "nlb.hip", "nlbatch.hip", "ip.hip", "trrp.hip", "glv.hip", "capi.hip", "testhooks.hip"]
+HIP_SOURCES = ["msm.hip", "fold.hip", "rounds.hip", "nl.hip", "nlb.hip", "nlbatch.hip", "ip.hip", "trrp.hip", "glv.hip", "capi.hip"]
+TEST_SOURCES = ["testhooks.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -26,10 +29,10 @@ def _newer(target: str, deps) -> bool:
 
 def build_hip(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(LIB, "obj"), exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp"))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
     headers.append(os.path.join(HERE, "..", "include", "bppp.h"))
     jobs = []
-    for src in HIP_SOURCES:
+    for src in HIP_SOURCES + TEST_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIB, "obj", src.replace(".hip", ".o"))
         if force or _newer(o, [s] + headers):
@@ -48,6 +51,13 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     objs = [os.path.join(LIB, "obj", s.replace(".hip", ".o")) for s in HIP_SOURCES]
     if force or jobs or _newer(out, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    tout = os.path.join(LIB, "libbppp_hip_test.so")
+    tobjs = [os.path.join(LIB, "obj", s.replace(".hip", ".o")) for s in TEST_SOURCES]
+    if force or jobs or _newer(tout, tobjs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tout] + tobjs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -34,6 +34,7 @@ class NormLinearBP:
                                     _ptr(points_to_array(pad(lgs, llen, None))), llen, C.byref(h))
         gpu._check(rc, "bppp_nl_create")
         self.h = h
+        gpu._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -201,6 +202,7 @@ class NormLinearIP:
                                     _ptr(points_to_array(pad(lgs, llen, None))) if llen else None, llen, C.byref(h))
         gpu._check(rc, "bppp_ip_create")
         self.h = h
+        gpu._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -266,6 +268,7 @@ class NormLinearBatch:
                                      _ptr(cat(cs, llen)), _ptr(cat(lss, llen)), _ptr(points_to_array(lgs)) if llen else None, llen, C.byref(h))
         gpu._check(rc, "bppp_nlb_create")
         self.h = h
+        gpu._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):

@@ -110,6 +110,20 @@ def load_library() -> C.CDLL:
     return lib
 
 
+def load_test_library() -> C.CDLL:
+    """libbppp_hip_test.so: the bppp_test_* hooks of include/bppp_test.h (parity tests, bench.py's multiply-rate probe).
+    They take the product library's context handle; nothing in the product depends on them."""
+    p = os.path.join(_HERE, "lib", "libbppp_hip_test.so")
+    if not os.path.exists(p):
+        raise BpppError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(p)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    lib.bppp_test_fe_op.argtypes = [vp, i, i, vp, vp, sz, vp]
+    lib.bppp_test_point_op.argtypes = [vp, i, vp, vp, sz, vp]
+    lib.bppp_test_mulmod_rate.argtypes = [vp, i, C.POINTER(C.c_double)]
+    return lib
+
+
 # ---- integer <-> limb helpers (host-side glue for tests / bench)
 def int_to_limbs(x: int, n: int = 4) -> np.ndarray:
     return np.array([(x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(n)], dtype=np.uint64)
@@ -173,11 +187,23 @@ class Bppp:
             raise BpppError(f"bppp_ctx_create(device={device}) failed with {rc} "
                             "(-3 = no GPU visible; this library has no CPU path)")
         self.h = h
+        import weakref
+        self._children = weakref.WeakSet()      # child handles (NormLinearBP, ...): closed before the context
         if stream is not None:
             self.set_stream(stream)
 
+    def _adopt(self, child):
+        self._children.add(child)
+
     def close(self):
+        """Closes the child handles first, then the context.  (The C ABI is safe in either order — a child keeps its context
+        alive until it is destroyed itself — this just releases the device memory promptly.)"""
         if getattr(self, "h", None):
+            for ch in list(getattr(self, "_children", ())):
+                try:
+                    ch.close()
+                except Exception:
+                    pass
             self.lib.bppp_ctx_destroy(self.h)
             self.h = None
 

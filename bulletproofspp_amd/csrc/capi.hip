@@ -16,6 +16,18 @@ int tensor_run(bppp_ctx *, const uint64_t *, size_t, const uint64_t *, const uin
 int lift_x_run(bppp_ctx *, const void *, size_t, void *);
 int batch_inverse_run(bppp_ctx *, const void *, size_t, int, void *);
 
+void ctx_retain(bppp_ctx *ctx) { ctx->refs.fetch_add(1); }
+void ctx_release(bppp_ctx *ctx) {
+  if (ctx->refs.fetch_sub(1) != 1) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->ws2) hipFree(ctx->ws2);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->ev_ready) for (int i = 0; i <= BPPP_NUM_STAGES; i++) hipEventDestroy(ctx->ev[i]);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
 int ensure_workspace(bppp_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return BPPP_OK;
   BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -87,14 +99,12 @@ int bppp_ctx_create(int device, bppp_ctx **out) {
 }
 void bppp_ctx_destroy(bppp_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->closed.exchange(true)) return;      // a second destroy of the same handle is ignored while children keep it alive
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  if (ctx->ws) hipFree(ctx->ws);
-  if (ctx->ws2) hipFree(ctx->ws2);
-  if (ctx->pinned) hipHostFree(ctx->pinned);
-  if (ctx->ev_ready) for (int i = 0; i <= BPPP_NUM_STAGES; i++) hipEventDestroy(ctx->ev[i]);
-  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
-  delete ctx;
+  // a caller-bound stream may not outlive this call: fall back to the context's own for whatever the children still do
+  ctx->stream = ctx->own_stream;
+  ctx_release(ctx);
 }
 int bppp_ctx_set_stream(bppp_ctx *ctx, void *hip_stream) {
   if (!ctx) return BPPP_ERR_ARG;
@@ -106,6 +116,7 @@ const char *bppp_last_error(const bppp_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 #define CTX_ENTER(ctx)                         \
   if (!(ctx)) return BPPP_ERR_ARG;             \
+  if ((ctx)->closed.load()) return BPPP_ERR_ARG; \
   if (hipSetDevice((ctx)->device) != hipSuccess) return bppp::fail(ctx, BPPP_ERR_HIP, "hipSetDevice failed")
 
 int bppp_msm_batch_device(bppp_ctx *ctx, const void *d_scalars, const void *d_points_xy, size_t n, size_t batch, int shared_points,

@@ -2,11 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/bppp.h"
 
 struct bppp_ctx {
+  // Lifetime: the caller's handle holds one reference, every child handle (bppp_nl, bppp_nlb, bppp_ip, bppp_trrp, bppp_basis,
+  // bppp_rp) one more.  bppp_ctx_destroy marks the context closed and drops the caller's reference; the stream, the
+  // workspaces and the struct itself go when the LAST reference goes, so a child destroyed after its context (a finaliser
+  // running in any order) never touches freed memory.  Calls on a child of a closed context fail with BPPP_ERR_ARG.
+  std::atomic<int> refs{1};
+  std::atomic<bool> closed{false};
   int device = 0;
   hipStream_t stream = nullptr;      // stream all work is issued on
   hipStream_t own_stream = nullptr;  // created by the context (used unless the caller binds its own)
@@ -57,6 +64,9 @@ struct Carver {
   }
 };
 
+void ctx_retain(bppp_ctx *ctx);
+void ctx_release(bppp_ctx *ctx);          // the last release tears the context down
+inline bool ctx_closed(const bppp_ctx *ctx) { return !ctx || ctx->closed.load(); }
 int ensure_workspace(bppp_ctx *ctx, size_t bytes);
 int ensure_pinned(bppp_ctx *ctx, size_t bytes);
 int ensure_scratch(bppp_ctx *ctx, size_t bytes);

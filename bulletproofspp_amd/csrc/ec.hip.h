@@ -1,4 +1,4 @@
-// ec.cuh — secp256k1 group law on the device: affine inputs, XYZZ accumulators over fq26.
+// ec.hip.h — secp256k1 group law on the device: affine inputs, XYZZ accumulators over fq26.
 //
 // Replaces the reference's NormalAdd / FastDouble layer (src/Commitment.hs:58-176): `nrmlAdd`
 // (affine + projective/Jacobian mixed add, :128-144, :156-169), `dbl'` (:111-113) and
@@ -10,13 +10,13 @@
 // Unlike the reference's formulas (incomplete for P = Q, acknowledged at Commitment.hs:98,110)
 // every routine here follows the group law for all inputs: infinity, P = Q, P = -Q.
 //
-// Coordinates are fq26 values with these magnitude invariants (see fq26.cuh):
+// Coordinates are fq26 values with these magnitude invariants (see fq26.hip.h):
 //   affine x, y : 1        XYZZ  X <= 5, Y <= 3, ZZ = ZZZ = 1
 // Infinity: affine (0,0) (never on y^2 = x^3+7); XYZZ with every limb of ZZ exactly zero (ZZ of a
 // finite point is a product of non-zero factors, so it is never 0 mod p and never all-zero).
 // In memory: affine = 16 u32 (two canonical 8x32 values, the ABI format); XYZZ = 40 u32 (raw limbs).
 #pragma once
-#include "fq26.cuh"
+#include "fq26.hip.h"
 
 namespace bppp {
 

@@ -1,4 +1,4 @@
-// fe.cuh — 256-bit modular arithmetic for gfx950 (8 x 32-bit limbs in VGPRs).
+// fe.hip.h — 256-bit modular arithmetic for gfx950 (8 x 32-bit limbs in VGPRs).
 //
 // Device counterpart of the reference's field layer: `Prime p` from galois-field (default path,
 // app/Main.hs:17) / FastPrime primops addField# negField# mulField# sqrField# invField#

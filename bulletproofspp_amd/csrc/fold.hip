@@ -6,10 +6,10 @@
 //
 // The reference runs a 129-row Straus loop per pair and pays one field inversion per pair
 // (normalizeBasis on two points, Commitment.hs:347).  Here every lane owns one pair and walks the joint-sparse-form
-// schedule of (b', a') against its own four-entry table in LDS (foldcore.cuh); inputs are already affine.
+// schedule of (b', a') against its own four-entry table in LDS (foldcore.hip.h); inputs are already affine.
 #include <string.h>
 #include "ctx.hpp"
-#include "foldcore.cuh"
+#include "foldcore.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {

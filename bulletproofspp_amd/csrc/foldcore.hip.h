@@ -1,4 +1,4 @@
-// foldcore.cuh — one basis-fold pair per lane:  out = b' * GL + a' * GR  for 129-bit reduced scalars (b', a').
+// foldcore.hip.h — one basis-fold pair per lane:  out = b' * GL + a' * GR  for 129-bit reduced scalars (b', a').
 //
 // The group element is the reference's `projectivePairIP (b', gL) (a', gR)` (src/Commitment.hs:343-353, reached from
 // collapsePoints, src/Bulletproof.hs:213-214): a 129-row double-and-add over the two points.  Any addition chain that
@@ -11,7 +11,7 @@
 // then holds only the XYZZ accumulator and one addend, and because the addend is picked PER LANE, lanes of one wavefront
 // may belong to different folds (different proofs / different scalar pairs): short folds are packed into full wavefronts.
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace bppp {
 

@@ -1,4 +1,4 @@
-// fq26.cuh — the coordinate field Fq (p = 2^256 - 2^32 - 977) in 10 x 26-bit limbs with lazy reduction.
+// fq26.hip.h — the coordinate field Fq (p = 2^256 - 2^32 - 977) in 10 x 26-bit limbs with lazy reduction.
 //
 // Why this representation on gfx950 (measured, benchmarks/valu_microbench.hip): v_mad_u64_u32 costs about
 // the same as any other multiply or 64-bit add (~4.8 cycles per wave-instruction per SIMD) while 32-bit
@@ -15,8 +15,8 @@
 // Magnitude rule: a value has magnitude m when limb[i] <= 2*m*(2^26-1) for i < 9 and limb[9] <= 2*m*(2^22-1).
 // mul / sqr take magnitudes <= 8 and return 1; add adds magnitudes; neg<M> takes <= M and returns M + 1.
 #pragma once
-#include "fe.cuh"
-#include "modinv.cuh"
+#include "fe.hip.h"
+#include "modinv.hip.h"
 
 namespace bppp {
 
@@ -242,7 +242,7 @@ BPPP_DI fq fq_inv_fermat(const fq &a) {
   t = fq_mul(fq_sqr_n(t, 2), a);
   return t;
 }
-// production inverse: safegcd division steps on the canonical value (modinv.cuh): ~60 multiplications' worth of instructions instead
+// production inverse: safegcd division steps on the canonical value (modinv.hip.h): ~60 multiplications' worth of instructions instead
 // of the chain's 270, the same for every lane; 0 -> 0
 BPPP_DI fq fq_inv(const fq &a) { return fq_from_fe(fe_modinv<0>(fq_to_fe(a))); }
 

@@ -10,7 +10,7 @@
 // (It is not faster than the plain path at 2^20 — same number of bucket additions — and exists for parity with that option.)
 #include <string.h>
 #include "ctx.hpp"
-#include "ec.cuh"
+#include "ec.hip.h"
 #include "../../include/bppp.h"
 
 namespace bppp {

@@ -135,7 +135,7 @@ inline void batch_minv(U256 *v, size_t n, const Mod &M) {
   delete[] pre;
 }
 
-// a lazily-reduced device value: 10 limbs of radix 2^26 (csrc/fq26.cuh), any magnitude -> canonical mod p
+// a lazily-reduced device value: 10 limbs of radix 2^26 (csrc/fq26.hip.h), any magnitude -> canonical mod p
 inline U256 from_limbs26(const uint32_t *n) {
   const Mod &M = FQ();
   U256 acc = U256::zero(), radix = U256::from_u64(1ull << 26);
@@ -259,7 +259,7 @@ inline SInt squot(const SInt &a, const SInt &b) {
 // Joint sparse form (Solinas, "Low-weight binary representations for pairs of integers") of two magnitudes < 2^129:
 // digits (u0_i, u1_i) in {-1,0,1}^2 with sum_i u_i 2^i = k and at most half of the rows non-zero on average.
 // Output: 4 bits per row, [1:0] = code(u0), [3:2] = code(u1), code(0)=0, code(+1)=1, code(-1)=3; 130 rows in 17 words.
-// Consumed by foldcore.cuh (device) as the add schedule of b'*GL + a'*GR.
+// Consumed by foldcore.hip.h (device) as the add schedule of b'*GL + a'*GR.
 inline void jsf_recode(const uint64_t k0_[3], const uint64_t k1_[3], uint32_t out[17]) {
   uint64_t k0[3] = {k0_[0], k0_[1], k0_[2]}, k1[3] = {k1_[0], k1_[1], k1_[2]};
   memset(out, 0, 17 * sizeof(uint32_t));

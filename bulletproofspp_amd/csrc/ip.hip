@@ -12,7 +12,7 @@
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
-#include "ec.cuh"
+#include "ec.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -168,18 +168,20 @@ extern "C" {
 
 void bppp_ip_destroy(bppp_ip *ip) {
   if (!ip) return;
-  hipSetDevice(ip->ctx->device);
-  hipStreamSynchronize(ip->ctx->stream);
+  bppp_ctx *ctx = ip->ctx;                 // kept alive by this handle's reference even after bppp_ctx_destroy
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(ip->x[k]); hipFree(ip->y[k]); hipFree(ip->lx[k]); hipFree(ip->lc[k]); hipFree(ip->P[k]); }
   hipFree(ip->sc); hipFree(ip->sums);
   delete ip;
+  ctx_release(ctx);
 }
 
 // makeNormLinearBP' 1 r cs nss ngs lss lgs (InnerProductArgument.hs:248) inside makePSV s g
 int bppp_ip_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], const uint64_t r_[4], const uint64_t *norm_s,
                    const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy,
                    size_t llen, bppp_ip **out) {
-  if (!ctx || !out || !s || !g_xy || !r_) return BPPP_ERR_ARG;
+  if (!ctx || !out || !s || !g_xy || !r_ || ctx_closed(ctx)) return BPPP_ERR_ARG;
   if ((nlen && (!norm_s || !norm_g_xy)) || (llen && (!lin_c || !lin_x || !lin_h_xy))) return fail(ctx, BPPP_ERR_ARG, "ip_create: null vector");
   if (nlen + llen == 0 || nlen >= (1u << 30) || llen >= (1u << 30)) return fail(ctx, BPPP_ERR_ARG, "ip_create: bad lengths");
   hipSetDevice(ctx->device);
@@ -187,7 +189,7 @@ int bppp_ip_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], c
   bppp_ip *ip = new bppp_ip();
   memset(ip, 0, sizeof *ip);
   const size_t m = (nlen + 1) / 2;
-  ip->ctx = ctx; ip->m = m; ip->l = llen; ip->cap = 2 * ev2(m) + ev2(llen) + 1; ip->cur = 0;
+  ip->ctx = ctx; ctx_retain(ctx); ip->m = m; ip->l = llen; ip->cap = 2 * ev2(m) + ev2(llen) + 1; ip->cur = 0;
   U256 r = U256::load(r_), r2 = mmul(r, r, M);
   ip->q = mmul(r2, r2, M); ip->qinv = minv(ip->q, M);
   ip->s = U256::from_u64(4); ip->nx = U256::one(); ip->ny = U256::one(); ip->ln = U256::one();
@@ -203,6 +205,7 @@ int bppp_ip_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], c
   uint32_t *tmp = nullptr;
   if (!bad && nlen) bad |= hipMalloc(&tmp, ev2(nlen) * 64) != hipSuccess;
   if (bad) { if (tmp) hipFree(tmp); bppp_ip_destroy(ip); return fail(ctx, BPPP_ERR_HIP, "ip_create: hipMalloc failed"); }
+  auto fill = [&]() -> int {                 // any failure below goes through ONE cleanup (tmp freed, handle destroyed)
   IP_HIP(ip, hipMemsetAsync(ip->P[0], 0, ip->cap * 64, st));
   if (nlen) {
     // x' = s0/(2r) + s1/2,  y' = -s0/(2r) + s1/2   (:202-203)
@@ -219,7 +222,7 @@ int bppp_ip_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], c
     IP_HIP(ip, hipMemcpyAsync(tmp, norm_g_xy, nlen * 64, hipMemcpyHostToDevice, st));
     IP_HIP(ip, hipStreamSynchronize(st));
     int rc = ip_transform_basis(ctx, r, tmp, nlen, ip->P[0], ip->P[0] + ev2(m) * 16);
-    if (rc) { hipFree(tmp); bppp_ip_destroy(ip); return rc; }
+    if (rc) return rc;
   }
   if (llen) {
     IP_HIP(ip, hipMemcpyAsync(ip->lc[0], lin_c, llen * 32, hipMemcpyHostToDevice, st));
@@ -228,7 +231,11 @@ int bppp_ip_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], c
   }
   IP_HIP(ip, hipMemcpyAsync(ip->P[0] + (2 * ev2(m) + ev2(llen)) * 16, g_xy, 64, hipMemcpyHostToDevice, st));
   IP_HIP(ip, hipStreamSynchronize(st));
-  if (tmp) hipFree(tmp);
+  return BPPP_OK;
+  };
+  const int rc_fill = fill();
+  if (tmp) { hipStreamSynchronize(st); hipFree(tmp); }
+  if (rc_fill) { bppp_ip_destroy(ip); return rc_fill; }
   *out = ip;
   return BPPP_OK;
 }
@@ -243,6 +250,7 @@ int bppp_ip_lengths(const bppp_ip *ip, size_t *ip_len, size_t *llen) {
 int bppp_ip_round_commit(bppp_ip *ip, uint64_t sL[4], uint64_t L_xy[8], uint64_t sR[4], uint64_t R_xy[8]) {
   if (!ip || !sL || !L_xy || !sR || !R_xy) return BPPP_ERR_ARG;
   bppp_ctx *ctx = ip->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = RM();
   const size_t me = ev2(ip->m), le = ev2(ip->l), T = 2 * me + le + 1;
@@ -284,6 +292,7 @@ int bppp_ip_round_commit(bppp_ip *ip, uint64_t sL[4], uint64_t L_xy[8], uint64_t
 int bppp_ip_round_collapse(bppp_ip *ip, const uint64_t e_[4]) {
   if (!ip || !e_) return BPPP_ERR_ARG;
   bppp_ctx *ctx = ip->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = RM();
   const U256 e = U256::load(e_);
@@ -338,6 +347,7 @@ int bppp_ip_round_collapse(bppp_ip *ip, const uint64_t e_[4]) {
 int bppp_ip_get_witness(bppp_ip *ip, uint64_t *norm_w /*2*ip_len*/, uint64_t *lin_w, uint64_t s[4]) {
   if (!ip || (ip->m && !norm_w) || (ip->l && !lin_w)) return BPPP_ERR_ARG;
   bppp_ctx *ctx = ip->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = RM();
   const int c = ip->cur;

@@ -1,4 +1,4 @@
-// modinv.cuh — modular inversion by Bernstein-Yang "safegcd" division steps, 30 bits at a time.
+// modinv.hip.h — modular inversion by Bernstein-Yang "safegcd" division steps, 30 bits at a time.
 //
 // The reference inverts through GMP (`invField#`, src/Data/Field/Galois/FastPrime/Internal.hs:981-983; `recip` of Prime p);
 // only the value matters: x^-1 mod m in [0, m), and 0 -> 0 as batchInverse defines it (src/Data/Field/BatchInverse.hs:18).
@@ -8,7 +8,7 @@
 // code serves both moduli.  The construction (signed 30-bit limbs, 2x2 transition matrices scaled by 2^30, the zeta = -delta - 1/2
 // bookkeeping, 600 steps for 256-bit inputs) is the published one used by libsecp256k1's modinv32.
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace bppp {
 

@@ -24,7 +24,7 @@
 #include <algorithm>
 #include <vector>
 #include "ctx.hpp"
-#include "ec.cuh"
+#include "ec.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {

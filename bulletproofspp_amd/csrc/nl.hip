@@ -18,7 +18,7 @@
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
-#include "ec.cuh"
+#include "ec.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -94,23 +94,25 @@ extern "C" {
 
 void bppp_nl_destroy(bppp_nl *nl) {
   if (!nl) return;
-  hipSetDevice(nl->ctx->device);
-  hipStreamSynchronize(nl->ctx->stream);
+  bppp_ctx *ctx = nl->ctx;                 // kept alive by this handle's reference even after bppp_ctx_destroy
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(nl->x[k]); hipFree(nl->lx[k]); hipFree(nl->lc[k]); hipFree(nl->P[k]); }
   hipFree(nl->sc);
   delete nl;
+  ctx_release(ctx);
 }
 
 int bppp_nl_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], const uint64_t q[4], const uint64_t *norm_x,
                    const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy,
                    size_t llen, bppp_nl **out) {
-  if (!ctx || !out || !s || !g_xy || !q) return BPPP_ERR_ARG;
+  if (!ctx || !out || !s || !g_xy || !q || ctx_closed(ctx)) return BPPP_ERR_ARG;
   if ((nlen && (!norm_x || !norm_g_xy)) || (llen && (!lin_c || !lin_x || !lin_h_xy))) return fail(ctx, BPPP_ERR_ARG, "nl_create: null vector");
   if (nlen + llen == 0 || nlen >= (1u << 30) || llen >= (1u << 30)) return fail(ctx, BPPP_ERR_ARG, "nl_create: bad lengths");
   hipSetDevice(ctx->device);
   bppp_nl *nl = new bppp_nl();
   memset(nl, 0, sizeof *nl);
-  nl->ctx = ctx; nl->n = nlen; nl->l = llen; nl->cap = ev(nlen) + ev(llen) + 1; nl->cur = 0;
+  nl->ctx = ctx; ctx_retain(ctx); nl->n = nlen; nl->l = llen; nl->cap = ev(nlen) + ev(llen) + 1; nl->cur = 0;
   nl->q = U256::load(q); nl->qinv = minv(nl->q, R_()); nl->nn = U256::one(); nl->ln = U256::one();
   nl->s = U256::load(s); nl->scomp = U256::one();
   hipStream_t st = ctx->stream;
@@ -122,6 +124,7 @@ int bppp_nl_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], c
     }
   }
   if (hipMalloc(&nl->sc, 2 * nl->cap * 32) != hipSuccess) { bppp_nl_destroy(nl); return fail(ctx, BPPP_ERR_HIP, "nl_create: hipMalloc failed"); }
+  auto fill = [&]() -> int {                 // any failure below goes through ONE cleanup: the handle is destroyed
   NL_HIP(nl, hipMemsetAsync(nl->P[0], 0, nl->cap * 64, st));
   if (nlen) {
     NL_HIP(nl, hipMemcpyAsync(nl->x[0], norm_x, nlen * 32, hipMemcpyHostToDevice, st));
@@ -134,6 +137,9 @@ int bppp_nl_create(bppp_ctx *ctx, const uint64_t s[4], const uint64_t g_xy[8], c
   }
   NL_HIP(nl, hipMemcpyAsync(nl->P[0] + (ev(nlen) + ev(llen)) * 16, g_xy, 64, hipMemcpyHostToDevice, st));
   NL_HIP(nl, hipStreamSynchronize(st));
+  return BPPP_OK;
+  };
+  if (int rc = fill()) { bppp_nl_destroy(nl); return rc; }
   *out = nl;
   return BPPP_OK;
 }
@@ -147,6 +153,7 @@ int bppp_nl_lengths(const bppp_nl *nl, size_t *nlen, size_t *llen) {
 int bppp_nl_round_commit(bppp_nl *nl, uint64_t sX[4], uint64_t X_xy[8], uint64_t sR[4], uint64_t R_xy[8]) {
   if (!nl || !sX || !X_xy || !sR || !R_xy) return BPPP_ERR_ARG;
   bppp_ctx *ctx = nl->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = R_();
   const size_t ne = ev(nl->n), le = ev(nl->l), T = ne + le + 1;
@@ -185,6 +192,7 @@ int bppp_nl_round_commit(bppp_nl *nl, uint64_t sX[4], uint64_t X_xy[8], uint64_t
 int bppp_nl_round_collapse(bppp_nl *nl, const uint64_t e_[4]) {
   if (!nl || !e_) return BPPP_ERR_ARG;
   bppp_ctx *ctx = nl->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = R_();
   const U256 e = U256::load(e_);
@@ -234,6 +242,7 @@ int bppp_nl_download(bppp_nl *nl, uint64_t *norm_x, uint64_t *norm_g_xy, uint64_
                      uint64_t s[4], uint64_t q[4], uint64_t norm_nrmlz[4], uint64_t lin_nrmlz[4]) {
   if (!nl) return BPPP_ERR_ARG;
   bppp_ctx *ctx = nl->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const int c = nl->cur;
   hipStream_t st = ctx->stream;

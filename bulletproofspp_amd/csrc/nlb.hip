@@ -11,7 +11,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
-#include "foldcore.cuh"
+#include "foldcore.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_nlb_fold_scalars(const uint32_t *__rest
 
 // basis folds of all proofs: the pairs [norm | linear] of every proof are numbered consecutively over the whole batch, so
 // wavefronts are full in every round (a late round has a handful of pairs per proof); each lane walks the digit schedule of
-// its own proof and fold (foldcore.cuh)
+// its own proof and fold (foldcore.hip.h)
 __global__ void __launch_bounds__(64) k_nlb_fold_points(const uint32_t *__restrict__ P, uint32_t n, uint32_t l, uint32_t cap, uint32_t cap_out,
                                                         const CollapseK *__restrict__ K, uint32_t batch, uint32_t *__restrict__ Po) {
   __shared__ uint32_t tab[FOLD_TAB_WORDS];
@@ -181,11 +181,13 @@ extern "C" {
 
 void bppp_nlb_destroy(bppp_nlb *o) {
   if (!o) return;
-  hipSetDevice(o->ctx->device);
-  hipStreamSynchronize(o->ctx->stream);
+  bppp_ctx *ctx = o->ctx;                  // kept alive by this handle's reference even after bppp_ctx_destroy
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(o->x[k]); hipFree(o->lx[k]); hipFree(o->lc[k]); hipFree(o->P[k]); }
   hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK);
   delete o;
+  ctx_release(ctx);
 }
 
 // `batch` x makeNormLinearBP' 1 q_b cs_b nss_b ngs lss_b lgs (NormArgument.hs:162) inside makePSV s_b g: the basis (g, G, H) is
@@ -204,14 +206,14 @@ extern "C" {
 int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
                     const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
                     bppp_nlb **out) {
-  if (!ctx || !out || !s || !g_xy || !q || !batch) return BPPP_ERR_ARG;
+  if (!ctx || !out || !s || !g_xy || !q || !batch || ctx_closed(ctx)) return BPPP_ERR_ARG;
   if ((nlen && (!norm_x || !norm_g_xy)) || (llen && (!lin_c || !lin_x || !lin_h_xy)) || nlen + llen == 0 || nlen >= (1u << 24) || llen >= (1u << 24) ||
       batch >= (1u << 20))
     return fail(ctx, BPPP_ERR_ARG, "nlb_create: bad arguments");
   hipSetDevice(ctx->device);
   const Mod &M = FR();
   bppp_nlb *o = new bppp_nlb();
-  o->ctx = ctx; o->batch = batch; o->n = o->n0 = nlen; o->l = o->l0 = llen; o->cur = 0;
+  o->ctx = ctx; ctx_retain(ctx); o->batch = batch; o->n = o->n0 = nlen; o->l = o->l0 = llen; o->cur = 0;
   o->cap = evb(nlen) + evb(llen) + 1; o->xstride = evb(nlen) + 2; o->lstride = evb(llen) + 2;
   for (int k = 0; k < 2; k++) { o->x[k] = o->lx[k] = o->lc[k] = o->P[k] = nullptr; }
   o->sc = o->sums = o->qs = nullptr; o->dK = nullptr;
@@ -224,6 +226,7 @@ int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   bad |= hipMalloc(&o->qs, batch * 64) != hipSuccess || hipMalloc(&o->dK, batch * sizeof(CollapseK)) != hipSuccess;
   if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
   hipStream_t st = ctx->stream;
+  auto fill = [&]() -> int {                 // any failure below goes through ONE cleanup: the handle is destroyed
   NLB_HIP(o, hipMemsetAsync(o->P[0], 0, batch * o->cap * 64, st));
   NLB_HIP(o, hipMemsetAsync(o->x[0], 0, batch * o->xstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lx[0], 0, batch * o->lstride * 32, st));
@@ -248,6 +251,9 @@ int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   for (size_t b = 0; b < batch; b++) { o->q[b] = U256::load(q + 4 * b); o->qinv[b] = o->q[b]; o->s[b] = U256::load(s + 4 * b); }
   batch_minv(o->qinv.data(), batch, M);
   NLB_HIP(o, hipStreamSynchronize(st));
+  return BPPP_OK;
+  };
+  if (int rc = fill()) { bppp_nlb_destroy(o); return rc; }
   *out = o;
   return BPPP_OK;
 }
@@ -262,6 +268,7 @@ int bppp_nlb_lengths(const bppp_nlb *o, size_t *batch, size_t *nlen, size_t *lle
 int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy) {
   if (!o || !sX || !X_xy || !sR || !R_xy) return BPPP_ERR_ARG;
   bppp_ctx *ctx = o->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = FR();
   const size_t B = o->batch, ne = evb(o->n), le = evb(o->l), T = ne + le + 1;
@@ -299,6 +306,7 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
 int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   if (!o || !es) return BPPP_ERR_ARG;
   bppp_ctx *ctx = o->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = FR();
   const size_t B = o->batch;
@@ -308,6 +316,9 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   std::vector<CollapseK> K(B);
   auto put8 = [](uint32_t *dst, const U256 &v) { for (int i = 0; i < 8; i++) dst[i] = (uint32_t)(v.w[i / 2] >> (32 * (i & 1))); };
   std::vector<U256> inv(2 * B, U256::zero()), a0l(B), b0n(B), b0l(B);
+  // the advanced host state is built beside the current one and committed only after the device work has been issued and has
+  // completed: an error return leaves the prover exactly where it was
+  std::vector<U256> s_new(o->s), nn_new(o->nn), q_new(o->q), qinv_new(o->qinv), ln_new(o->ln);
   for (size_t b = 0; b < B; b++)
     if (cmp(U256::load(es + 4 * b), M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
   std::atomic<int> too_big{0};
@@ -315,7 +326,7 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
    for (size_t b = lo; b < hi; b++) {
     const U256 e = U256::load(es + 4 * b);
     U256 e1 = msub(mmul(e, e, M), U256::one(), M);
-    o->s[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
+    s_new[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
     memset(&K[b], 0, sizeof(CollapseK));
     if (o->n) {
       auto ab = rational_reduce_scalar(mmul(e, o->qinv[b], M));
@@ -335,12 +346,12 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
     const U256 e = U256::load(es + 4 * b);
     if (o->n) {
       put8(K[b].nu, inv[2 * b]); put8(K[b].nv, mmul(mmul(e, o->q[b], M), inv[2 * b], M));
-      o->nn[b] = mmul(mmul(o->nn[b], b0n[b], M), o->qinv[b], M);
-      o->q[b] = mmul(o->q[b], o->q[b], M); o->qinv[b] = mmul(o->qinv[b], o->qinv[b], M);
+      nn_new[b] = mmul(mmul(o->nn[b], b0n[b], M), o->qinv[b], M);
+      q_new[b] = mmul(o->q[b], o->q[b], M); qinv_new[b] = mmul(o->qinv[b], o->qinv[b], M);
     }
     if (o->l) {
       put8(K[b].cu, b0l[b]); put8(K[b].cv, a0l[b]); put8(K[b].lu, inv[2 * b + 1]); put8(K[b].lv, mmul(e, inv[2 * b + 1], M));
-      o->ln[b] = mmul(o->ln[b], b0l[b], M);
+      ln_new[b] = mmul(o->ln[b], b0l[b], M);
     }
    }
   });
@@ -361,6 +372,7 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   k_nlb_move_g<<<dim3((unsigned)B), dim3(64), 0, st>>>(o->P[c], (uint32_t)(ne + le + 1), (uint32_t)(ne2 + le2 + 1), (uint32_t)(ne + le), (uint32_t)(ne2 + le2), o->P[d]);
   NLB_HIP(o, hipGetLastError());
   NLB_HIP(o, hipStreamSynchronize(st));
+  o->s.swap(s_new); o->nn.swap(nn_new); o->q.swap(q_new); o->qinv.swap(qinv_new); o->ln.swap(ln_new);
   o->n = o->n ? n2 : 0; o->l = o->l ? l2 : 0; o->cur = d;
   return BPPP_OK;
 }
@@ -369,6 +381,7 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
 int bppp_nlb_get_witness(bppp_nlb *o, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s) {
   if (!o || (o->n && !norm_w) || (o->l && !lin_w)) return BPPP_ERR_ARG;
   bppp_ctx *ctx = o->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   const Mod &M = FR();
   const int c = o->cur;

@@ -13,7 +13,7 @@
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
-#include "fe.cuh"
+#include "fe.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {

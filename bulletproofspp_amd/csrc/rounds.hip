@@ -9,8 +9,8 @@
 // Vectors are traversed as ADJACENT pairs (x0,x1),(x2,x3),.. with a zero default for an odd tail
 // (src/Bulletproof.hs:77-90).  All values are canonical integers mod n.
 #include "ctx.hpp"
-#include "fe.cuh"
-#include "modinv.cuh"
+#include "fe.hip.h"
+#include "modinv.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -134,7 +134,7 @@ template <int MOD> __global__ void __launch_bounds__(64) k_batch_inverse(const u
     pre[k] = acc;
     if (!fe_is_zero(v[k])) acc = fe_mul<MOD>(acc, v[k]);          // rec0 skips zeros (BatchInverse.hs:18)
   }
-  fe y = fe_modinv<MOD>(acc);      // division steps (modinv.cuh): every lane inverts here, and their stream is input-independent
+  fe y = fe_modinv<MOD>(acc);      // division steps (modinv.hip.h): every lane inverts here, and their stream is input-independent
 #pragma unroll
   for (int k = BI_RUN - 1; k >= 0; k--) {
     fe r = fe_zero();

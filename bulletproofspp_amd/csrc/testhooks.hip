@@ -2,8 +2,8 @@
 #include "../../include/bppp_test.h"
 #include <vector>
 #include "ctx.hpp"
-#include "ec.cuh"
-#include "modinv.cuh"
+#include "ec.hip.h"
+#include "modinv.hip.h"
 
 namespace bppp {
 template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
@@ -13,12 +13,12 @@ template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
     case BPPP_FE_MUL: return fe_mul<MOD>(a, b);
     case BPPP_FE_SQR: return fe_sqr<MOD>(a);
     case BPPP_FE_INV: return fe_inv<MOD>(a);
-    case 7: return fe_inv_vartime<MOD>(a);       // binary extended Euclid (fe.cuh)
-    case 8: return fe_modinv<MOD>(a);            // safegcd division steps (modinv.cuh)
+    case 7: return fe_inv_vartime<MOD>(a);       // binary extended Euclid (fe.hip.h)
+    case 8: return fe_modinv<MOD>(a);            // safegcd division steps (modinv.hip.h)
     default: return fe_neg<MOD>(a);
   }
 }
-// Fq through the production representation (10 x 26-bit limbs, csrc/fq26.cuh)
+// Fq through the production representation (10 x 26-bit limbs, csrc/fq26.hip.h)
 BPPP_DI fe apply_op_fq(int op, const fe &a, const fe &b) {
   fq x = fq_from_fe(a), y = fq_from_fe(b);
   switch (op) {

@@ -8,12 +8,12 @@
 // batch of fresh proofs goes from challenges to the combined MSM without its O(nrmLen + linLen) scalars crossing PCIe.
 //
 // One wavefront per proof.  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
-// inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 8x32 limbs (fe.cuh).
+// inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 8x32 limbs (fe.hip.h).
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
-#include "fe.cuh"
-#include "modinv.cuh"
+#include "fe.hip.h"
+#include "modinv.hip.h"
 #include "../../include/bppp.h"
 
 namespace bppp {
@@ -196,18 +196,21 @@ extern "C" {
 
 void bppp_trrp_destroy(bppp_trrp *o) {
   if (!o) return;
-  hipSetDevice(o->ctx->device);
+  bppp_ctx *ctx = o->ctx;                  // kept alive by this handle's reference even after bppp_ctx_destroy
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
   for (uint32_t *p : {o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min, o->range_assumed, o->syms, o->cs_slot, o->cs_sym, o->pub_is_out,
                       o->pub_amount, o->pub_sym})
     if (p) hipFree(p);
   delete o;
+  ctx_release(ctx);
 }
 
 int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, size_t llen, size_t nranges, const uint32_t *pos_kind, const uint32_t *pos_range,
                      const uint32_t *pos_slot, const uint32_t *pos_sym, const uint64_t *pos_coeff, const uint64_t *range_min, const uint32_t *range_assumed,
                      size_t nsyms, const uint64_t *syms, const uint32_t *cs_slot, const uint32_t *cs_sym, size_t npub, const uint32_t *pub_is_out,
                      const uint64_t *pub_amount, const uint32_t *pub_sym, bppp_trrp **out) {
-  if (!ctx || !out) return BPPP_ERR_ARG;
+  if (!ctx || !out || ctx_closed(ctx)) return BPPP_ERR_ARG;
   if (!nlen || llen < 6 || !nranges || nlen >= (1u << 24) || llen >= (1u << 24) || nranges >= (1u << 20) || nsyms + 2 > 1024 || npub >= (1u << 20) ||
       !pos_kind || !pos_range || !pos_slot || !pos_sym || !pos_coeff || !range_min || !range_assumed || (nsyms && !syms) || (llen > 6 && (!cs_slot || !cs_sym)) ||
       (npub && (!pub_is_out || !pub_amount || !pub_sym)))
@@ -222,7 +225,7 @@ int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, siz
   hipSetDevice(ctx->device);
   bppp_trrp *o = new bppp_trrp();
   memset(o, 0, sizeof *o);
-  o->ctx = ctx;
+  o->ctx = ctx; ctx_retain(ctx);
   o->D = TrrpDims{(uint32_t)nlen, (uint32_t)llen, (uint32_t)nranges, (uint32_t)nsyms, (uint32_t)npub, has_types ? 1u : 0u, flavour ? 1u : 0u};
   bool bad = false;
   auto up = [&](uint32_t **dst, const void *src, size_t bytes) {
@@ -243,6 +246,7 @@ int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges
                             void *d_init_scalars) {
   if (!o) return BPPP_ERR_ARG;
   bppp_ctx *ctx = o->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   if (!batch) return BPPP_OK;
   if (!d_challenges || !d_q || !d_sp || !d_pub_norm || !d_pub_lin_c || !d_init_scalars || batch >= (1u << 24)) return fail(ctx, BPPP_ERR_ARG, "trrp_public: bad arguments");
   hipSetDevice(ctx->device);

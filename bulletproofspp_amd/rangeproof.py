@@ -767,6 +767,7 @@ class DeviceVerifierTables:
                                       _ptr(k[11]), _ptr(k[12]), C.byref(h))
         gpu._check(rc, "bppp_trrp_create")
         self.h = h
+        gpu._adopt(self)
         self.ninit = 4 + len(st.rds)
 
     def close(self):

@@ -1,5 +1,5 @@
 /*
- * bppp_test.h — test-only hooks exported by libbppp_hip.so so the parity tests can exercise the
+ * bppp_test.h — test-only hooks exported by libbppp_hip_test.so (a separate library; the product library does not contain them) so the parity tests can exercise the
  * device field and group arithmetic directly (the device counterparts of mulField# / addField# /
  * invField#, src/Data/Field/Galois/FastPrime/Internal.hs:909-988, and of nrmlAdd / dbl',
  * src/Commitment.hs:111-144).  Not part of the drop-in boundary.

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import pyoracle as O
-from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_scalars, array_to_point
+from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_scalars, array_to_point, load_test_library
 
 pytestmark = pytest.mark.gpu
 
@@ -17,8 +17,7 @@ OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5, "mag8mul": 6,
 def _fe_op(gpu, op, mod, a, b):
     A, B = scalars_to_array(a), scalars_to_array(b)
     out = np.zeros_like(A)
-    lib = gpu.lib
-    lib.bppp_test_fe_op.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib = load_test_library()            # the hooks live in libbppp_hip_test.so, not in the product library
     rc = lib.bppp_test_fe_op(gpu.h, OPS[op], mod, A.ctypes.data, B.ctypes.data, len(a), out.ctypes.data)
     assert rc == 0, gpu.lib.bppp_last_error(gpu.h)
     return array_to_scalars(out)
@@ -71,8 +70,7 @@ def test_reference_constant_3_pow_160(gpu):
 def _pt_op(gpu, op, ps, qs):
     A, B = points_to_array(ps), points_to_array(qs)
     out = np.zeros_like(A)
-    lib = gpu.lib
-    lib.bppp_test_point_op.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib = load_test_library()
     rc = lib.bppp_test_point_op(gpu.h, op, A.ctypes.data, B.ctypes.data, len(ps), out.ctypes.data)
     assert rc == 0
     return [array_to_point(out[i]) for i in range(len(ps))]
