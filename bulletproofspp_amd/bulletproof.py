@@ -158,9 +158,19 @@ def verifyBatch(gpu: Bppp, proofs: Sequence[dict], g: Point, ngs: Sequence[Point
     """Batch verifier (no reference implementation): one MSM for all proofs.  Each proof is a dict with keys
     q, sp, pub_norm, pub_lin_c, pub_lin_x, es, responses, wit_norm, wit_lin, init_terms (shapes equal across the batch)."""
     B = len(proofs)
+    if B == 0:
+        return True
+    if len(rhos) != B or any(r % N_ORDER == 0 for r in rhos):
+        raise ValueError("verifyBatch needs one non-zero weight rho per proof")
     p0 = proofs[0]
     nlen, llen, k = len(ngs), len(lgs), len(p0["es"])
     fn, fl, ninit = len(p0["wit_norm"]), len(p0["wit_lin"]), len(p0["init_terms"])
+    # every proof must have the shape of the first one: the device arrays are [batch][...] with those strides, a short list would
+    # make them smaller than the kernels assume
+    want = {"pub_norm": nlen, "pub_lin_c": llen, "pub_lin_x": llen, "es": k, "responses": k, "wit_norm": fn, "wit_lin": fl, "init_terms": ninit}
+    for p in proofs:
+        if any(len(p[key]) != n for key, n in want.items()):
+            return False
     cat_s = lambda key: np.concatenate([scalars_to_array(p[key]) for p in proofs]) if len(p0[key]) else np.zeros((1, 4), dtype=np.uint64)
     arrs = {
         "g": points_to_array([g]), "G": points_to_array(ngs) if nlen else np.zeros((1, 8), dtype=np.uint64),

@@ -28,6 +28,7 @@ SYMBOLS = [
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
+    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device",
 ]
 
 
@@ -105,6 +106,12 @@ def load_library() -> C.CDLL:
     lib.bppp_device_free.argtypes = [vp, vp]
     lib.bppp_upload.argtypes = [vp, vp, vp, sz]
     lib.bppp_download.argtypes = [vp, vp, vp, sz]
+    lib.bppp_rp_create.argtypes = [vp, i, i, vp, sz, vp, sz, vp, sz, C.c_char_p, C.POINTER(vp)]
+    lib.bppp_rp_destroy.argtypes = [vp]
+    lib.bppp_rp_destroy.restype = None
+    lib.bppp_rp_info.argtypes = [vp, vp]
+    lib.bppp_rp_verify_batch.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp]
+    lib.bppp_rp_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp]
     lib.bppp_profile_enable.argtypes = [vp, i]
     lib.bppp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]
     return lib
@@ -122,6 +129,26 @@ def load_test_library() -> C.CDLL:
     lib.bppp_test_point_op.argtypes = [vp, i, vp, vp, sz, vp]
     lib.bppp_test_mulmod_rate.argtypes = [vp, i, C.POINTER(C.c_double)]
     return lib
+
+
+class RpRange(C.Structure):
+    """bppp_rp_range (include/bppp.h)"""
+    _fields_ = [("base", C.c_uint32), ("flags", C.c_uint32), ("min", C.c_uint64 * 4), ("max", C.c_uint64 * 4)]
+
+
+class RpPublic(C.Structure):
+    """bppp_rp_public"""
+    _fields_ = [("is_output", C.c_uint32), ("reserved", C.c_uint32), ("type", C.c_uint64 * 4), ("amount", C.c_uint64 * 4)]
+
+
+class RpShape(C.Structure):
+    """bppp_rp_shape"""
+    _fields_ = [(n, C.c_size_t) for n in ("nranges", "norm_len", "lin_len", "rounds", "final_norm", "final_lin", "coms_bytes", "proof_bytes",
+                                          "challenges_per_proof")]
+
+
+RP_SHARED, RP_OUTPUT, RP_ASSUMED = 1, 2, 4
+RP_VALID, RP_INVALID, RP_MALFORMED = 0, 1, 2
 
 
 # ---- integer <-> limb helpers (host-side glue for tests / bench)

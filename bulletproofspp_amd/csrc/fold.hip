@@ -61,16 +61,7 @@ __global__ void __launch_bounds__(64) k_lift_x(const uint32_t *__restrict__ xs, 
   fq x = fq_from_fe(xe);
   fq seven = fq_zero(); seven.n[0] = 7;
   fq rhs = fq_add(fq_mul(fq_sqr(x), x), seven);     // magnitude 2
-  // exponent (p+1)/4
-  fe e = fp_modulus();
-  e.v[0] += 1;                                      // p + 1 (low limb 0xFFFFFC2F + 1, no carry)
-#pragma unroll
-  for (int k = 0; k < 8; k++) e.v[k] = (e.v[k] >> 2) | (k < 7 ? e.v[k + 1] << 30 : 0u);
-  fq acc = fq_one(), base = rhs;
-  for (int b = 0; b < 254; b++) {
-    if ((e.v[b >> 5] >> (b & 31)) & 1u) acc = fq_mul(acc, base);
-    base = fq_sqr(base);
-  }
+  fq acc = fq_sqrt_candidate(rhs);                  // rhs^((p+1)/4): 253 squarings + 13 multiplications
   ok = ok && fq_normalizes_to_zero(fq_sub<2>(fq_sqr(acc), rhs));
   fq y = fq_normalize(acc);
   if (y.n[0] & 1u) y = fq_normalize(fq_neg<1>(y));

@@ -242,6 +242,25 @@ BPPP_DI fq fq_inv_fermat(const fq &a) {
   t = fq_mul(fq_sqr_n(t, 2), a);
   return t;
 }
+// square-root candidate a^((p+1)/4) (p = 3 mod 4) by the same kind of chain: (p+1)/4 has three runs of ones, 223, 22 and 2 long:
+// 253 squarings + 13 multiplications.  The caller checks r^2 = a (a non-residue gives a root of -a).  pointX of the reference
+// (app/Main.hs:68-72, src/Encoding.hs:97-103) bottoms out here.
+BPPP_DI fq fq_sqrt_candidate(const fq &a) {
+  fq x2 = fq_mul(fq_sqr(a), a);
+  fq x3 = fq_mul(fq_sqr(x2), a);
+  fq x6 = fq_mul(fq_sqr_n(x3, 3), x3);
+  fq x9 = fq_mul(fq_sqr_n(x6, 3), x3);
+  fq x11 = fq_mul(fq_sqr_n(x9, 2), x2);
+  fq x22 = fq_mul(fq_sqr_n(x11, 11), x11);
+  fq x44 = fq_mul(fq_sqr_n(x22, 22), x22);
+  fq x88 = fq_mul(fq_sqr_n(x44, 44), x44);
+  fq x176 = fq_mul(fq_sqr_n(x88, 88), x88);
+  fq x220 = fq_mul(fq_sqr_n(x176, 44), x44);
+  fq x223 = fq_mul(fq_sqr_n(x220, 3), x3);
+  fq t = fq_mul(fq_sqr_n(x223, 23), x22);
+  t = fq_mul(fq_sqr_n(t, 6), x2);
+  return fq_sqr_n(t, 2);
+}
 // production inverse: safegcd division steps on the canonical value (modinv.hip.h): ~60 multiplications' worth of instructions instead
 // of the chain's 270, the same for every lane; 0 -> 0
 BPPP_DI fq fq_inv(const fq &a) { return fq_from_fe(fe_modinv<0>(fq_to_fe(a))); }

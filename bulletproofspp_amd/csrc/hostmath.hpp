@@ -195,6 +195,24 @@ inline HJac hj_from_xyzz(const U256 &X, const U256 &Y, const U256 &ZZ, const U25
   return {fqmul(X, ZZ), fqmul(Y, ZZZ), ZZ};
 }
 
+// ---- input validation for the verifier entry points (proof-supplied data is untrusted)
+inline bool scalars_canonical(const uint64_t *s, size_t n) {
+  for (size_t i = 0; i < n; i++) if (cmp(U256::load(s + 4 * i), FR().m) >= 0) return false;
+  return true;
+}
+// every point is the infinity encoding (0,0) or has canonical coordinates with y^2 = x^3 + 7
+inline bool points_on_curve(const uint64_t *p, size_t n) {
+  const Mod &M = FQ();
+  for (size_t i = 0; i < n; i++) {
+    U256 x = U256::load(p + 8 * i), y = U256::load(p + 8 * i + 4);
+    if (x.is_zero() && y.is_zero()) continue;
+    if (cmp(x, M.m) >= 0 || cmp(y, M.m) >= 0) return false;
+    U256 rhs = madd(fqmul(fqmul(x, x), x), U256::from_u64(7), M);
+    if (!(fqmul(y, y) == rhs)) return false;
+  }
+  return true;
+}
+
 // ---- signed multi-precision integers for rationalReduceScalar (5 limbs + sign)
 struct SInt {
   static const int L = 5;

@@ -379,6 +379,15 @@ int bppp_ip_verify(bppp_ctx *ctx, const uint64_t r_[4], const uint64_t sp_[4], c
   if ((nlen && (!pub_norm || !norm_g_xy)) || (llen && (!pub_lin_c || !pub_lin_x || !lin_h_xy)) || (k && (!es || !responses_xy)) ||
       (fn && !wit_norm) || (fl && !wit_lin) || (ninit && (!init_scalars || !init_points_xy)) || k > 30 || (fn & 1))
     return fail(ctx, BPPP_ERR_ARG, "ip_verify: bad arguments");
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
+  // the proof-supplied data is untrusted: scalars must be canonical, points on the curve (or the infinity encoding)
+  if (!scalars_canonical(r_, 1) || !scalars_canonical(sp_, 1) || !scalars_canonical(pub_norm, nlen) || !scalars_canonical(pub_lin_c, llen) ||
+      !scalars_canonical(pub_lin_x, llen) || !scalars_canonical(es, k) || !scalars_canonical(wit_norm, fn) || !scalars_canonical(wit_lin, fl) ||
+      !scalars_canonical(init_scalars, ninit))
+    return fail(ctx, BPPP_ERR_ARG, "ip_verify: a scalar is not canonical (>= n)");
+  if (!points_on_curve(g_xy, 1) || !points_on_curve(norm_g_xy, nlen) || !points_on_curve(lin_h_xy, llen) || !points_on_curve(init_points_xy, ninit) ||
+      !points_on_curve(responses_xy, 2 * k))
+    return fail(ctx, BPPP_ERR_POINT, "ip_verify: a point is not on the curve");
   hipSetDevice(ctx->device);
   const Mod &M = RM();
   hipStream_t st = ctx->stream;

@@ -196,6 +196,27 @@ __global__ void __launch_bounds__(256) k_vb_sum_gs(const uint32_t *__restrict__ 
   if (t == 0) { fe x; for (int i = 0; i < 8; i++) x.v[i] = lds[i]; fe_store(out, x); }
 }
 
+// Validation of the untrusted per-proof arrays: every scalar canonical (< n), rho non-zero, every point the infinity encoding
+// or on y^2 = x^3 + 7 with canonical coordinates.  flags[0] |= 1 (scalar) / 2 (point) / 4 (rho = 0).
+__global__ void __launch_bounds__(256) k_vb_validate_scalars(const uint32_t *__restrict__ s, uint64_t n, int nonzero, uint32_t *__restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe v = fe_load(s + i * 8), t;
+  if (!raw_sub(t, v, fr_modulus())) atomicOr(flags, 1u);        // no borrow: v >= n
+  if (nonzero && fe_is_zero(v)) atomicOr(flags, 4u);
+}
+__global__ void __launch_bounds__(256) k_vb_validate_points(const uint32_t *__restrict__ p, uint64_t n, uint32_t *__restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x = fe_load(p + i * 16), y = fe_load(p + i * 16 + 8), t;
+  if (fe_is_zero(x) && fe_is_zero(y)) return;
+  bool ok = raw_sub(t, x, fp_modulus()) && raw_sub(t, y, fp_modulus());
+  fe seven = fe_zero(); seven.v[0] = 7;
+  fe rhs = fe_add<0>(fe_mul<0>(fe_sqr<0>(x), x), seven);
+  ok = ok && fe_eq(fe_sqr<0>(y), rhs);
+  if (!ok) atomicOr(flags, 2u);
+}
+
 }  // namespace bppp
 
 using namespace bppp;
@@ -211,19 +232,32 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
       (k && (!d_es || !d_responses_xy)) || (fn && !d_wit_norm) || (fl && !d_wit_lin) || (ninit && (!d_init_scalars || !d_init_points_xy)) || k > 30 ||
       batch >= (1u << 24) || nlen >= (1u << 24) || llen >= (1u << 24))
     return fail(ctx, BPPP_ERR_ARG, "nl_verify_batch: bad arguments");
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   hipSetDevice(ctx->device);
   hipStream_t st = ctx->stream;
   const size_t per = ninit + 2 * k, shared = nlen + llen + 1, T = shared + batch * per;
   const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
   const size_t maxlen = nlen > llen ? nlen : llen;
   // scratch (separate from the MSM workspace, which msm_run carves from ctx->ws)
-  size_t words = (batch * 2 * (k ? k : 1) + batch + (size_t)ntiles * maxlen + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16;
+  size_t words = (batch * 2 * (k ? k : 1) + batch + (size_t)ntiles * maxlen + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16 + 64;
   { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
   uint32_t *buf = (uint32_t *)ctx->ws2;
   uint32_t *fac = buf, *qf2 = fac + batch * 2 * (k ? k : 1) * 8, *partial = qf2 + batch * 8, *partial2 = partial + (size_t)ntiles * maxlen * 8, *gs = partial2 + (size_t)SUM_GROUPS * maxlen * 8,
-           *sc = gs + batch * 8, *pts = sc + (T + 32) * 8;
+           *sc = gs + batch * 8, *pts = sc + (T + 32) * 8, *flags = pts + T * 16;
   int rc = BPPP_OK;
   do {
+    // untrusted inputs first (asynchronous; the flag word is read after the MSM has synchronised the stream)
+    if (hipMemsetAsync(flags, 0, 4, st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: memset"); break; }
+    auto vs = [&](const void *p, uint64_t n, int nz) {
+      if (n) k_vb_validate_scalars<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, nz, flags);
+    };
+    auto vp = [&](const void *p, uint64_t n) {
+      if (n) k_vb_validate_points<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, flags);
+    };
+    vs(d_rho, batch, 1); vs(d_q, batch, 0); vs(d_sp, batch, 0); vs(d_pub_norm, batch * nlen, 0); vs(d_pub_lin_c, batch * llen, 0);
+    vs(d_pub_lin_x, batch * llen, 0); vs(d_es, batch * k, 0); vs(d_wit_norm, batch * fn, 0); vs(d_wit_lin, batch * fl, 0);
+    vs(d_init_scalars, batch * ninit, 0);
+    vp(d_g_xy, 1); vp(d_norm_g_xy, nlen); vp(d_lin_h_xy, llen); vp(d_init_points_xy, batch * ninit); vp(d_responses_xy, batch * 2 * k);
     k_vb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_q, (const uint32_t *)d_es, (uint32_t)batch, (int)k, fac, qf2);
     if (nlen) {
       if (k >= 2) k_vb_shared4<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
@@ -254,6 +288,14 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
       he = hipMemcpy2DAsync(pts + (shared + ninit) * 16, per * 64, d_responses_xy, 2 * k * 64, 2 * k * 64, batch, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: assembling the MSM failed"); break; }
     rc = msm_run(ctx, sc, pts, T, 1, 1, 0, out_xy);
+    if (rc) break;
+    uint32_t hflags = 0;
+    if (hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: reading the validation flags failed"); break;
+    }
+    if (hflags & 2u) rc = fail(ctx, BPPP_ERR_POINT, "nl_verify_batch: a point is not on the curve");
+    else if (hflags & 1u) rc = fail(ctx, BPPP_ERR_ARG, "nl_verify_batch: a scalar is not canonical (>= n)");
+    else if (hflags & 4u) rc = fail(ctx, BPPP_ERR_ARG, "nl_verify_batch: a weight rho is zero (it would drop its proof from the combination)");
   } while (0);
   hipStreamSynchronize(st);
   return rc;

@@ -1,0 +1,579 @@
+// rp.hip — the range-proof layer end to end: encoded proofs in, accept / reject out, for a whole batch, on the device.
+//
+// Replaces, for B proofs of ONE typed-reciprocal setup, the reference's unit of verification work:
+//   decodeProof' / decodeCommitments          src/RangeProof.hs:68-85, src/Encoding.hs:92-128   (x-only points, packed signs)
+//   verifyM of RangeProof                     src/RangeProof.hs:103-105
+//     verifyTRRPM                             src/RangeProof/TypedReciprocal.hs:447-467
+//       its three oracle calls                :459-462, through ZKPT.oracle (src/ZKP.hs:96-101) and shaOracle (app/Main.hs:64-80)
+//     verifyBPM                               src/Bulletproof.hs:370-378 (one more oracle call per round, :374)
+// with the random-linear-combination batch check the reference only sketches (TODOs at TypedReciprocal.hs:469-472,
+// RangeProof.hs:103-106; semantics SURVEY.md 8(c)).
+//
+// Pipeline (all kernels on the context's stream, nothing but the final 64-byte point and the status words return to the host):
+//   k_rp_decode_points   one lane per encoded point: Binary (Prime p) x (4 big-endian words, least significant first), toP,
+//                        pointX (square root by the (p+1)/4 addition chain), fromXWithSign (Encoding.hs:97-103)
+//   k_rp_decode_scalars  the final witness scalars of the proof file, toP
+//   k_rp_text            one workgroup per proof: `show x <> show y` of every commitment in transcript order (newest first),
+//                        compacted into one text per proof + the offset of every commitment
+//   k_rp_hash            one lane per (proof, oracle output): SHA-256 of  tag <> show n <> show (length ps) <> text suffix,
+//                        digest -> field by Binary (Prime p); 7 + rounds challenges per proof and the batch weight rho
+//   k_trrp_public        (csrc/trrp.hip) verifyTRRPM's scalar work from the challenges
+//   bppp_nl_verify_batch_device (csrc/nlbatch.hip) challenge expansion, shared-basis merge, ONE combined MSM
+//
+// The same file holds the setup handle (`bppp_rp`: ranges, layout, basis resident in HBM) and, further down, the batch prover.
+#include <string.h>
+#include <string>
+#include <vector>
+#include "ctx.hpp"
+#include "ec.hip.h"
+#include "hostmath.hpp"
+#include "rpsetup.hpp"
+#include "sha256.hip.h"
+
+struct bppp_trrp;
+
+namespace bppp {
+
+// ------------------------------------------------------------------------------------------------ decode
+// Binary (Prime p) get (Encoding.hs:76-80): limb i = big-endian 64-bit word at bytes 8i..8i+7, least-significant limb first;
+// toP reduces (one conditional subtraction: the value is < 2^256 < 2m)
+template <int MOD> BPPP_DI fe load_field_be(const uint8_t *p) {
+  fe v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint8_t *q = p + 8 * i;
+    v.v[2 * i + 1] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    v.v[2 * i] = ((uint32_t)q[4] << 24) | ((uint32_t)q[5] << 16) | ((uint32_t)q[6] << 8) | q[7];
+  }
+  fe t;
+  uint32_t br = raw_sub(t, v, modulus<MOD>());
+#pragma unroll
+  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  return v;
+}
+
+struct RpDims {
+  uint32_t nr, k, fn, fl;            // ranges (input commitments), rounds, final witness lengths
+  uint32_t coms_bytes, proof_bytes;  // per-proof file sizes
+  uint32_t text_stride;              // bytes reserved per proof for the transcript text (multiple of 16)
+};
+__host__ __device__ inline uint32_t rp_npts(const RpDims &D) { return 4 + D.nr + 2 * D.k; }
+
+// Point t of a proof IN TRANSCRIPT ORDER (newest first, the order shaOracle's final call sees, src/ZKP.hs:98):
+//   t < 2k            the argument's responses, last round first  = bpComs of the proof file (RangeProof.hs:60-66)
+//   2k <= t < 2k + 4  blCom, rCom, dmCom, mCom                      = rpComs of the proof file
+//   else              the input commitments                         = the commitments file
+// Output: responses to resp[b][t], the rest to init[b][...] in the order blCom : rCom : dmCom : mCom : nComs.
+__global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batch, const uint8_t *__restrict__ coms, const uint8_t *__restrict__ proofs,
+                                                         uint32_t *__restrict__ init_pts, uint32_t *__restrict__ resp_pts, uint32_t *__restrict__ bad) {
+  const uint32_t npts = rp_npts(D);
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)batch * npts) return;
+  const uint32_t b = (uint32_t)(g / npts), t = (uint32_t)(g % npts);
+  const uint8_t *signs, *xs;
+  uint32_t idx;
+  const uint32_t nproof_pts = 4 + 2 * D.k;
+  if (t < 2 * D.k + 4) {
+    const uint8_t *pf = proofs + (size_t)b * D.proof_bytes + (size_t)(D.fn + D.fl) * 32;
+    signs = pf; xs = pf + (nproof_pts + 7) / 8;
+    idx = t < 2 * D.k ? 4 + t : t - 2 * D.k;
+  } else {
+    const uint8_t *cf = coms + (size_t)b * D.coms_bytes;
+    signs = cf; xs = cf + (D.nr + 7) / 8;
+    idx = t - 2 * D.k - 4;
+  }
+  const bool want_big = (signs[idx >> 3] >> (idx & 7)) & 1;
+  const fe xe = load_field_be<0>(xs + (size_t)idx * 32);
+  const fq x = fq_from_fe(xe);
+  fq seven = fq_zero(); seven.n[0] = 7;
+  const fq rhs = fq_add(fq_mul(fq_sqr(x), x), seven);         // magnitude 2
+  fq y = fq_sqrt_candidate(rhs);
+  const bool ok = fq_normalizes_to_zero(fq_sub<2>(fq_sqr(y), rhs));
+  y = fq_normalize(y);
+  // fromXWithSign (Encoding.hs:97-103): keep the root whose (y > p - y) equals the sign bit
+  const fe ye = fq_to_fe(y), yn = fe_neg<0>(ye);
+  fe d;
+  const bool y_big = raw_sub(d, yn, ye) != 0;                  // -y < y
+  aff r; r.x = x; r.y = (y_big != want_big) ? fq_from_fe(yn) : y;
+  if (!ok) { r = aff_inf(); atomicOr(bad + b, 1u); }
+  uint32_t *out = t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16
+                              : init_pts + ((size_t)b * (4 + D.nr) + (t - 2 * D.k)) * 16;
+  aff_store(out, r);
+}
+
+// final witness scalars: norm part then linear part (encodeProof', RangeProof.hs:60-66)
+__global__ void __launch_bounds__(64) k_rp_decode_scalars(RpDims D, uint32_t batch, const uint8_t *__restrict__ proofs, uint32_t *__restrict__ wit_norm,
+                                                          uint32_t *__restrict__ wit_lin) {
+  const uint32_t ns = D.fn + D.fl;
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)batch * ns) return;
+  const uint32_t b = (uint32_t)(g / ns), i = (uint32_t)(g % ns);
+  const fe v = load_field_be<1>(proofs + (size_t)b * D.proof_bytes + (size_t)i * 32);
+  if (i < D.fn) fe_store(wit_norm + ((size_t)b * D.fn + i) * 8, v);
+  else fe_store(wit_lin + ((size_t)b * D.fl + (i - D.fn)) * 8, v);
+}
+
+// ------------------------------------------------------------------------------------------------ transcript text
+// `show` of a field element = its decimal integer.  v is split into nine 9-digit chunks (10^81 > 2^256) by repeated division.
+struct Dec { uint32_t ch[9]; uint32_t top, len; };
+BPPP_DI uint32_t ndigits9(uint32_t v) {
+  return v >= 100000000u ? 9 : v >= 10000000u ? 8 : v >= 1000000u ? 7 : v >= 100000u ? 6 : v >= 10000u ? 5 : v >= 1000u ? 4 : v >= 100u ? 3 : v >= 10u ? 2 : 1;
+}
+BPPP_DI Dec dec_convert(fe v) {
+  Dec d;
+#pragma unroll
+  for (int c = 0; c < 9; c++) {
+    uint64_t rem = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+      const uint64_t cur = (rem << 32) | v.v[i];
+      const uint64_t q = cur / 1000000000ull;
+      v.v[i] = (uint32_t)q; rem = cur - q * 1000000000ull;
+    }
+    d.ch[c] = (uint32_t)rem;
+  }
+  d.top = 0;
+#pragma unroll
+  for (int c = 1; c < 9; c++) if (d.ch[c]) d.top = c;
+  uint32_t tv = 0;
+#pragma unroll
+  for (int c = 0; c < 9; c++) if ((uint32_t)c == d.top) tv = d.ch[c];
+  d.len = 9 * d.top + ndigits9(tv);
+  return d;
+}
+// writes the d.len characters so that they END at `end` (exclusive); returns the start
+BPPP_DI uint8_t *dec_write_backward(const Dec &d, uint8_t *end) {
+  uint8_t *p = end;
+#pragma unroll
+  for (int c = 0; c < 9; c++) {
+    if ((uint32_t)c > d.top) continue;
+    uint32_t v = d.ch[c];
+    const uint32_t n = (uint32_t)c == d.top ? ndigits9(v) : 9u;
+    for (uint32_t j = 0; j < n; j++) { *--p = (uint8_t)('0' + v % 10u); v /= 10u; }
+  }
+  return p;
+}
+
+BPPP_DI const uint32_t *rp_point_ptr(const RpDims &D, const uint32_t *init_pts, const uint32_t *resp_pts, uint32_t b, uint32_t t) {
+  return t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16 : init_pts + ((size_t)b * (4 + D.nr) + (t - 2 * D.k)) * 16;
+}
+
+// One workgroup per proof.  Pass 1: the text length of every point (x digits + y digits); exclusive scan; pass 2: the digits
+// again, written at the point's offset.  text_off[b][t] (t <= npts) are byte offsets into text[b]; a proof whose points did not all
+// decode gets "0"s for the missing ones — its hashes are never used (bad[b] rejects it).
+__global__ void __launch_bounds__(256) k_rp_text(RpDims D, const uint32_t *__restrict__ init_pts, const uint32_t *__restrict__ resp_pts,
+                                                 uint8_t *__restrict__ text, uint32_t *__restrict__ text_off) {
+  extern __shared__ uint32_t lens[];            // [npts + 1] lengths, then offsets
+  __shared__ uint32_t wsum[4];
+  const uint32_t npts = rp_npts(D), b = blockIdx.x, tid = threadIdx.x;
+  for (uint32_t t = tid; t < npts; t += 256) {
+    const uint32_t *p = rp_point_ptr(D, init_pts, resp_pts, b, t);
+    lens[t] = dec_convert(fe_load(p)).len + dec_convert(fe_load(p + 8)).len;
+  }
+  __syncthreads();
+  // exclusive scan of lens[0..npts): every thread owns a contiguous chunk
+  const uint32_t per = (npts + 255) / 256, lo = min(npts, tid * per), hi = min(npts, lo + per);
+  uint32_t s = 0;
+  for (uint32_t t = lo; t < hi; t++) s += lens[t];
+  uint32_t inc = s;
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if ((int)(tid & 63) >= d) inc += o; }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  uint32_t run = inc - s;
+  for (uint32_t w = 0; w < (tid >> 6); w++) run += wsum[w];
+  __syncthreads();
+  for (uint32_t t = lo; t < hi; t++) { const uint32_t l = lens[t]; lens[t] = run; run += l; }
+  if (tid == 255) lens[npts] = run;             // total (thread 255's chunk ends the list, possibly empty)
+  __syncthreads();
+  uint8_t *tx = text + (size_t)b * D.text_stride;
+  for (uint32_t t = tid; t <= npts; t += 256) text_off[(size_t)b * (npts + 1) + t] = lens[t];
+  for (uint32_t t = tid; t < npts; t += 256) {
+    const uint32_t *p = rp_point_ptr(D, init_pts, resp_pts, b, t);
+    const Dec dx = dec_convert(fe_load(p)), dy = dec_convert(fe_load(p + 8));
+    uint8_t *end = tx + lens[t] + dx.len + dy.len;
+    end = dec_write_backward(dy, end);
+    dec_write_backward(dx, end);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ hashing
+// Hash h of a proof (h < 7 + k):  0,1,2 -> e, x, r0   first oracle call  [dmCom, mCom] ++ nComs      (TypedReciprocal.hs:459)
+//                                 3,4,5 -> q, x', r1  second call, rCom prepended                    (:460)
+//                                 6     -> t          third call, blCom prepended                    (:462)
+//                                 7 + j -> e of round j + 1 (first round first), (X, R) prepended    (Bulletproof.hs:374)
+// The hashed message is  header_h <> text[b][off[start_h] ..]  with header_h = tag <> show n <> show (length ps), identical for
+// every proof (precomputed on the host, HashPlan).  Hash 7 + k is the batch weight rho_b = H(seed <> b) (b = 0: rho = 1).
+static constexpr int RP_HDR_MAX = 64;
+struct HashPlan { uint8_t hdr[RP_HDR_MAX]; uint32_t hlen, start_pt, out_slot; };   // out_slot: index into ch[7] (< 7) or 7 + index into es[k]
+
+BPPP_DI uint32_t load_unaligned_be32(const uint8_t *p) {
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+  const uint32_t sh = (uint32_t)(a & 3) * 8;
+  const uint64_t two = ((uint64_t)q[1] << 32) | q[0];
+  return __builtin_bswap32((uint32_t)(two >> sh));
+}
+
+__global__ void __launch_bounds__(64) k_rp_hash(RpDims D, uint32_t batch, uint32_t nhash, const HashPlan *__restrict__ plan, const uint8_t *__restrict__ text,
+                                                const uint32_t *__restrict__ text_off, const uint8_t *__restrict__ seed, uint32_t *__restrict__ ch,
+                                                uint32_t *__restrict__ es, uint32_t *__restrict__ rho) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)batch * (nhash + 1)) return;
+  // hashes of one KIND sit in one wavefront (equal lengths, the same header): g = h * batch + b
+  const uint32_t h = (uint32_t)(g / batch), b = (uint32_t)(g % batch);
+  uint32_t st[8];
+  sha256_init(st);
+  uint32_t w[16];
+  if (h == nhash) {
+    // rho_b: one block, seed (32 bytes) <> b as 8 little-endian bytes, padded
+    if (b == 0) { fe one = fe_one(); fe_store(rho, one); return; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+    w[8] = __builtin_bswap32(b); w[9] = 0; w[10] = 0x80000000u;
+    w[11] = w[12] = w[13] = w[14] = 0; w[15] = 40 * 8;
+    sha256_compress(st, w);
+    fe v; sha256_digest_to_limbs(st, v.v);
+    fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
+    for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+    if (fe_is_zero(v)) v = fe_one();
+    fe_store(rho + (size_t)b * 8, v);
+    return;
+  }
+  const HashPlan *pl = plan + h;
+  const uint32_t npts = rp_npts(D), hlen = pl->hlen;
+  const uint32_t *off = text_off + (size_t)b * (npts + 1);
+  const uint32_t t0 = off[pl->start_pt], t1 = off[npts];
+  const uint8_t *tx = text + (size_t)b * D.text_stride + t0;     // the suffix of the proof's text this call hashes
+  const uint32_t mlen = hlen + (t1 - t0);
+  const uint32_t nblk = (mlen + 9 + 63) / 64;
+  for (uint32_t blk = 0; blk < nblk; blk++) {
+    const uint32_t p0 = blk * 64;
+    if (p0 >= hlen && p0 + 64 <= mlen) {
+      const uint8_t *src = tx + (p0 - hlen);
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = load_unaligned_be32(src + 4 * i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t p = p0 + 4 * i + j;
+          uint32_t byte = 0;
+          if (p < hlen) byte = pl->hdr[p];
+          else if (p < mlen) byte = tx[p - hlen];
+          else if (p == mlen) byte = 0x80;
+          word = (word << 8) | byte;
+        }
+        w[i] = word;
+      }
+      if (blk == nblk - 1) { w[14] = 0; w[15] = mlen * 8; }     // mlen < 2^29 bytes
+    }
+    sha256_compress(st, w);
+  }
+  fe v; sha256_digest_to_limbs(st, v.v);
+  fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
+  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  const uint32_t slot = pl->out_slot;
+  if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
+  else fe_store(es + ((size_t)b * D.k + (slot - 7)) * 8, v);
+}
+
+}  // namespace bppp
+
+using namespace bppp;
+using bppp_host::U256;
+
+extern "C" {
+int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, size_t llen, size_t nranges, const uint32_t *pos_kind, const uint32_t *pos_range,
+                     const uint32_t *pos_slot, const uint32_t *pos_sym, const uint64_t *pos_coeff, const uint64_t *range_min, const uint32_t *range_assumed,
+                     size_t nsyms, const uint64_t *syms, const uint32_t *cs_slot, const uint32_t *cs_sym, size_t npub, const uint32_t *pub_is_out,
+                     const uint64_t *pub_amount, const uint32_t *pub_sym, bppp_trrp **out);
+void bppp_trrp_destroy(bppp_trrp *t);
+int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges, void *d_q, void *d_sp, void *d_pub_norm, void *d_pub_lin_c, void *d_init_scalars);
+}
+
+struct bppp_rp {
+  bppp_ctx *ctx = nullptr;
+  bppp_rps::Setup st;
+  bppp_trrp *tabs = nullptr;
+  std::string tag;
+  std::vector<uint64_t> h_g, h_G, h_H;          // the basis on the host (prover: commit inputs, argument start)
+  uint32_t *d_basis = nullptr;                  // [g (1) | G (nlen) | H (llen)] affine, resident in HBM
+  HashPlan *d_plan = nullptr;
+  uint32_t nhash = 0;
+  RpDims D{};
+  // grow-only verifier workspace and the staging buffer of the host-buffer entry point
+  void *work = nullptr; size_t work_bytes = 0;
+  void *stage = nullptr; size_t stage_bytes = 0;
+};
+
+namespace {
+
+std::string dec_str(uint64_t v) { return std::to_string(v); }
+
+int rp_build_tables(bppp_rp *rp) {
+  const bppp_rps::Setup &st = rp->st;
+  std::vector<uint32_t> kind, rng, slot, psym, cs_slot, cs_sym, pub_out, pub_sym, assumed;
+  std::vector<uint64_t> coeff, mins, syms, pub_amt;
+  std::vector<U256> sym_vals;
+  auto sym = [&](const U256 &v) -> uint32_t {
+    for (size_t i = 0; i < sym_vals.size(); i++) if (sym_vals[i] == v) return (uint32_t)i;
+    sym_vals.push_back(v);
+    for (int i = 0; i < 4; i++) syms.push_back(v.w[i]);
+    return (uint32_t)(sym_vals.size() - 1);
+  };
+  auto push = [](std::vector<uint64_t> &dst, const U256 &v) { for (int i = 0; i < 4; i++) dst.push_back(v.w[i]); };
+  for (const bppp_rps::Pos &p : st.pos) {
+    const uint32_t k = p.kind & 0xFFu;
+    kind.push_back(p.kind); rng.push_back(p.range);
+    slot.push_back(k == bppp_rps::POS_TYPING ? 0u : (uint32_t)st.slot_of(p.radix));
+    psym.push_back((k == bppp_rps::POS_INLINE && p.sym_small) ? sym(U256::from_u64(p.sym_small)) : bppp_rps::POS_NO_SYM);
+    push(coeff, p.coeff);
+  }
+  for (uint32_t b : st.m_bases)
+    for (uint32_t s = 1; s < b; s++) { cs_slot.push_back((uint32_t)st.slot_of(b)); cs_sym.push_back(sym(U256::from_u64(s))); }
+  for (const bppp_rps::RangeData &rd : st.rds) { push(mins, bppp_rps::u_mod_n(rd.lo)); assumed.push_back(rd.assumed ? 1u : 0u); }
+  for (const bppp_rps::PublicVT &pv : st.pubs) { pub_out.push_back(pv.is_output ? 1u : 0u); pub_sym.push_back(sym(pv.type)); push(pub_amt, pv.amount); }
+  auto p32 = [](std::vector<uint32_t> &v) { if (v.empty()) v.push_back(0); return v.data(); };
+  auto p64 = [](std::vector<uint64_t> &v) { if (v.empty()) v.assign(4, 0); return v.data(); };
+  const size_t nsyms = sym_vals.size();
+  return bppp_trrp_create(rp->ctx, 0, st.has_types ? 1 : 0, st.nlen, st.llen, st.rds.size(), p32(kind), p32(rng), p32(slot), p32(psym), p64(coeff), p64(mins),
+                          p32(assumed), nsyms, p64(syms), p32(cs_slot), p32(cs_sym), st.pubs.size(), p32(pub_out), p64(pub_amt), p32(pub_sym), &rp->tabs);
+}
+
+// header_h = tag <> show n <> show (length ps) for the 7 + k oracle outputs of a verification (see k_rp_hash)
+int rp_build_plan(bppp_rp *rp) {
+  const uint32_t k = rp->D.k, nr = rp->D.nr;
+  std::vector<HashPlan> plan;
+  auto add = [&](uint32_t n, uint32_t count, uint32_t start, uint32_t slot) -> bool {
+    HashPlan p; memset(&p, 0, sizeof p);
+    std::string h = rp->tag + dec_str(n) + dec_str(count);
+    if (h.size() > RP_HDR_MAX) return false;
+    memcpy(p.hdr, h.data(), h.size());
+    p.hlen = (uint32_t)h.size(); p.start_pt = start; p.out_slot = slot;
+    plan.push_back(p);
+    return true;
+  };
+  bool ok = true;
+  for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 2 + nr, 2 * k + 2, n - 1);          // e, x, r0
+  for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 3 + nr, 2 * k + 1, 3 + n - 1);      // q, x', r1
+  ok &= add(1, 4 + nr, 2 * k, 6);                                                    // t
+  for (uint32_t j = 1; j <= k; j++) ok &= add(1, 4 + nr + 2 * j, 2 * (k - j), 7 + (k - j));   // round j: es is LAST round first
+  if (!ok) return fail(rp->ctx, BPPP_ERR_ARG, "rp_create: oracle tag too long");
+  rp->nhash = (uint32_t)plan.size();
+  BPPP_HIP(rp->ctx, hipMalloc(&rp->d_plan, plan.size() * sizeof(HashPlan)));
+  BPPP_HIP(rp->ctx, hipMemcpy(rp->d_plan, plan.data(), plan.size() * sizeof(HashPlan), hipMemcpyHostToDevice));
+  return BPPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bppp_rp_destroy(bppp_rp *rp) {
+  if (!rp) return;
+  bppp_ctx *ctx = rp->ctx;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (rp->tabs) bppp_trrp_destroy(rp->tabs);
+  if (rp->d_basis) hipFree(rp->d_basis);
+  if (rp->d_plan) hipFree(rp->d_plan);
+  if (rp->work) hipFree(rp->work);
+  if (rp->stage) hipFree(rp->stage);
+  delete rp;
+  ctx_release(ctx);
+}
+
+int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_range *ranges, size_t nranges, const bppp_rp_public *pubs, size_t npub,
+                   const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out) {
+  if (!ctx || !out || ctx_closed(ctx)) return BPPP_ERR_ARG;
+  *out = nullptr;
+  if (!ranges || !nranges || (npub && !pubs) || !points_xy) return fail(ctx, BPPP_ERR_ARG, "rp_create: null argument");
+  if (flavour != 0) return fail(ctx, BPPP_ERR_ARG, "rp_create: only the norm-linear (NL) argument flavour has a batch path; use bppp_ip_* for IP");
+  if (nranges >= (1u << 20) || npub >= (1u << 20)) return fail(ctx, BPPP_ERR_ARG, "rp_create: too many ranges");
+  std::vector<bppp_rps::RangeData> rds(nranges);
+  std::string err;
+  for (size_t i = 0; i < nranges; i++) {
+    const bppp_rp_range &r = ranges[i];
+    if (!bppp_rps::make_range_data(r.base, U256::load(r.min), U256::load(r.max), (r.flags & BPPP_RP_SHARED) != 0, (r.flags & BPPP_RP_OUTPUT) != 0,
+                                  (r.flags & BPPP_RP_ASSUMED) != 0, rds[i], err))
+      return fail(ctx, BPPP_ERR_ARG, "rp_create: range " + std::to_string(i) + ": " + err);
+  }
+  std::vector<bppp_rps::PublicVT> pv(npub);
+  for (size_t i = 0; i < npub; i++) {
+    if (!bppp_host::scalars_canonical(pubs[i].type, 1) || !bppp_host::scalars_canonical(pubs[i].amount, 1))
+      return fail(ctx, BPPP_ERR_ARG, "rp_create: public type / amount not canonical");
+    pv[i] = bppp_rps::PublicVT{pubs[i].is_output != 0, U256::load(pubs[i].type), U256::load(pubs[i].amount)};
+  }
+  bppp_rp *rp = new bppp_rp();
+  rp->ctx = ctx; ctx_retain(ctx);
+  auto fill = [&]() -> int {
+    if (!bppp_rps::make_setup(has_types != 0, rds, pv, rp->st, err)) return fail(ctx, BPPP_ERR_ARG, "rp_create: " + err);
+    const bppp_rps::Setup &st = rp->st;
+    // points = h : g : hs (linLen) ++ gs (nrmLen)   (TypedReciprocal.hs:334, :348-349); h is not used by the proof
+    if (npoints < 2 + st.llen + st.nlen) return fail(ctx, BPPP_ERR_ARG, "rp_create: not enough basis points (need 2 + linLen + nrmLen)");
+    if (!bppp_host::points_on_curve(points_xy, 2 + st.llen + st.nlen)) return fail(ctx, BPPP_ERR_POINT, "rp_create: a basis point is not on the curve");
+    rp->h_g.assign(points_xy + 8, points_xy + 16);
+    rp->h_H.assign(points_xy + 16, points_xy + 16 + 8 * st.llen);
+    rp->h_G.assign(points_xy + 16 + 8 * st.llen, points_xy + 16 + 8 * (st.llen + st.nlen));
+    rp->tag = oracle_tag ? oracle_tag : "";
+    hipSetDevice(ctx->device);
+    BPPP_HIP(ctx, hipMalloc(&rp->d_basis, (1 + st.nlen + st.llen) * 64));
+    BPPP_HIP(ctx, hipMemcpy(rp->d_basis, rp->h_g.data(), 64, hipMemcpyHostToDevice));
+    BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16, rp->h_G.data(), st.nlen * 64, hipMemcpyHostToDevice));
+    BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16 * (1 + st.nlen), rp->h_H.data(), st.llen * 64, hipMemcpyHostToDevice));
+    RpDims &D = rp->D;
+    D.nr = (uint32_t)st.rds.size(); D.k = (uint32_t)st.rounds; D.fn = (uint32_t)st.fn; D.fl = (uint32_t)st.fl;
+    D.coms_bytes = (D.nr + 7) / 8 + 32 * D.nr;
+    const uint32_t npp = 4 + 2 * D.k;
+    D.proof_bytes = 32 * (D.fn + D.fl) + (npp + 7) / 8 + 32 * npp;
+    D.text_stride = ((rp_npts(D) * 2 * 78 + 15) & ~15u) + 16;      // 78 = decimal digits of 2^256, +16: aligned over-read of the last word
+    int rc = rp_build_tables(rp); if (rc) return rc;
+    return rp_build_plan(rp);
+  };
+  if (int rc = fill()) { bppp_rp_destroy(rp); return rc; }
+  *out = rp;
+  return BPPP_OK;
+}
+
+int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out) {
+  if (!rp || !out) return BPPP_ERR_ARG;
+  const bppp_rps::Setup &st = rp->st;
+  out->nranges = st.rds.size(); out->norm_len = st.nlen; out->lin_len = st.llen; out->rounds = st.rounds;
+  out->final_norm = st.fn; out->final_lin = st.fl; out->coms_bytes = rp->D.coms_bytes; out->proof_bytes = rp->D.proof_bytes;
+  out->challenges_per_proof = 7 + st.rounds;
+  return BPPP_OK;
+}
+
+// grow-only device workspace of the verifier; returns the carved pointers through `cv`
+static int rp_ensure_work(bppp_rp *rp, size_t bytes) {
+  if (bytes <= rp->work_bytes) return BPPP_OK;
+  bppp_ctx *ctx = rp->ctx;
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rp->work) BPPP_HIP(ctx, hipFree(rp->work));
+  rp->work = nullptr; rp->work_bytes = 0;
+  BPPP_HIP(ctx, hipMalloc(&rp->work, bytes + bytes / 8));
+  rp->work_bytes = bytes + bytes / 8;
+  return BPPP_OK;
+}
+
+int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit, const void *d_g_xy,
+                                const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q, const void *d_sp, const void *d_pub_norm,
+                                const void *d_pub_lin_c, const void *d_pub_lin_x, const void *d_es, const void *d_wit_norm, const void *d_wit_lin,
+                                const void *d_init_scalars, const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
+
+int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
+                                uint32_t *proof_status, uint64_t *challenges_out) {
+  if (!rp || !accept) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = rp->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
+  *accept = 0;
+  if (!batch) { *accept = 1; return BPPP_OK; }
+  if (!d_coms_files || !d_proof_files || !seed || batch >= (1u << 22)) return fail(ctx, BPPP_ERR_ARG, "rp_verify_batch: bad arguments");
+  hipSetDevice(ctx->device);
+  hipStream_t st = ctx->stream;
+  const bppp_rps::Setup &S = rp->st;
+  const RpDims D = rp->D;
+  const size_t B = batch, nlen = S.nlen, llen = S.llen, k = S.rounds, ninit = 4 + D.nr, npts = rp_npts(D);
+  size_t need = 0;
+  uint32_t *init_pts = nullptr, *resp_pts = nullptr, *wit_norm = nullptr, *wit_lin = nullptr, *text_off = nullptr, *ch = nullptr, *es = nullptr, *rho = nullptr,
+           *q = nullptr, *sp = nullptr, *pub_norm = nullptr, *pub_lin_c = nullptr, *pub_lin_x = nullptr, *init_sc = nullptr, *bad = nullptr;
+  uint8_t *text = nullptr, *d_seed = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    Carver cv(pass ? rp->work : nullptr, rp->work_bytes);
+    init_pts = cv.take<uint32_t>(B * ninit * 16); resp_pts = cv.take<uint32_t>(B * 2 * k * 16 + 16);
+    wit_norm = cv.take<uint32_t>(B * D.fn * 8 + 8); wit_lin = cv.take<uint32_t>(B * D.fl * 8 + 8);
+    text = cv.take<uint8_t>(B * (size_t)D.text_stride + 64); text_off = cv.take<uint32_t>(B * (npts + 1));
+    ch = cv.take<uint32_t>(B * 7 * 8); es = cv.take<uint32_t>(B * k * 8 + 8); rho = cv.take<uint32_t>(B * 8);
+    q = cv.take<uint32_t>(B * 8); sp = cv.take<uint32_t>(B * 8); pub_norm = cv.take<uint32_t>(B * nlen * 8); pub_lin_c = cv.take<uint32_t>(B * llen * 8);
+    pub_lin_x = cv.take<uint32_t>(B * llen * 8); init_sc = cv.take<uint32_t>(B * ninit * 8); bad = cv.take<uint32_t>(B);
+    d_seed = cv.take<uint8_t>(32);
+    if (!pass) { need = cv.off; int rc = rp_ensure_work(rp, need); if (rc) return rc; }
+  }
+  BPPP_HIP(ctx, hipMemsetAsync(bad, 0, B * 4, st));
+  BPPP_HIP(ctx, hipMemsetAsync(pub_lin_x, 0, B * llen * 32, st));       // the public linear vector of these proofs is zero (TypedReciprocal.hs:466)
+  BPPP_HIP(ctx, hipMemcpyAsync(d_seed, seed, 32, hipMemcpyHostToDevice, st));
+  const uint64_t np = (uint64_t)B * npts, ns = (uint64_t)B * (D.fn + D.fl);
+  k_rp_decode_points<<<dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_coms_files, (const uint8_t *)d_proof_files, init_pts,
+                                                                           resp_pts, bad);
+  if (ns) k_rp_decode_scalars<<<dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_proof_files, wit_norm, wit_lin);
+  k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
+  const uint64_t nh = (uint64_t)B * (rp->nhash + 1);
+  k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, d_seed, ch, es, rho);
+  BPPP_HIP(ctx, hipGetLastError());
+  int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
+  if (rc) return rc;
+  uint64_t out_xy[8];
+  rc = bppp_nl_verify_batch_device(ctx, B, nlen, llen, k, D.fn, D.fl, ninit, rp->d_basis, rp->d_basis + 16, rp->d_basis + 16 * (1 + nlen), rho, q, sp, pub_norm,
+                                   pub_lin_c, pub_lin_x, es, wit_norm, wit_lin, init_sc, init_pts, resp_pts, out_xy);
+  if (rc) return rc;
+  // decode failures (an x with no point on the curve): Nothing in the reference (decodeCommitments, Encoding.hs:119-128)
+  std::vector<uint32_t> hbad(B);
+  BPPP_HIP(ctx, hipMemcpyAsync(hbad.data(), bad, B * 4, hipMemcpyDeviceToHost, st));
+  if (challenges_out) {
+    BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out, (7 + k) * 32, ch, 7 * 32, 7 * 32, B, hipMemcpyDeviceToHost, st));
+    if (k) BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out + 28, (7 + k) * 32, es, k * 32, k * 32, B, hipMemcpyDeviceToHost, st));
+  }
+  BPPP_HIP(ctx, hipStreamSynchronize(st));
+  bool any_bad = false;
+  for (size_t b = 0; b < B; b++) any_bad |= hbad[b] != 0;
+  auto is_inf = [](const uint64_t *p) { uint64_t o = 0; for (int i = 0; i < 8; i++) o |= p[i]; return o == 0; };
+  const bool whole = is_inf(out_xy);
+  *accept = (whole && !any_bad) ? 1 : 0;
+  if (!proof_status) return BPPP_OK;
+  for (size_t b = 0; b < B; b++) proof_status[b] = hbad[b] ? BPPP_RP_MALFORMED : BPPP_RP_VALID;
+  if (whole) return BPPP_OK;
+  // The combination is not the identity: find the culprits by bisection.  Every per-proof array is [batch][...], so a sub-batch
+  // [lo, hi) is the same call on offset pointers (any non-zero weights do); a malformed proof decodes to infinity points and is
+  // simply another failing member.  O(f log B) combined MSMs for f bad proofs.
+  struct Range { size_t lo, hi; bool known_bad; };
+  std::vector<Range> todo;
+  todo.push_back(Range{0, B, true});
+  while (!todo.empty()) {
+    const Range r = todo.back(); todo.pop_back();
+    bool ok = false;
+    if (!r.known_bad) {
+      const size_t o = r.lo, n = r.hi - r.lo;
+      rc = bppp_nl_verify_batch_device(ctx, n, nlen, llen, k, D.fn, D.fl, ninit, rp->d_basis, rp->d_basis + 16, rp->d_basis + 16 * (1 + nlen), rho + o * 8, q + o * 8,
+                                       sp + o * 8, pub_norm + o * nlen * 8, pub_lin_c + o * llen * 8, pub_lin_x + o * llen * 8, es + o * k * 8, wit_norm + o * D.fn * 8,
+                                       wit_lin + o * D.fl * 8, init_sc + o * ninit * 8, init_pts + o * ninit * 16, resp_pts + o * 2 * k * 16, out_xy);
+      if (rc) return rc;
+      ok = is_inf(out_xy);
+    }
+    if (ok) continue;
+    if (r.hi - r.lo == 1) { if (proof_status[r.lo] == BPPP_RP_VALID) proof_status[r.lo] = BPPP_RP_INVALID; continue; }
+    const size_t mid = r.lo + (r.hi - r.lo) / 2;
+    todo.push_back(Range{r.lo, mid, false}); todo.push_back(Range{mid, r.hi, false});
+  }
+  return BPPP_OK;
+}
+
+int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, const uint8_t *proof_files, const uint8_t seed[32], int *accept,
+                         uint32_t *proof_status, uint64_t *challenges_out) {
+  if (!rp || !accept) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = rp->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
+  if (!batch) { *accept = 1; return BPPP_OK; }
+  if (!coms_files || !proof_files) return fail(ctx, BPPP_ERR_ARG, "rp_verify_batch: null input");
+  hipSetDevice(ctx->device);
+  const size_t cb = batch * (size_t)rp->D.coms_bytes, pb = batch * (size_t)rp->D.proof_bytes;
+  const size_t cbp = (cb + 255) & ~(size_t)255;
+  if (cbp + pb + 256 > rp->stage_bytes) {      // a private grow-only buffer: the context's scratch serves bppp_nl_verify_batch_device
+    BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rp->stage) BPPP_HIP(ctx, hipFree(rp->stage));
+    rp->stage = nullptr; rp->stage_bytes = 0;
+    BPPP_HIP(ctx, hipMalloc(&rp->stage, cbp + pb + 256));
+    rp->stage_bytes = cbp + pb + 256;
+  }
+  void *stage = rp->stage;
+  int rc = BPPP_OK;
+  if (hipMemcpyAsync(stage, coms_files, cb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync((char *)stage + cbp, proof_files, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    rc = fail(ctx, BPPP_ERR_HIP, "rp_verify_batch: upload failed");
+  if (!rc) rc = bppp_rp_verify_batch_device(rp, batch, stage, (char *)stage + cbp, seed, accept, proof_status, challenges_out);
+  hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+
+}  // extern "C"

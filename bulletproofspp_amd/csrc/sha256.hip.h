@@ -1,0 +1,112 @@
+// sha256.hip.h — SHA-256 (FIPS 180-4) for the Fiat-Shamir transcript, on the device and on the host.
+//
+// The reference's oracle is `hash = decode . fromStrict . SHA.hash` (app/Main.hs:64-65, cryptohash-sha256) over
+// `show n <> show (length ps) <> foldMap (coords . toA) ps` (shaOracle, app/Main.hs:75-80): every oracle call hashes the WHOLE
+// transcript again, newest commitments first (src/ZKP.hs:96-101).  A 64by64 verification makes 15 such hashes of ~10-13 KB each
+// (~2800 compression-function calls per proof): with the group arithmetic on the GPU that hashing is what is left, so it runs
+// there too — one lane per (proof, oracle output), the transcript text staged once per proof in HBM (csrc/rp.hip).
+//
+// One compression function, `sha256_compress`, compiled for both sides (the host side serves the prover, whose oracle calls
+// are sequential).  The digest -> field decode of Binary (Prime p) (src/Encoding.hs:75-79: four big-endian 64-bit words,
+// least-significant first) is `sha256_digest_to_limbs`.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BPPP_HD __host__ __device__ __forceinline__
+#else
+#define BPPP_HD inline
+#endif
+
+namespace bppp {
+
+BPPP_HD uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+BPPP_HD void sha256_init(uint32_t h[8]) {
+  h[0] = 0x6a09e667u; h[1] = 0xbb67ae85u; h[2] = 0x3c6ef372u; h[3] = 0xa54ff53au;
+  h[4] = 0x510e527fu; h[5] = 0x9b05688cu; h[6] = 0x1f83d9abu; h[7] = 0x5be0cd19u;
+}
+
+// one 64-byte block, given as 16 big-endian words; the round constants are literals so that neither side needs a table in memory
+BPPP_HD void sha256_compress(uint32_t h[8], uint32_t w[16]) {
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#define SHA_RND(i, K)                                                                                            \
+  {                                                                                                              \
+    uint32_t wi;                                                                                                 \
+    if ((i) < 16) wi = w[(i)];                                                                                   \
+    else {                                                                                                       \
+      const uint32_t w15 = w[((i) + 1) & 15], w2 = w[((i) + 14) & 15];                                           \
+      const uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);                                     \
+      const uint32_t s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);                                      \
+      wi = w[(i) & 15] = w[(i) & 15] + s0 + w[((i) + 9) & 15] + s1;                                              \
+    }                                                                                                            \
+    const uint32_t t1 = hh + (sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + (K) + wi; \
+    const uint32_t t2 = (sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));    \
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;                                          \
+  }
+  SHA_RND(0, 0x428a2f98u) SHA_RND(1, 0x71374491u) SHA_RND(2, 0xb5c0fbcfu) SHA_RND(3, 0xe9b5dba5u)
+  SHA_RND(4, 0x3956c25bu) SHA_RND(5, 0x59f111f1u) SHA_RND(6, 0x923f82a4u) SHA_RND(7, 0xab1c5ed5u)
+  SHA_RND(8, 0xd807aa98u) SHA_RND(9, 0x12835b01u) SHA_RND(10, 0x243185beu) SHA_RND(11, 0x550c7dc3u)
+  SHA_RND(12, 0x72be5d74u) SHA_RND(13, 0x80deb1feu) SHA_RND(14, 0x9bdc06a7u) SHA_RND(15, 0xc19bf174u)
+  SHA_RND(16, 0xe49b69c1u) SHA_RND(17, 0xefbe4786u) SHA_RND(18, 0x0fc19dc6u) SHA_RND(19, 0x240ca1ccu)
+  SHA_RND(20, 0x2de92c6fu) SHA_RND(21, 0x4a7484aau) SHA_RND(22, 0x5cb0a9dcu) SHA_RND(23, 0x76f988dau)
+  SHA_RND(24, 0x983e5152u) SHA_RND(25, 0xa831c66du) SHA_RND(26, 0xb00327c8u) SHA_RND(27, 0xbf597fc7u)
+  SHA_RND(28, 0xc6e00bf3u) SHA_RND(29, 0xd5a79147u) SHA_RND(30, 0x06ca6351u) SHA_RND(31, 0x14292967u)
+  SHA_RND(32, 0x27b70a85u) SHA_RND(33, 0x2e1b2138u) SHA_RND(34, 0x4d2c6dfcu) SHA_RND(35, 0x53380d13u)
+  SHA_RND(36, 0x650a7354u) SHA_RND(37, 0x766a0abbu) SHA_RND(38, 0x81c2c92eu) SHA_RND(39, 0x92722c85u)
+  SHA_RND(40, 0xa2bfe8a1u) SHA_RND(41, 0xa81a664bu) SHA_RND(42, 0xc24b8b70u) SHA_RND(43, 0xc76c51a3u)
+  SHA_RND(44, 0xd192e819u) SHA_RND(45, 0xd6990624u) SHA_RND(46, 0xf40e3585u) SHA_RND(47, 0x106aa070u)
+  SHA_RND(48, 0x19a4c116u) SHA_RND(49, 0x1e376c08u) SHA_RND(50, 0x2748774cu) SHA_RND(51, 0x34b0bcb5u)
+  SHA_RND(52, 0x391c0cb3u) SHA_RND(53, 0x4ed8aa4au) SHA_RND(54, 0x5b9cca4fu) SHA_RND(55, 0x682e6ff3u)
+  SHA_RND(56, 0x748f82eeu) SHA_RND(57, 0x78a5636fu) SHA_RND(58, 0x84c87814u) SHA_RND(59, 0x8cc70208u)
+  SHA_RND(60, 0x90befffau) SHA_RND(61, 0xa4506cebu) SHA_RND(62, 0xbef9a3f7u) SHA_RND(63, 0xc67178f2u)
+#undef SHA_RND
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// `decode` of the 32 digest bytes through Binary (Prime p) (src/Encoding.hs:75-79): limb i (64 bits, i = 0 least significant)
+// is the big-endian word at bytes 8i .. 8i+7, i.e. (h[2i] << 32) | h[2i+1].  Output: 8 little-endian 32-bit limbs of the
+// 256-bit integer, NOT yet reduced (toP reduces; the caller subtracts the modulus once — the value is < 2^256 < 2 m).
+BPPP_HD void sha256_digest_to_limbs(const uint32_t h[8], uint32_t v[8]) {
+  for (int i = 0; i < 4; i++) { v[2 * i] = h[2 * i + 1]; v[2 * i + 1] = h[2 * i]; }
+}
+
+// ---- host-side streaming interface (prover transcripts, rho derivation on the host when needed)
+struct Sha256 {
+  uint32_t h[8];
+  uint8_t buf[64];
+  uint64_t len;
+  Sha256() { reset(); }
+  void reset() { sha256_init(h); len = 0; }
+  void block(const uint8_t *p) {
+    uint32_t w[16];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    sha256_compress(h, w);
+  }
+  void update(const void *data, size_t n) {
+    const uint8_t *p = (const uint8_t *)data;
+    size_t fill = (size_t)(len & 63);
+    len += n;
+    if (fill) {
+      size_t take = 64 - fill < n ? 64 - fill : n;
+      memcpy(buf + fill, p, take); p += take; n -= take; fill += take;
+      if (fill < 64) return;
+      block(buf);
+    }
+    for (; n >= 64; p += 64, n -= 64) block(p);
+    if (n) memcpy(buf, p, n);
+  }
+  void finish(uint32_t out_h[8]) {
+    uint64_t bits = len * 8;
+    uint8_t pad[72] = {0x80};
+    size_t fill = (size_t)(len & 63), padlen = (fill < 56 ? 56 - fill : 120 - fill);
+    update(pad, padlen);
+    uint8_t lb[8];
+    for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    for (int i = 0; i < 8; i++) out_h[i] = h[i];
+  }
+};
+
+}  // namespace bppp

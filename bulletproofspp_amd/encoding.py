@@ -15,7 +15,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
-from .rangeproof import N, Point, RangeProof
+from .rangeproof import N, Point, RangeProof, decode_field
 
 P = 2**256 - 2**32 - 977
 
@@ -27,7 +27,7 @@ def put_field(v: int) -> bytes:
 
 def get_field(b: bytes, modulus: int) -> int:
     """Binary (Prime p) get (:76-80): toP reduces"""
-    return sum(int.from_bytes(b[8 * i:8 * i + 8], "big") << (64 * i) for i in range(4)) % modulus
+    return decode_field(b, modulus)
 
 
 def encode_commitments(pts: Sequence[Point]) -> bytes:
@@ -87,6 +87,34 @@ def decode_proof(num_rp_coms: int, rounds: int, final_lens: Tuple[int, int], n_c
     rp_coms, bp_coms = coms[:num_rp_coms], coms[num_rp_coms:]
     resps = [(bp_coms[2 * i], bp_coms[2 * i + 1]) for i in range(rounds)]
     return RangeProof(list(rp_coms) + list(n_coms), resps, scs[:num_nrm], scs[num_nrm:])
+
+
+def encode_wide(pts: Sequence[Point]) -> bytes:
+    """The points file of the CLI: `encodeFile "points.bin" $ take n $ WE <$> ps` (app/Main.hs:260-262) with the `WideEncoding`
+    instance put (WE p) = put x <> put y (app/Main.hs:89-98).  The value encoded is a LIST, so Data.Binary's list instance
+    applies: an 8-byte big-endian element count, then every point as both coordinates in full (Binary (Prime p), 32 bytes
+    each) — no sign bytes."""
+    if any(p is None for p in pts):
+        raise ValueError("the point at infinity has no encoding")
+    return len(pts).to_bytes(8, "big") + b"".join(put_field(p[0]) + put_field(p[1]) for p in pts)
+
+
+def decode_wide(data: bytes, check: bool = True) -> List[Point]:
+    """`map getWE <$> decodeFile` (app/Main.hs:260): count prefix, then 64 bytes per point, x then y.  `fromA (A x y)`
+    (app/Main.hs:94-98) does not check the curve equation; `check=True` (default) does and raises ValueError."""
+    if len(data) < 8:
+        raise ValueError("points file too short")
+    n = int.from_bytes(data[:8], "big")
+    if len(data) < 8 + 64 * n:
+        raise ValueError("points file too short")
+    out: List[Point] = []
+    for i in range(n):
+        o = 8 + 64 * i
+        x, y = get_field(data[o:o + 32], P), get_field(data[o + 32:o + 64], P)
+        if check and (y * y - x * x * x - 7) % P:
+            raise ValueError("point %d is not on the curve" % i)
+        out.append((x, y))
+    return out
 
 
 def gpu_lift_x(gpu):

@@ -25,6 +25,13 @@ OracleN = Callable[[List[Point], int], List[int]]     # whole transcript (newest
 RandFn = Callable[[int], int]                         # counter -> scalar (ZKPT's `h n`, src/ZKP.hs:88-92)
 
 
+def decode_field(b: bytes, modulus: int) -> int:
+    """`decode` through Binary (Prime p) (src/Encoding.hs:75-79): four big-endian 64-bit words, LEAST-significant word first,
+    reduced by toP.  This is how the reference turns a SHA-256 digest into a field element (`hash = decode . SHA.hash`,
+    app/Main.hs:64-65) and how it reads scalars and coordinates from files."""
+    return sum(int.from_bytes(b[8 * i:8 * i + 8], "big") << (64 * i) for i in range(4)) % modulus
+
+
 # ----------------------------------------------------------------------------- small helpers (src/Utils.hs)
 def inv(a: int) -> int:
     a %= N
@@ -414,9 +421,14 @@ class Transcript:
         return v
 
 
-def sha256_oracle(tag: bytes = b"bppp") -> OracleN:
-    """Stand-in for shaOracle (app/Main.hs:75-80): challenge n = SHA-256(tag, n, #commitments, decimal coordinates of the whole
-    transcript).  The exact `Show` text the reference hashes cannot be confirmed offline — documented choice."""
+def sha256_oracle(tag: bytes = b"") -> OracleN:
+    """shaOracle (app/Main.hs:75-80): challenge n = hash (show n <> show (length ps) <> foldMap (coords . toA) ps) with
+    coords (A x y) = show x <> show y and hash = decode . SHA-256 — the digest read as a field element by Binary (Prime p)
+    (decode_field).  `show` of a field element is taken to be its plain decimal integer (as FastPrime's instance prints it,
+    src/Data/Field/Galois/FastPrime.hs:129-130); that text format of the third-party `Prime` type cannot be confirmed offline
+    (SURVEY.md 8c), so the hash INPUT is parity-unpinned while the digest decode follows the source.  `tag` (default empty =
+    the reference's input) is an optional domain-separation prefix for tests that want distinct oracles.  The native
+    counterpart (same bytes in, same challenge out) is csrc/sha256.hip.h + bppp_rp_* (include/bppp.h)."""
     enc: Dict[Point, bytes] = {}
 
     def one(p: Point) -> bytes:
@@ -427,13 +439,14 @@ def sha256_oracle(tag: bytes = b"bppp") -> OracleN:
 
     def fn(cs: List[Point], count: int) -> List[int]:
         body = b"".join(one(p) for p in cs)
-        return [int.from_bytes(hashlib.sha256(tag + str(n).encode() + str(len(cs)).encode() + body).digest(), "big") % N for n in range(1, count + 1)]
+        return [decode_field(hashlib.sha256(tag + str(n).encode() + str(len(cs)).encode() + body).digest(), N) for n in range(1, count + 1)]
     return fn
 
 
 def hash_to_scalar(prefix: bytes) -> RandFn:
-    """hashToScalar rn . show (app/Main.hs:83-84, :189) — the prover's deterministic randomness."""
-    return lambda n: int.from_bytes(hashlib.sha256(prefix + str(n).encode()).digest(), "big") % N
+    """hashToScalar rn . show (app/Main.hs:83-84, :189) — the prover's deterministic randomness: hash (prefix <> show n), the
+    digest decoded by Binary (Prime p) as everywhere else (decode_field)."""
+    return lambda n: decode_field(hashlib.sha256(prefix + str(n).encode()).digest(), N)
 
 
 # ----------------------------------------------------------------------------- setup (TypedReciprocal.hs:332-359)
@@ -807,6 +820,91 @@ class DeviceVerifierTables:
                  "init_scalars": cut(host["init"], self.ninit, b)} for b in range(B)]
 
 
+# ----------------------------------------------------------------------------- the native range-proof layer (csrc/rp.hip)
+class NativeRangeProofs:
+    """One setup registered with the library (bppp_rp_create): ranges, layout and basis live on the device; batches of ENCODED
+    proofs (the reference's commitments / proof files, bulletproofspp_amd.encoding) are verified end to end there — decoding,
+    all SHA-256 transcript hashing (the CLI's shaOracle), verifyTRRPM's scalars, challenge expansion and one combined MSM."""
+
+    def __init__(self, gpu, st: SetupTRRP, oracle_tag: bytes = b"", h: Point = None):
+        import ctypes as C
+        from .capi import RP_ASSUMED, RP_OUTPUT, RP_SHARED, RpPublic, RpRange, RpShape, int_to_limbs, points_to_array
+        if st.flavour != "NL":
+            raise ValueError("the native batch paths exist for the norm-linear argument flavour")
+        self.gpu, self.st, self.h = gpu, st, None
+        rng = (RpRange * len(st.rds))()
+        for r, rd in zip(rng, st.rds):
+            r.base = rd.base
+            r.flags = (RP_SHARED if rd.is_shared else 0) | (RP_OUTPUT if rd.is_output else 0) | (RP_ASSUMED if rd.is_assumed else 0)
+            r.min[:] = [int(v) for v in int_to_limbs(rd.lo)]
+            r.max[:] = [int(v) for v in int_to_limbs(rd.hi)]
+        pubs = (RpPublic * max(len(st.pub_vt), 1))()
+        for p_, (io, ty, v) in zip(pubs, st.pub_vt):
+            p_.is_output = 1 if io else 0
+            p_.type[:] = [int(x) for x in int_to_limbs(ty % N)]
+            p_.amount[:] = [int(x) for x in int_to_limbs(v % N)]
+        pts = points_to_array([h if h is not None else st.g, st.g] + list(st.hs) + list(st.gs))
+        hnd = C.c_void_p()
+        rc = gpu.lib.bppp_rp_create(gpu.h, 0, int(st.has_types), C.cast(rng, C.c_void_p), len(st.rds), C.cast(pubs, C.c_void_p), len(st.pub_vt),
+                                    C.c_void_p(pts.ctypes.data), pts.shape[0], oracle_tag if oracle_tag else None, C.byref(hnd))
+        gpu._check(rc, "bppp_rp_create")
+        self.h = hnd
+        gpu._adopt(self)
+        shp = RpShape()
+        gpu._check(gpu.lib.bppp_rp_info(self.h, C.byref(shp)), "bppp_rp_info")
+        self.shape = {n: int(getattr(shp, n)) for n, _ in RpShape._fields_}
+        if (self.shape["norm_len"], self.shape["lin_len"], self.shape["rounds"], (self.shape["final_norm"], self.shape["final_lin"])) != \
+                (st.nrm_len, st.lin_len, st.rounds, tuple(st.final_lens)):
+            raise RuntimeError("native setup disagrees with the host setup: %r" % (self.shape,))
+
+    def close(self):
+        if self.h:
+            self.gpu.lib.bppp_rp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def verify_batch(self, coms_files: Sequence[bytes], proof_files: Sequence[bytes], seed: bytes, want_status: bool = False, want_challenges: bool = False):
+        """bppp_rp_verify_batch on host byte strings: returns accept, or (accept, status list, challenges per proof) as asked"""
+        import ctypes as C
+        import numpy as np
+        B = len(proof_files)
+        if len(coms_files) != B or len(seed) != 32:
+            raise ValueError("one commitments file per proof and a 32-byte seed are required")
+        if any(len(c) != self.shape["coms_bytes"] for c in coms_files) or any(len(p_) != self.shape["proof_bytes"] for p_ in proof_files):
+            return (False, [2] * B, None) if (want_status or want_challenges) else False       # wrong length: malformed, as decodeProof' returns Nothing
+        cb, pb = np.frombuffer(b"".join(coms_files), dtype=np.uint8), np.frombuffer(b"".join(proof_files), dtype=np.uint8)
+        return self._verify(self.gpu.lib.bppp_rp_verify_batch, B, C.c_void_p(cb.ctypes.data), C.c_void_p(pb.ctypes.data), seed, want_status, want_challenges, (cb, pb))
+
+    def verify_batch_device(self, batch: int, d_coms: int, d_proofs: int, seed: bytes, want_status: bool = False, want_challenges: bool = False):
+        import ctypes as C
+        return self._verify(self.gpu.lib.bppp_rp_verify_batch_device, batch, C.c_void_p(d_coms), C.c_void_p(d_proofs), seed, want_status, want_challenges, None)
+
+    def _verify(self, fn, B, pc, pp, seed, want_status, want_challenges, keep):
+        import ctypes as C
+        import numpy as np
+        from .capi import array_to_scalars
+        acc = C.c_int(0)
+        status = np.zeros(max(B, 1), dtype=np.uint32) if want_status else None
+        nch = self.shape["challenges_per_proof"]
+        chal = np.zeros((max(B, 1) * nch, 4), dtype=np.uint64) if want_challenges else None
+        sd = np.frombuffer(seed, dtype=np.uint8)
+        rc = fn(self.h, B, pc, pp, C.c_void_p(sd.ctypes.data), C.byref(acc), C.c_void_p(status.ctypes.data) if want_status else None,
+                C.c_void_p(chal.ctypes.data) if want_challenges else None)
+        self.gpu._check(rc, "bppp_rp_verify_batch")
+        if not (want_status or want_challenges):
+            return bool(acc.value)
+        chs = None
+        if want_challenges:
+            flat = array_to_scalars(chal)
+            chs = [(flat[b * nch:b * nch + 7], flat[b * nch + 7:(b + 1) * nch]) for b in range(B)]
+        return bool(acc.value), ([int(v) for v in status[:B]] if want_status else None), chs
+
+
 # ----------------------------------------------------------------------------- schema files (app/Parse.hs, app/Main.hs)
 def approx_log_w(n: int) -> int:
     """approxLogW (app/Parse.hs:202-206): the default base for a range of width n"""
@@ -855,12 +953,13 @@ def inputs_from_witness(witness_json: Sequence[dict], random_seed: bytes = b"def
 
 
 def basis_points(seed: bytes, count: int) -> List[Point]:
-    """getPoints (app/Main.hs:68-72): x = SHA-256(seed ++ show n) as a big-endian integer mod p for n = 0, 1, ...; kept when
-    x^3 + 7 is a square; the root taken is the even one (the reference's `sr` choice cannot be confirmed offline)."""
+    """getPoints (app/Main.hs:68-72): x = hash (seed <> show n) for n = 0, 1, ... — the digest decoded by Binary (Prime p)
+    (decode_field, Encoding.hs:75-79) — kept when x^3 + 7 is a square (pointX); the root taken is the even one (the
+    reference's `sr` choice cannot be confirmed offline)."""
     p = 2**256 - 2**32 - 977
     out, n = [], 0
     while len(out) < count:
-        x = int.from_bytes(hashlib.sha256(seed + str(n).encode()).digest(), "big") % p
+        x = decode_field(hashlib.sha256(seed + str(n).encode()).digest(), p)
         n += 1
         rhs = (x * x * x + 7) % p
         y = pow(rhs, (p + 1) // 4, p)

@@ -20,6 +20,14 @@
  * stream and is not thread-safe; use one context per thread/GPU.
  *
  * Every function returns BPPP_OK (0) or a negative BPPP_ERR_* code; bppp_last_error() gives text.
+ *
+ * Handle lifetime: every child handle (bppp_nl, bppp_nlb, bppp_ip, bppp_trrp, bppp_rp) holds a reference on its context.
+ * bppp_ctx_destroy closes the context (further calls through it or its children fail with BPPP_ERR_ARG) and drops the caller's
+ * reference; the stream and workspaces are released when the last child is destroyed, so finalisers may run in any order.
+ *
+ * Untrusted input: the verifier entry points (bppp_nl_verify, bppp_ip_verify, bppp_nl_verify_batch_device, bppp_rp_verify_batch*)
+ * check that proof-supplied scalars are canonical (< n) and points are on the curve (or the infinity encoding) and return
+ * BPPP_ERR_ARG / BPPP_ERR_POINT otherwise; the batch weights rho must be non-zero.
  */
 #ifndef BPPP_H
 #define BPPP_H
@@ -35,7 +43,7 @@ extern "C" {
 #define BPPP_ERR_ARG (-1)      /* bad length / null pointer / unsupported parameter */
 #define BPPP_ERR_HIP (-2)      /* a HIP runtime call or kernel launch failed */
 #define BPPP_ERR_NODEVICE (-3) /* no gfx950 GPU visible */
-#define BPPP_ERR_POINT (-4)    /* validation requested and a point is not on the curve */
+#define BPPP_ERR_POINT (-4)    /* a proof-supplied point is not on the curve (verifier entry points validate their inputs) */
 
 typedef struct bppp_ctx bppp_ctx;
 
@@ -251,6 +259,58 @@ int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, siz
 void bppp_trrp_destroy(bppp_trrp *t);
 int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges, void *d_q, void *d_sp, void *d_pub_norm, void *d_pub_lin_c,
                             void *d_init_scalars);
+
+/* ---- the range-proof layer end to end: encoded proofs in, accept / reject out ------------------
+ * `bppp_rp` is one typed-reciprocal setup (setup, src/RangeProof/TypedReciprocal.hs:332-359) resident on the device: the ranges
+ * with their digit coefficients (makeRangeData :103-120), the Phase1 layout (:133-169), the round count (optimalWitnessSize,
+ * src/Bulletproof/NormArgument.hs:165-178) and the REGISTERED BASIS g, G, H — uploaded once, referenced by every later call
+ * (G, H are fixed per setup, TypedReciprocal.hs:348-359).  Argument flavour: 0 = norm-linear (the batch paths exist for this one).
+ *
+ * bppp_rp_create: `ranges` as the schema gives them (app/Parse.hs:125-172): base, min, max (plain 256-bit integers, max exclusive
+ * as in makeRangeData), flags.  `pubs`: the public (isOutput, type, amount) triples.  `points_xy` = h : g : hs ++ gs, the stream the
+ * CLI takes from getPoints (app/Main.hs:68-72, :260); at least 2 + lin_len + norm_len points (validated: on the curve).
+ * `oracle_tag` (may be NULL = the reference's input) is prepended to every hashed message (domain separation for tests).
+ *
+ * The Fiat-Shamir oracle of these entry points is the CLI's shaOracle (app/Main.hs:64-80) computed natively: challenge n =
+ * decode (SHA-256 (tag <> show n <> show (length ps) <> foldMap (show x <> show y) ps)) over the WHOLE transcript, newest first
+ * (src/ZKP.hs:96-101); `show` of a coordinate = its decimal integer (parity of that text with galois-field's Show instance is
+ * unpinned), `decode` = Binary (Prime p): four big-endian 64-bit words, least significant first (Encoding.hs:75-79).
+ * The injectable-oracle route stays available: bppp_trrp_public_device + bppp_nl_verify_batch_device from caller-made challenges. */
+#define BPPP_RP_SHARED 1u  /* isShared  */
+#define BPPP_RP_OUTPUT 2u  /* isOutput  */
+#define BPPP_RP_ASSUMED 4u /* isAssumed */
+typedef struct bppp_rp_range { uint32_t base; uint32_t flags; uint64_t min[4]; uint64_t max[4]; } bppp_rp_range;
+typedef struct bppp_rp_public { uint32_t is_output; uint32_t reserved; uint64_t type[4]; uint64_t amount[4]; } bppp_rp_public;
+typedef struct bppp_rp_shape {
+  size_t nranges, norm_len, lin_len, rounds, final_norm, final_lin;
+  size_t coms_bytes;            /* the commitments file of one proof: sign bytes + 32 per input commitment (Encoding.hs:130-134) */
+  size_t proof_bytes;           /* the proof file: final witness scalars, sign bytes, 4 + 2*rounds x coordinates (RangeProof.hs:60-66) */
+  size_t challenges_per_proof;  /* 7 + rounds */
+} bppp_rp_shape;
+typedef struct bppp_rp bppp_rp;
+int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_range *ranges, size_t nranges, const bppp_rp_public *pubs, size_t npub,
+                   const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out);
+void bppp_rp_destroy(bppp_rp *rp);
+int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out);
+
+/* Batch verification, end to end: for `batch` proofs of this setup, given as the reference's FILES — coms_files [batch][coms_bytes],
+ * proof_files [batch][proof_bytes] — decodeProof (src/RangeProof.hs:68-85, src/Encoding.hs:97-128: x-only points, square roots and
+ * sign selection on the device), verifyM (src/RangeProof.hs:103-105): verifyTRRPM with its three oracle calls
+ * (TypedReciprocal.hs:447-467) and verifyBPM with one per round (src/Bulletproof.hs:370-378), all SHA-256 on the device, then ONE
+ * combined MSM over sum_b rho_b T_b (rho_0 = 1, rho_b = decode(SHA-256(seed <> b)), `seed` = 32 bytes of the
+ * VERIFIER's randomness).  *accept = 1 iff every proof decodes and the combination is the identity.
+ * proof_status (may be NULL, [batch]): BPPP_RP_VALID / _INVALID / _MALFORMED (an x coordinate with no curve point: `Nothing` in
+ * the reference); when the batch is rejected the culprits are found by bisection over sub-batches (each a combined MSM).
+ * challenges_out (may be NULL, [batch][7 + rounds][4]): (e, x, r0, q, x', r1, t) then the argument's challenges LAST ROUND FIRST
+ * (src/Bulletproof.hs:374) — what the injected-oracle route would have been given; for parity tests.
+ * _device: the files are already in HBM (the timed configuration of bench.py); the host variant uploads them first. */
+#define BPPP_RP_VALID 0u
+#define BPPP_RP_INVALID 1u
+#define BPPP_RP_MALFORMED 2u
+int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, const uint8_t *proof_files, const uint8_t seed[32], int *accept,
+                         uint32_t *proof_status, uint64_t *challenges_out);
+int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
+                                uint32_t *proof_status, uint64_t *challenges_out);
 
 /* ---- harness utility: pointX of getPoints (app/Main.hs:68-72) -------------------------------
  * For each candidate x (n x 4 uint64 in HBM) writes the affine point (x, y) with y the EVEN root of

@@ -81,3 +81,44 @@ def test_proof_sizes_of_the_examples(name, rp_coms, points, scalars):
     size = 32 * scalars + (points + 7) // 8 + 32 * points
     if name == "64bit":
         assert size == 418        # 10 points + 3 scalars = 416 B (the paper's figure) + 2 sign bytes
+
+
+def test_digest_to_field_limb_order():
+    """`hash = decode . SHA.hash` (app/Main.hs:64-65) reads the 32 digest bytes through Binary (Prime p) (Encoding.hs:75-79):
+    four big-endian Word64, least-significant FIRST — not one big-endian 256-bit integer."""
+    import hashlib
+    d = bytes(range(1, 33))
+    want = (0x0102030405060708 | 0x090A0B0C0D0E0F10 << 64 | 0x1112131415161718 << 128 | 0x191A1B1C1D1E1F20 << 192)
+    assert RP.decode_field(d, 2**256) == want
+    assert RP.decode_field(d, O.N) == want % O.N != int.from_bytes(d, "big") % O.N
+    # the oracle, the prover's randomness and the basis stream all decode their digests this way
+    dg = hashlib.sha256(b"1" + b"0").digest()
+    assert RP.sha256_oracle()([], 1) == [RP.decode_field(dg, O.N)]
+    assert RP.hash_to_scalar(b"seed")(7) == RP.decode_field(hashlib.sha256(b"seed7").digest(), O.N)
+    x0 = RP.basis_points(b"test points", 1)[0][0]
+    n = 0
+    while True:
+        x = RP.decode_field(hashlib.sha256(b"test points" + str(n).encode()).digest(), O.P)
+        if pow((x**3 + 7) % O.P, (O.P - 1) // 2, O.P) == 1:
+            break
+        n += 1
+    assert x0 == x
+
+
+def test_wide_encoding_points_file():
+    """points.bin (app/Main.hs:89-98, :260-262): Data.Binary list = 8-byte big-endian count, then x ++ y in full per point."""
+    pts = O.hash_points(b"wide", 3)
+    data = E.encode_wide(pts)
+    assert len(data) == 8 + 3 * 64
+    assert data[:8] == bytes([0, 0, 0, 0, 0, 0, 0, 3])
+    assert data[8:40] == E.put_field(pts[0][0]) and data[40:72] == E.put_field(pts[0][1])
+    assert E.decode_wide(data) == pts
+    assert E.decode_wide(data + b"junk") == pts
+    with pytest.raises(ValueError):
+        E.decode_wide(data[:-1])
+    bad = bytearray(data); bad[-1] ^= 1
+    with pytest.raises(ValueError):
+        E.decode_wide(bytes(bad))
+    assert len(E.decode_wide(bytes(bad), check=False)) == 3
+    with pytest.raises(ValueError):
+        E.encode_wide([None])
