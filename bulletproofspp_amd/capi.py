@@ -28,7 +28,7 @@ SYMBOLS = [
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
-    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device",
+    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_prove_batch",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.bppp_rp_info.argtypes = [vp, vp]
     lib.bppp_rp_verify_batch.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp]
     lib.bppp_rp_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp]
+    lib.bppp_rp_prove_batch.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, vp]
     lib.bppp_profile_enable.argtypes = [vp, i]
     lib.bppp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]
     return lib

@@ -29,8 +29,7 @@
 #include "hostmath.hpp"
 #include "rpsetup.hpp"
 #include "sha256.hip.h"
-
-struct bppp_trrp;
+#include "rp_internal.hpp"
 
 namespace bppp {
 
@@ -51,13 +50,6 @@ template <int MOD> BPPP_DI fe load_field_be(const uint8_t *p) {
   for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
   return v;
 }
-
-struct RpDims {
-  uint32_t nr, k, fn, fl;            // ranges (input commitments), rounds, final witness lengths
-  uint32_t coms_bytes, proof_bytes;  // per-proof file sizes
-  uint32_t text_stride;              // bytes reserved per proof for the transcript text (multiple of 16)
-};
-__host__ __device__ inline uint32_t rp_npts(const RpDims &D) { return 4 + D.nr + 2 * D.k; }
 
 // Point t of a proof IN TRANSCRIPT ORDER (newest first, the order shaOracle's final call sees, src/ZKP.hs:98):
 //   t < 2k            the argument's responses, last round first  = bpComs of the proof file (RangeProof.hs:60-66)
@@ -203,9 +195,6 @@ __global__ void __launch_bounds__(256) k_rp_text(RpDims D, const uint32_t *__res
 //                                 7 + j -> e of round j + 1 (first round first), (X, R) prepended    (Bulletproof.hs:374)
 // The hashed message is  header_h <> text[b][off[start_h] ..]  with header_h = tag <> show n <> show (length ps), identical for
 // every proof (precomputed on the host, HashPlan).  Hash 7 + k is the batch weight rho_b = H(seed <> b) (b = 0: rho = 1).
-static constexpr int RP_HDR_MAX = 64;
-struct HashPlan { uint8_t hdr[RP_HDR_MAX]; uint32_t hlen, start_pt, out_slot; };   // out_slot: index into ch[7] (< 7) or 7 + index into es[k]
-
 BPPP_DI uint32_t load_unaligned_be32(const uint8_t *p) {
   const uintptr_t a = (uintptr_t)p;
   const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
@@ -284,30 +273,6 @@ __global__ void __launch_bounds__(64) k_rp_hash(RpDims D, uint32_t batch, uint32
 using namespace bppp;
 using bppp_host::U256;
 
-extern "C" {
-int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, size_t llen, size_t nranges, const uint32_t *pos_kind, const uint32_t *pos_range,
-                     const uint32_t *pos_slot, const uint32_t *pos_sym, const uint64_t *pos_coeff, const uint64_t *range_min, const uint32_t *range_assumed,
-                     size_t nsyms, const uint64_t *syms, const uint32_t *cs_slot, const uint32_t *cs_sym, size_t npub, const uint32_t *pub_is_out,
-                     const uint64_t *pub_amount, const uint32_t *pub_sym, bppp_trrp **out);
-void bppp_trrp_destroy(bppp_trrp *t);
-int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges, void *d_q, void *d_sp, void *d_pub_norm, void *d_pub_lin_c, void *d_init_scalars);
-}
-
-struct bppp_rp {
-  bppp_ctx *ctx = nullptr;
-  bppp_rps::Setup st;
-  bppp_trrp *tabs = nullptr;
-  std::string tag;
-  std::vector<uint64_t> h_g, h_G, h_H;          // the basis on the host (prover: commit inputs, argument start)
-  uint32_t *d_basis = nullptr;                  // [g (1) | G (nlen) | H (llen)] affine, resident in HBM
-  HashPlan *d_plan = nullptr;
-  uint32_t nhash = 0;
-  RpDims D{};
-  // grow-only verifier workspace and the staging buffer of the host-buffer entry point
-  void *work = nullptr; size_t work_bytes = 0;
-  void *stage = nullptr; size_t stage_bytes = 0;
-};
-
 namespace {
 
 std::string dec_str(uint64_t v) { return std::to_string(v); }
@@ -381,6 +346,8 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->d_plan) hipFree(rp->d_plan);
   if (rp->work) hipFree(rp->work);
   if (rp->stage) hipFree(rp->stage);
+  if (rp->d_fixed) hipFree(rp->d_fixed);
+  if (rp->pwork) hipFree(rp->pwork);
   delete rp;
   ctx_release(ctx);
 }
@@ -421,8 +388,8 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
     hipSetDevice(ctx->device);
     BPPP_HIP(ctx, hipMalloc(&rp->d_basis, (1 + st.nlen + st.llen) * 64));
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis, rp->h_g.data(), 64, hipMemcpyHostToDevice));
-    BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16, rp->h_G.data(), st.nlen * 64, hipMemcpyHostToDevice));
-    BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16 * (1 + st.nlen), rp->h_H.data(), st.llen * 64, hipMemcpyHostToDevice));
+    BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16, rp->h_H.data(), st.llen * 64, hipMemcpyHostToDevice));
+    BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16 * (1 + st.llen), rp->h_G.data(), st.nlen * 64, hipMemcpyHostToDevice));
     RpDims &D = rp->D;
     D.nr = (uint32_t)st.rds.size(); D.k = (uint32_t)st.rounds; D.fn = (uint32_t)st.fn; D.fl = (uint32_t)st.fl;
     D.coms_bytes = (D.nr + 7) / 8 + 32 * D.nr;
@@ -505,7 +472,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
   int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
   if (rc) return rc;
   uint64_t out_xy[8];
-  rc = bppp_nl_verify_batch_device(ctx, B, nlen, llen, k, D.fn, D.fl, ninit, rp->d_basis, rp->d_basis + 16, rp->d_basis + 16 * (1 + nlen), rho, q, sp, pub_norm,
+  rc = bppp_nl_verify_batch_device(ctx, B, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho, q, sp, pub_norm,
                                    pub_lin_c, pub_lin_x, es, wit_norm, wit_lin, init_sc, init_pts, resp_pts, out_xy);
   if (rc) return rc;
   // decode failures (an x with no point on the curve): Nothing in the reference (decodeCommitments, Encoding.hs:119-128)
@@ -535,7 +502,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
     bool ok = false;
     if (!r.known_bad) {
       const size_t o = r.lo, n = r.hi - r.lo;
-      rc = bppp_nl_verify_batch_device(ctx, n, nlen, llen, k, D.fn, D.fl, ninit, rp->d_basis, rp->d_basis + 16, rp->d_basis + 16 * (1 + nlen), rho + o * 8, q + o * 8,
+      rc = bppp_nl_verify_batch_device(ctx, n, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho + o * 8, q + o * 8,
                                        sp + o * 8, pub_norm + o * nlen * 8, pub_lin_c + o * llen * 8, pub_lin_x + o * llen * 8, es + o * k * 8, wit_norm + o * D.fn * 8,
                                        wit_lin + o * D.fl * 8, init_sc + o * ninit * 8, init_pts + o * ninit * 16, resp_pts + o * 2 * k * 16, out_xy);
       if (rc) return rc;

@@ -1,0 +1,73 @@
+// rp_internal.hpp — declarations shared by the two halves of the range-proof layer (csrc/rp.hip: setup + batch verifier,
+// csrc/rpprove.hip: batch prover).
+#pragma once
+#include <string>
+#include <thread>
+#include <vector>
+#include "ctx.hpp"
+#include "hostmath.hpp"
+#include "rpsetup.hpp"
+
+struct bppp_trrp;
+struct bppp_nlb;
+
+namespace bppp {
+
+struct RpDims {
+  uint32_t nr, k, fn, fl;            // ranges (input commitments), rounds, final witness lengths
+  uint32_t coms_bytes, proof_bytes;  // per-proof file sizes
+  uint32_t text_stride;              // bytes reserved per proof for the transcript text (multiple of 16)
+};
+__host__ __device__ inline uint32_t rp_npts(const RpDims &D) { return 4 + D.nr + 2 * D.k; }
+
+static constexpr int RP_HDR_MAX = 64;
+struct HashPlan { uint8_t hdr[RP_HDR_MAX]; uint32_t hlen, start_pt, out_slot; };   // out_slot: index into ch[7] (< 7) or 7 + index into es[k]
+
+
+// f(lo, hi) on disjoint ranges covering [0, n), one host thread each (at most 16: the GPU box's CPU share per GPU)
+template <class F> static void rp_parallel(size_t n, F f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 4);
+  if (nt <= 1) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+  for (auto &x : th) x.join();
+}
+
+int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
+
+}  // namespace bppp
+
+extern "C" {
+int bppp_trrp_create(bppp_ctx *ctx, int flavour, int has_types, size_t nlen, size_t llen, size_t nranges, const uint32_t *pos_kind, const uint32_t *pos_range,
+                     const uint32_t *pos_slot, const uint32_t *pos_sym, const uint64_t *pos_coeff, const uint64_t *range_min, const uint32_t *range_assumed,
+                     size_t nsyms, const uint64_t *syms, const uint32_t *cs_slot, const uint32_t *cs_sym, size_t npub, const uint32_t *pub_is_out,
+                     const uint64_t *pub_amount, const uint32_t *pub_sym, bppp_trrp **out);
+void bppp_trrp_destroy(bppp_trrp *t);
+int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges, void *d_q, void *d_sp, void *d_pub_norm, void *d_pub_lin_c, void *d_init_scalars);
+}
+
+
+struct bppp_rp {
+  bppp_ctx *ctx = nullptr;
+  bppp_rps::Setup st;
+  bppp_trrp *tabs = nullptr;
+  std::string tag;
+  std::vector<uint64_t> h_g, h_G, h_H;          // the basis on the host (prover: commit inputs, argument start)
+  // the registered basis, affine, resident in HBM in commitRPW's term order (src/RangeProof/Internal.hs:45-50):
+  // [g (1) | H (llen) | G (nlen)]
+  uint32_t *d_basis = nullptr;
+  const uint32_t *d_g() const { return d_basis; }
+  const uint32_t *d_H() const { return d_basis + 16; }
+  const uint32_t *d_G() const { return d_basis + 16 * (1 + st.llen); }
+  bppp::HashPlan *d_plan = nullptr;
+  uint32_t nhash = 0;
+  bppp::RpDims D{};
+  // prover side (csrc/rpprove.hip): fixed-base window table of g, H[0], H[1] for the input commitments, prover workspace
+  uint32_t *d_fixed = nullptr;
+  void *pwork = nullptr; size_t pwork_bytes = 0;
+  // grow-only verifier workspace and the staging buffer of the host-buffer entry point
+  void *work = nullptr; size_t work_bytes = 0;
+  void *stage = nullptr; size_t stage_bytes = 0;
+};
+

@@ -1,0 +1,648 @@
+// rpprove.hip — batch prover of typed reciprocal range proofs: B proofs of one setup advance in lockstep.
+//
+// Replaces, with a leading batch dimension, proveM of RangeProof (src/RangeProof.hs:93-97):
+//   proveTRRPM                      src/RangeProof/TypedReciprocal.hs:399-446  (phases 1-3: digits and multiplicities, reciprocals,
+//                                   blinding — makePhase1s :133-161, makePhase2s :185-205, makeSharedCoeffs :213-216,
+//                                   makeErrorTerms :226-243, makePublicConsts :246-274, makeBpCoeffs :391-396)
+//   the blinding algebra            src/RangeProof/Internal.hs:118-196 (blindWitness, blindErrWitness, blindBlindingTerm)
+//   commitRPW                       src/RangeProof/Internal.hs:45-50
+//   proveBPM                        src/Bulletproof.hs:357-359 (the lockstep argument of csrc/nlb.hip)
+//   encodeProof'                    src/RangeProof.hs:60-66, src/Encoding.hs:130-134
+// Work split: every group operation is on the device — the input commitments through a fixed-base window table of (g, H0, H1)
+// (k_rp_commit_inputs: B x #ranges three-term commitments in one launch), the four range-proof commitments of all proofs as
+// batched MSMs over the registered basis (2B, B, B instances of 1 + linLen + nrmLen terms), the argument through bppp_nlb_*.
+// The per-proof field algebra (O(nrmLen) multiplications per phase) and the transcript hashing (the CLI's shaOracle and
+// hashToScalar, app/Main.hs:64-87) run on the host cores in parallel ranges.
+#include <string.h>
+#include <array>
+#include <atomic>
+#include <map>
+#include <string>
+#include <vector>
+#include "ec.hip.h"
+#include "rp_internal.hpp"
+#include "sha256.hip.h"
+
+namespace bppp {
+
+// ---- input commitments  v g + ty H0 + bl H1  (scalarPairRPW', src/RangeProof/Internal.hs:59-60) by fixed-base windows:
+// table[base][w][d - 1] = d 16^w P_base (affine), 3 x 64 x 15 points; a commitment is at most 192 mixed additions, no doubling.
+static constexpr int FB_BASES = 3, FB_WIN = 64, FB_DIG = 15;
+__global__ void __launch_bounds__(64) k_rp_commit_inputs(const uint32_t *__restrict__ table, const uint32_t *__restrict__ sc, uint64_t n,
+                                                         uint32_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  xyzz acc = xyzz_inf();
+  for (int base = 0; base < FB_BASES; base++) {
+    const fe s = fe_load(sc + (i * FB_BASES + base) * 8);
+    if (fe_is_zero(s)) continue;
+#pragma unroll 1
+    for (int w = 0; w < FB_WIN; w++) {
+      uint32_t limb = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if ((w >> 3) == k) limb = s.v[k];
+      const uint32_t d = (limb >> (4 * (w & 7))) & 15u;
+      if (d) xyzz_madd(acc, aff_load(table + ((size_t)(base * FB_WIN + w) * FB_DIG + (d - 1)) * 16));
+    }
+  }
+  aff_store(out + i * 16, xyzz_to_aff(acc));
+}
+
+}  // namespace bppp
+
+using namespace bppp;
+using namespace bppp_host;
+
+extern "C" {
+int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x, const uint64_t *norm_g_xy,
+                    size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out);
+void bppp_nlb_destroy(bppp_nlb *nlb);
+int bppp_nlb_round_commit(bppp_nlb *nlb, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy);
+int bppp_nlb_round_collapse(bppp_nlb *nlb, const uint64_t *es);
+int bppp_nlb_get_witness(bppp_nlb *nlb, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s);
+}
+
+namespace {
+
+using bppp_rps::Pos;
+using bppp_rps::RangeData;
+using bppp_rps::Setup;
+
+inline const Mod &MR() { return FR(); }
+inline U256 fa(const U256 &a, const U256 &b) { return madd(a, b, MR()); }
+inline U256 fs(const U256 &a, const U256 &b) { return msub(a, b, MR()); }
+inline U256 fm(const U256 &a, const U256 &b) { return mmul(a, b, MR()); }
+inline U256 fneg(const U256 &a) { return mneg(a, MR()); }
+inline U256 fdbl(const U256 &a) { return madd(a, a, MR()); }
+inline U256 fpow(U256 b, uint64_t e) { U256 r = U256::one(); while (e) { if (e & 1) r = fm(r, b); b = fm(b, b); e >>= 1; } return r; }
+inline U256 small(uint64_t v) { return U256::from_u64(v); }
+
+// `show` of a field element: its decimal integer (see sha256_oracle in rangeproof.py / shaOracle, app/Main.hs:75-80)
+void dec_append(std::string &out, U256 v) {
+  char buf[80];
+  int n = 0;
+  if (v.is_zero()) { out.push_back('0'); return; }
+  while (!v.is_zero()) {
+    uint64_t rem = 0;
+    v = bppp_rps::u_div64(v, 10000000000000000000ull, &rem);
+    const bool last = v.is_zero();
+    for (int k = 0; k < 19 && (rem || !last); k++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; }
+  }
+  while (n) out.push_back(buf[--n]);
+}
+void point_text(std::string &out, const uint64_t *xy) { dec_append(out, U256::load(xy)); dec_append(out, U256::load(xy + 4)); }
+
+// digest -> field by Binary (Prime p) (src/Encoding.hs:75-79), toP
+U256 digest_to_fr(const uint32_t h[8]) {
+  uint32_t v[8];
+  sha256_digest_to_limbs(h, v);
+  U256 r;
+  for (int i = 0; i < 4; i++) r.w[i] = ((uint64_t)v[2 * i + 1] << 32) | v[2 * i];
+  return bppp_rps::u_mod_n(r);
+}
+
+// hashToScalar prefix . show (app/Main.hs:83-87, :189): the prover's randomness, counter from 0 (ZKPT.random, src/ZKP.hs:88-92)
+struct Rnd {
+  const uint8_t *prefix; size_t plen; uint64_t n = 0;
+  U256 next() {
+    Sha256 h;
+    h.update(prefix, plen);
+    const std::string c = std::to_string(n++);
+    h.update(c.data(), c.size());
+    uint32_t d[8];
+    h.finish(d);
+    return digest_to_fr(d);
+  }
+};
+
+struct RPW { U256 sc; std::vector<U256> lin, nrm; };
+
+struct PState {
+  std::vector<U256> v, ty, bl;                 // inputs (amount, type, blinding) as field elements
+  std::vector<U256> d, mi, pv;                 // per norm position: digit (type for typing), inline multiplicity, ps (amount | 1)
+  std::vector<U256> ms_shared;                 // linLen - 6 shared multiplicities, bases in sorted order
+  RPW dm, m, r, blw;
+  std::vector<U256> u, vv, rr, cc;             // Phase2 (TypedReciprocal.hs:180-181)
+  U256 e, x, r0, q, xp, r1, t, e_inv, r0_inv, q0, q0_inv, r1_inv;
+  std::vector<U256> shared_cs;
+  U256 ns_sc, ns_ty, ns_bl;                    // sum_i inputCoeff_i * (v, ty, bl)_i
+  std::vector<std::string> groups;             // transcript text, one string per oracle call, oldest first
+  size_t npoints = 0;
+  Rnd rnd;
+  std::string err;
+};
+
+// shaOracle (app/Main.hs:75-80) over ZKPT's transcript (src/ZKP.hs:96-101): the new commitments go IN FRONT; output n hashes
+// tag <> show n <> show (length ps) <> text of the whole transcript, newest call first
+void oracle(const std::string &tag, PState &ps, const uint64_t *const *pts, size_t npts, int count, U256 *out) {
+  std::string g;
+  g.reserve(npts * 160);
+  for (size_t i = 0; i < npts; i++) point_text(g, pts[i]);
+  ps.groups.push_back(std::move(g));
+  ps.npoints += npts;
+  for (int n = 1; n <= count; n++) {
+    Sha256 h;
+    const std::string hdr = tag + std::to_string(n) + std::to_string(ps.npoints);
+    h.update(hdr.data(), hdr.size());
+    for (size_t k = ps.groups.size(); k-- > 0;) h.update(ps.groups[k].data(), ps.groups[k].size());
+    uint32_t d[8];
+    h.finish(d);
+    out[n - 1] = digest_to_fr(d);
+  }
+}
+
+// witnessTRRP (TypedReciprocal.hs:372-389) + makePhase1s (:133-161) + getDsMs (:74-80): fills d, mi, pv, ms_shared
+bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds) {
+  const size_t nr = st.rds.size();
+  ps.v.resize(nr); ps.ty.resize(nr); ps.bl.resize(nr);
+  std::vector<U256> amt(nr);
+  for (size_t i = 0; i < nr; i++) {
+    amt[i] = U256::load(amounts + 4 * i);
+    if (!scalars_canonical(types + 4 * i, 1) || !scalars_canonical(blinds + 4 * i, 1)) { ps.err = "type / blinding not canonical"; return false; }
+    ps.v[i] = bppp_rps::u_mod_n(amt[i]); ps.ty[i] = U256::load(types + 4 * i); ps.bl[i] = U256::load(blinds + 4 * i);
+  }
+  if (st.has_types) {                                     // amounts of every type must balance (:376-381)
+    std::vector<std::pair<U256, U256>> sums;
+    auto add = [&](const U256 &ty, const U256 &val, bool neg) {
+      for (auto &kv : sums) if (kv.first == ty) { kv.second = neg ? fs(kv.second, val) : fa(kv.second, val); return; }
+      sums.emplace_back(ty, neg ? fneg(val) : val);
+    };
+    for (const auto &pv : st.pubs) add(pv.type, pv.amount, pv.is_output);
+    for (size_t i = 0; i < nr; i++) add(ps.ty[i], ps.v[i], st.rds[i].output);
+    for (auto &kv : sums) if (!kv.second.is_zero()) { ps.err = "amounts of some type do not balance"; return false; }
+  }
+  ps.d.assign(st.nlen, U256::zero()); ps.mi.assign(st.nlen, U256::zero()); ps.pv.assign(st.nlen, U256::one());
+  ps.ms_shared.assign(st.llen - 6, U256::zero());
+  std::vector<size_t> base_off(st.m_bases.size(), 0);
+  for (size_t k = 1; k < st.m_bases.size(); k++) base_off[k] = base_off[k - 1] + st.m_bases[k - 1] - 1;
+  auto moff = [&](uint32_t base) { size_t k = std::lower_bound(st.m_bases.begin(), st.m_bases.end(), base) - st.m_bases.begin(); return base_off[k]; };
+  size_t p = 0;
+  if (st.has_types)
+    for (size_t i = 0; i < nr; i++, p++) { ps.d[p] = ps.ty[i]; ps.pv[p] = ps.v[i]; }
+  for (size_t i = 0; i < nr; i++) {
+    const RangeData &rd = st.rds[i];
+    if (rd.assumed) continue;
+    if (bppp_rps::u_lt(amt[i], rd.lo) || !bppp_rps::u_lt(amt[i], rd.hi)) { ps.err = "value outside its range"; return false; }
+    const std::vector<uint32_t> ds = bppp_rps::digits(rd, bppp_rps::u_sub(amt[i], rd.lo));
+    const uint32_t b = rd.base;
+    // ms aligned with ns = [1 | hasBit] ++ [1 .. b-1]: the bit itself, then how often each non-zero digit value occurs (:141-145)
+    std::vector<uint32_t> cnt(b, 0);
+    for (size_t j = rd.has_bit ? 1 : 0; j < ds.size(); j++) cnt[ds[j]]++;
+    std::vector<uint32_t> ms;
+    if (rd.has_bit) ms.push_back(ds[0]);
+    for (uint32_t s = 1; s < b; s++) ms.push_back(cnt[s]);
+    const size_t p0 = st.first_pos[i];
+    if (rd.shared) {
+      for (size_t j = 0; j < ds.size(); j++) ps.d[p0 + j] = small(ds[j]);
+      size_t k = 0;                                        // baseMss (:363-370): the bit's multiplicity goes to base 2
+      if (rd.has_bit) { U256 &a = ps.ms_shared[moff(2)]; a = fa(a, small(ms[0])); k = 1; }
+      const size_t o = moff(b);
+      for (uint32_t s = 0; s + 1 < b; s++) { U256 &a = ps.ms_shared[o + s]; a = fa(a, small(ms[k + s])); }
+    } else {
+      const size_t ln = std::max(ds.size(), ms.size());
+      for (size_t j = 0; j < ln; j++) {
+        if (j < ds.size()) ps.d[p0 + j] = small(ds[j]);
+        if (j < ms.size()) ps.mi[p0 + j] = small(ms[j]);
+      }
+    }
+  }
+  return true;
+}
+
+// blindWitness n = 3 (src/RangeProof/Internal.hs:130-139): five fresh scalars with one zero slot, 7 blinding entries in all
+RPW blind_witness(int k, const std::vector<U256> &ls, const std::vector<U256> &ns, Rnd &rnd, size_t llen) {
+  U256 b[7];
+  for (int i = 0; i < 7; i++) b[i] = U256::zero();
+  const int zero_at = 2 * 3 - k;                           // insertAt (2n - k) 0
+  int j = 0;
+  for (int i = 0; i < 5; i++, j++) { if (j == zero_at) j++; b[j] = rnd.next(); }
+  RPW w;
+  w.sc = b[0];
+  w.lin.assign(llen, U256::zero());
+  for (int i = 0; i < 6; i++) w.lin[i] = b[1 + i];
+  for (size_t i = 0; i < ls.size(); i++) w.lin[6 + i] = ls[i];
+  w.nrm = ns;
+  return w;
+}
+// blindErrWitness n = 3 (:142-149): [a, b, c, 0, d] ++ es, padded to 7
+RPW blind_err_witness(const U256 &err7, const std::vector<U256> &ns, Rnd &rnd, size_t llen) {
+  U256 b[7];
+  for (int i = 0; i < 7; i++) b[i] = U256::zero();
+  b[0] = rnd.next(); b[1] = rnd.next(); b[2] = rnd.next(); b[4] = rnd.next(); b[5] = err7;
+  RPW w;
+  w.sc = b[0];
+  w.lin.assign(llen, U256::zero());
+  for (int i = 0; i < 6; i++) w.lin[i] = b[1 + i];
+  w.nrm = ns;
+  return w;
+}
+
+void batch_inv(std::vector<U256> &v) { if (!v.empty()) batch_minv(v.data(), v.size(), MR()); }
+
+// makeBaseMap: sortedBases zipped with x^3, x^5, ... (TypedReciprocal.hs:349)
+std::vector<U256> base_map(const Setup &st, const U256 &x) {
+  std::vector<U256> out(st.sorted_bases.size());
+  U256 c = fm(fm(x, x), x), xx = fm(x, x);
+  for (size_t k = 0; k < out.size(); k++) { out[k] = c; c = fm(c, xx); }
+  return out;
+}
+
+// makePhase2s with the private fields (TypedReciprocal.hs:185-205)
+void make_phase2(const Setup &st, PState &ps) {
+  const size_t n = st.nlen;
+  const std::vector<U256> bm = base_map(st, ps.x);
+  const U256 xx = fm(ps.x, ps.x);
+  std::vector<U256> xpow(st.rds.size());
+  { U256 c = xx; for (size_t j = 0; j < xpow.size(); j++) { xpow[j] = c; c = fm(c, xx); } }     // x^(2 (j + 1))
+  ps.u.resize(n); ps.vv.resize(n); ps.rr.resize(n); ps.cc.resize(n);
+  std::vector<U256> dens(n), ss(n);
+  for (size_t i = 0; i < n; i++) {
+    const Pos &p = st.pos[i];
+    const uint32_t kind = p.kind & 0xFFu;
+    const U256 &xi = xpow[p.range];
+    dens[i] = fa(ps.e, ps.d[i]);
+    ss[i] = U256::zero();
+    if (kind == bppp_rps::POS_TYPING) {
+      ps.vv[i] = (p.kind & bppp_rps::POS_F_IO) ? fneg(ps.x) : ps.x;
+      ps.u[i] = (p.kind & bppp_rps::POS_F_IA) ? U256::zero() : xi;
+    } else {
+      ps.vv[i] = bm[st.slot_of(p.radix)];
+      ps.u[i] = fm(xi, p.coeff);
+      if (kind == bppp_rps::POS_INLINE && p.sym_small) ss[i] = fa(ps.e, small(p.sym_small));
+    }
+  }
+  batch_inv(dens); batch_inv(ss);
+  for (size_t i = 0; i < n; i++) {
+    ps.rr[i] = fm(ps.pv[i], dens[i]);
+    ps.cc[i] = ss[i].is_zero() ? U256::zero() : fm(ps.vv[i], fs(ps.e_inv, ss[i]));
+  }
+}
+
+// makeSharedCoeffs (:213-216)
+std::vector<U256> make_shared_coeffs(const Setup &st, const PState &ps) {
+  const std::vector<U256> bm = base_map(st, ps.x);
+  std::vector<U256> xs, ss;
+  for (uint32_t b : st.m_bases)
+    for (uint32_t s = 1; s < b; s++) { xs.push_back(bm[st.slot_of(b)]); ss.push_back(fa(ps.e, small(s))); }
+  batch_inv(ss);
+  for (size_t i = 0; i < xs.size(); i++) xs[i] = fm(xs[i], fs(ps.e_inv, ss[i]));
+  return xs;
+}
+
+// inputCoeffs (:325-328)
+std::vector<U256> input_coeffs(const Setup &st, const U256 &x, const U256 &q0) {
+  const size_t nr = st.rds.size();
+  std::vector<U256> out(nr);
+  const U256 xx = fm(x, x);
+  U256 xp = xx, qp = q0;
+  for (size_t i = 0; i < nr; i++) {
+    U256 c = st.rds[i].assumed ? U256::zero() : xp;
+    if (st.has_types) c = fa(c, qp);
+    out[i] = c;
+    xp = fm(xp, xx); qp = fm(qp, q0);
+  }
+  return out;
+}
+
+// makeErrorTerms (:226-243) with q2 = q0^(i+1), bl = the norm blinding of position i
+void make_error_terms(const Setup &st, const PState &ps, const std::vector<U256> &bls_ms, const std::vector<U256> &bls_nrm, U256 tot[6]) {
+  for (int k = 0; k < 6; k++) tot[k] = U256::zero();
+  U256 s3 = U256::zero();
+  for (size_t i = 0; i < ps.shared_cs.size(); i++) s3 = fa(s3, fm(ps.shared_cs[i], bls_ms[i]));
+  tot[3] = fdbl(s3);
+  U256 q2 = ps.q0;
+  for (size_t i = 0; i < st.nlen; i++) {
+    const bool is_t = (st.pos[i].kind & 0xFFu) == bppp_rps::POS_TYPING;
+    const U256 &d = ps.d[i], &m = ps.mi[i], &u = ps.u[i], &v = ps.vv[i], &r = ps.rr[i], &c = ps.cc[i], &bl = bls_nrm[i];
+    const U256 rC = is_t ? fm(ps.xp, fa(u, q2)) : u;
+    const U256 dC = fa(v, fm(q2, ps.e));
+    const U256 q2d_dC = fa(fm(q2, d), dC), q2r_rC = fa(fm(q2, r), rC), q2bl = fm(q2, bl), q2m = fm(q2, m);
+    tot[0] = fa(tot[0], fm(q2bl, bl));
+    tot[1] = fa(tot[1], fdbl(fm(q2m, bl)));
+    tot[2] = fa(tot[2], fa(fm(q2m, m), fdbl(fm(bl, q2d_dC))));
+    tot[3] = fa(tot[3], fdbl(fa(fm(bl, q2r_rC), fm(m, q2d_dC))));
+    tot[4] = fa(tot[4], fa(fa(fm(fm(q2, d), d), fdbl(fm(d, dC))), fdbl(fa(fm(bl, c), fm(m, q2r_rC)))));
+    tot[5] = fa(tot[5], fa(fa(fm(fm(q2, r), r), fdbl(fm(r, rC))), fdbl(fm(c, d))));
+    q2 = fm(q2, ps.q0);
+  }
+}
+
+// blindBlindingTerm for three earlier witnesses [mWit, dmWit, rWit] (src/RangeProof/Internal.hs:154-196)
+RPW blind_blinding_term(const std::vector<U256> &bls_lin, const std::vector<U256> &bls_nrm, const U256 &tC, const PState &ps, const U256 errs[6],
+                        const U256 &input_bl, size_t llen) {
+  const int n = 3;
+  const U256 blT = bls_lin[0];
+  const U256 rs_inv = fm(ps.r0_inv, ps.r1_inv);
+  // rows: [sc] ++ the first 2n linear entries; the error witness keeps only n + 1 of them (the rest zero)
+  U256 rows[3][7];
+  const RPW *w1[2] = {&ps.m, &ps.dm};
+  for (int a = 0; a < 2; a++) { rows[a][0] = w1[a]->sc; for (int j = 0; j < 6; j++) rows[a][1 + j] = w1[a]->lin[j]; }
+  rows[2][0] = ps.r.sc;
+  for (int j = 0; j < 6; j++) rows[2][1 + j] = j < n + 1 ? ps.r.lin[j] : U256::zero();
+  for (int a = 0; a < 3; a++) for (int j = 2; j < 7; j++) rows[a][j] = fneg(rows[a][j]);
+  // errs1 = negate ([errs0 - tC blT] ++ rs_inv * errs[1..])
+  U256 table[4][7];
+  U256 e1[6];
+  e1[0] = fneg(fs(errs[0], fm(tC, blT)));
+  for (int j = 1; j < 6; j++) e1[j] = fneg(fm(rs_inv, errs[j]));
+  auto scale_errs = [&](U256 *xs6, const U256 &s) { xs6[n + 1] = fm(s, xs6[n + 1]); };     // scaleErrs (:118-121): only entry n + 1 of six
+  auto ins = [&](U256 *dst7, const U256 *src6) { for (int j = 0; j < 5; j++) dst7[j] = src6[j]; dst7[5] = U256::zero(); dst7[6] = src6[5]; };   // insertAt (2n - 1) 0
+  ins(table[0], e1);
+  for (int a = 0; a < 3; a++) {
+    U256 r6[6];
+    r6[0] = fa(fm(rs_inv, rows[a][0]), fm(fm(rs_inv, tC), rows[a][1]));                      // addConsts
+    for (int j = 1; j < 6; j++) r6[j] = rows[a][j + 1];
+    scale_errs(r6, ps.r1_inv);
+    ins(table[1 + a], r6);
+  }
+  U256 diag[10];
+  for (int k = 0; k < 10; k++) diag[k] = U256::zero();
+  for (int a = 0; a < 4; a++) for (int b = 0; b < 7; b++) diag[a + b] = fa(diag[a + b], table[a][b]);     // sumDiagonals (:104-111)
+  U256 be[6];
+  for (int k = 0, j = 0; k < 7 && j < 6; k++) { if (k == 5) continue; be[j++] = diag[k]; }              // removeAt (2n - 1), take 2n
+  scale_errs(be, ps.r1);
+  be[5] = fs(be[5], fdbl(input_bl));
+  RPW w;
+  w.sc = fneg(be[0]);
+  w.lin.assign(llen, U256::zero());
+  w.lin[0] = blT;
+  for (int j = 1; j < 6; j++) w.lin[j] = be[j];
+  for (size_t j = 1; j < bls_lin.size(); j++) w.lin[5 + j] = bls_lin[j];
+  w.nrm = bls_nrm;
+  return w;
+}
+
+// makePublicConsts (TypedReciprocal.hs:246-274): returns sc and the norm vector
+void make_public_consts(const Setup &st, const PState &ps, U256 &sc, std::vector<U256> &nrm) {
+  const U256 t2 = fm(ps.t, ps.t), t3 = fm(t2, ps.t), t4 = fm(t2, t2), t5 = fm(t4, ps.t), two_t5 = fdbl(t5);
+  const U256 xx = fm(ps.x, ps.x);
+  U256 z = U256::zero();
+  { U256 xp = xx;
+    for (size_t j = 0; j < st.rds.size(); j++) { if (!st.rds[j].assumed) z = fa(z, fm(bppp_rps::u_mod_n(st.rds[j].lo), xp)); xp = fm(xp, xx); } }
+  z = fneg(fm(two_t5, z));
+  if (st.has_types) {
+    std::vector<U256> pr(st.pubs.size());
+    for (size_t j = 0; j < pr.size(); j++) pr[j] = fa(ps.e, st.pubs[j].type);
+    batch_inv(pr);
+    U256 sum = U256::zero();
+    for (size_t j = 0; j < pr.size(); j++) { const U256 rv = fm(pr[j], st.pubs[j].amount); sum = st.pubs[j].is_output ? fs(sum, rv) : fa(sum, rv); }
+    z = fs(z, fm(fm(two_t5, ps.x), sum));
+  }
+  nrm.resize(st.nlen);
+  U256 q2 = ps.q0, qi2 = ps.q0_inv, acc = U256::zero();
+  for (size_t i = 0; i < st.nlen; i++) {
+    const bool is_t = (st.pos[i].kind & 0xFFu) == bppp_rps::POS_TYPING;
+    U256 rC, p2C;
+    if (is_t) { rC = fm(ps.xp, fa(fm(qi2, ps.u[i]), U256::one())); p2C = U256::zero(); }
+    else { rC = fm(qi2, ps.u[i]); p2C = fa(fdbl(q2), fdbl(fm(ps.e_inv, ps.vv[i]))); }
+    const U256 pv = fa(fa(fm(t2, fa(ps.e, fm(qi2, ps.vv[i]))), fm(t3, rC)), fm(t4, fm(qi2, ps.cc[i])));
+    acc = fa(acc, fa(fm(q2, fm(pv, pv)), fm(t5, p2C)));
+    nrm[i] = pv;
+    q2 = fm(q2, ps.q0); qi2 = fm(qi2, ps.q0_inv);
+  }
+  sc = fa(z, acc);
+}
+
+void put_field(uint8_t *dst, const U256 &v) {      // Binary (Prime p) put (Encoding.hs:81-86)
+  for (int i = 0; i < 4; i++) for (int k = 0; k < 8; k++) dst[8 * i + k] = (uint8_t)(v.w[i] >> (56 - 8 * k));
+}
+// encodeCommitments (Encoding.hs:130-134): packed sign bits (y > p - y), then the x coordinates
+void encode_points(uint8_t *dst, const uint64_t *const *pts, size_t n) {
+  const size_t ns = (n + 7) / 8;
+  memset(dst, 0, ns);
+  for (size_t i = 0; i < n; i++) {
+    const U256 y = U256::load(pts[i] + 4), ny = mneg(y, FQ());
+    if (cmp(y, ny) > 0) dst[i >> 3] |= (uint8_t)(1u << (i & 7));
+    put_field(dst + ns + 32 * i, U256::load(pts[i]));
+  }
+}
+
+// the fixed-base table of (g, H0, H1): [3][64][15] affine points, built once per setup on the host (2880 additions, one batch inversion)
+int build_fixed_table(bppp_rp *rp) {
+  if (rp->d_fixed) return BPPP_OK;
+  bppp_ctx *ctx = rp->ctx;
+  const Mod &Q = FQ();
+  std::vector<HJac> jac;
+  jac.reserve(FB_BASES * FB_WIN * FB_DIG);
+  const uint64_t *bases[3] = {rp->h_g.data(), rp->h_H.data(), rp->h_H.data() + 8};
+  for (int b = 0; b < FB_BASES; b++) {
+    HJac cur = hj_from_aff(HAff{U256::load(bases[b]), U256::load(bases[b] + 4)});
+    for (int w = 0; w < FB_WIN; w++) {
+      HJac acc = cur;
+      for (int d = 1; d <= FB_DIG; d++) { jac.push_back(acc); acc = hj_add(acc, cur); }
+      cur = acc;                                   // 16 * cur
+    }
+  }
+  std::vector<U256> zs(jac.size());
+  for (size_t i = 0; i < jac.size(); i++) zs[i] = jac[i].Z;
+  batch_minv(zs.data(), zs.size(), Q);
+  std::vector<uint64_t> host(jac.size() * 8, 0);
+  for (size_t i = 0; i < jac.size(); i++) {
+    if (jac[i].inf()) continue;                    // cannot happen for points of prime order; kept as the infinity encoding
+    const U256 zi2 = fqmul(zs[i], zs[i]);
+    fqmul(jac[i].X, zi2).store(&host[8 * i]);
+    fqmul(jac[i].Y, fqmul(zi2, zs[i])).store(&host[8 * i + 4]);
+  }
+  BPPP_HIP(ctx, hipMalloc(&rp->d_fixed, host.size() * 8));
+  BPPP_HIP(ctx, hipMemcpy(rp->d_fixed, host.data(), host.size() * 8, hipMemcpyHostToDevice));
+  return BPPP_OK;
+}
+
+int ensure_pwork(bppp_rp *rp, size_t bytes) {
+  if (bytes <= rp->pwork_bytes) return BPPP_OK;
+  bppp_ctx *ctx = rp->ctx;
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rp->pwork) BPPP_HIP(ctx, hipFree(rp->pwork));
+  rp->pwork = nullptr; rp->pwork_bytes = 0;
+  BPPP_HIP(ctx, hipMalloc(&rp->pwork, bytes + bytes / 8));
+  rp->pwork_bytes = bytes + bytes / 8;
+  return BPPP_OK;
+}
+
+}  // namespace
+
+extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
+                                   size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files) {
+  if (!rp) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = rp->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
+  if (!batch) return BPPP_OK;
+  if (!amounts || !types || !blinds || (prefix_len && !rand_prefix) || !coms_files || !proof_files || batch >= (1u << 20) || prefix_len > 4096)
+    return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: bad arguments");
+  hipSetDevice(ctx->device);
+  hipStream_t stream = ctx->stream;
+  const Setup &st = rp->st;
+  const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
+  if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");
+  { int rc = build_fixed_table(rp); if (rc) return rc; }
+  // device workspace: [input scalars B nr 3 | input commitments B nr | commitment rows 2B T]
+  const size_t in_sc = B * nr * 3 * 32, in_pt = B * nr * 64, rows = 2 * B * T * 32;
+  { int rc = ensure_pwork(rp, in_sc + in_pt + rows + 1024); if (rc) return rc; }
+  uint32_t *d_in_sc = (uint32_t *)rp->pwork, *d_in_pt = (uint32_t *)((char *)rp->pwork + ((in_sc + 255) & ~(size_t)255)),
+           *d_rows = (uint32_t *)((char *)d_in_pt + ((in_pt + 255) & ~(size_t)255));
+
+  std::vector<PState> ps(B);
+  std::vector<uint64_t> h_in_sc(B * nr * 12), h_in_pt(B * nr * 8), h_rows(2 * B * T * 4), h_com(2 * B * 8);
+  std::atomic<int> failed{-1};
+  auto put_row = [&](size_t row, const RPW &w) {           // commitRPW's term order: [sc] ++ lin ++ nrm over [g] ++ hs ++ gs
+    uint64_t *dst = &h_rows[row * T * 4];
+    w.sc.store(dst);
+    for (size_t i = 0; i < llen; i++) w.lin[i].store(dst + 4 * (1 + i));
+    for (size_t i = 0; i < nlen; i++) w.nrm[i].store(dst + 4 * (1 + llen + i));
+  };
+  auto commit_rows = [&](size_t nrows) -> int {            // one batched MSM over the registered basis: h_com[row] = commit(row)
+    BPPP_HIP(ctx, hipMemcpyAsync(d_rows, h_rows.data(), nrows * T * 32, hipMemcpyHostToDevice, stream));
+    return msm_run(ctx, d_rows, rp->d_basis, T, nrows, 1, 0, h_com.data());
+  };
+
+  // ---- phase 1: witness, dmWit / mWit (TypedReciprocal.hs:402-410)
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    for (size_t b = lo; b < hi; b++) {
+      PState &p = ps[b];
+      p.rnd = Rnd{rand_prefix + b * prefix_len, prefix_len, 0};
+      if (!make_witness(st, p, amounts + 4 * nr * b, types + 4 * nr * b, blinds + 4 * nr * b)) { failed = (int)b; continue; }
+      for (size_t i = 0; i < nr; i++) { p.v[i].store(&h_in_sc[(b * nr + i) * 12]); p.ty[i].store(&h_in_sc[(b * nr + i) * 12 + 4]); p.bl[i].store(&h_in_sc[(b * nr + i) * 12 + 8]); }
+      p.dm = blind_witness(2, p.ms_shared, p.d, p.rnd, llen);
+      p.m = blind_witness(1, std::vector<U256>(), p.mi, p.rnd, llen);
+      put_row(2 * b, p.dm); put_row(2 * b + 1, p.m);
+    }
+  });
+  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((int)failed) + ": " + ps[failed].err);
+  BPPP_HIP(ctx, hipMemcpyAsync(d_in_sc, h_in_sc.data(), in_sc, hipMemcpyHostToDevice, stream));
+  {
+    const uint64_t n = (uint64_t)B * nr;
+    k_rp_commit_inputs<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(rp->d_fixed, d_in_sc, n, d_in_pt);
+    BPPP_HIP(ctx, hipGetLastError());
+    BPPP_HIP(ctx, hipMemcpyAsync(h_in_pt.data(), d_in_pt, in_pt, hipMemcpyDeviceToHost, stream));
+  }
+  { int rc = commit_rows(2 * B); if (rc) return rc; }       // synchronises the stream
+  std::vector<uint64_t> c_dm(B * 8), c_m(B * 8), c_r(B * 8), c_bl(B * 8);
+  for (size_t b = 0; b < B; b++) { memcpy(&c_dm[8 * b], &h_com[16 * b], 64); memcpy(&c_m[8 * b], &h_com[16 * b + 8], 64); }
+
+  // ---- phase 2: (e, x, r0), reciprocals, rWit (:412-419)
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    std::vector<const uint64_t *> pts(2 + nr);
+    for (size_t b = lo; b < hi; b++) {
+      PState &p = ps[b];
+      pts[0] = &c_dm[8 * b]; pts[1] = &c_m[8 * b];
+      for (size_t i = 0; i < nr; i++) pts[2 + i] = &h_in_pt[(b * nr + i) * 8];
+      U256 ch[3];
+      oracle(rp->tag, p, pts.data(), pts.size(), 3, ch);
+      p.e = ch[0]; p.x = ch[1]; p.r0 = ch[2];
+      p.e_inv = minv(p.e, MR()); p.r0_inv = minv(p.r0, MR());
+      make_phase2(st, p);
+      U256 s = U256::zero();
+      for (size_t i = 0; i < nlen; i++) s = fa(s, fdbl(fm(p.rr[i], p.cc[i])));
+      const U256 err7 = fm(p.r0_inv, fneg(s));             // err7Term (:209-211)
+      p.r = blind_err_witness(err7, p.rr, p.rnd, llen);
+      put_row(b, p.r);
+    }
+  });
+  { int rc = commit_rows(B); if (rc) return rc; }
+  memcpy(c_r.data(), h_com.data(), B * 64);
+
+  // ---- phase 3: (q, x', r1), error terms, the blinding commitment (:421-437)
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    for (size_t b = lo; b < hi; b++) {
+      PState &p = ps[b];
+      const uint64_t *pt = &c_r[8 * b];
+      U256 ch[3];
+      oracle(rp->tag, p, &pt, 1, 3, ch);
+      p.q = ch[0]; p.xp = ch[1]; p.r1 = ch[2];
+      p.q0 = fm(p.q, p.q);                                  // qPowers' of the NL norm: powers' (q^2) (NormArgument.hs:148)
+      p.q0_inv = minv(p.q0, MR()); p.r1_inv = minv(p.r1, MR());
+      p.shared_cs = make_shared_coeffs(st, p);
+      const U256 tC = st.has_types ? p.xp : U256::zero();
+      std::vector<U256> bls_lin(llen - 5), bls_nrm(nlen);
+      for (auto &v : bls_lin) v = p.rnd.next();
+      for (auto &v : bls_nrm) v = p.rnd.next();
+      const std::vector<U256> bls_ms(bls_lin.begin() + 1, bls_lin.end());
+      const std::vector<U256> ic = input_coeffs(st, p.x, p.q0);
+      p.ns_sc = p.ns_ty = p.ns_bl = U256::zero();
+      for (size_t i = 0; i < nr; i++) { p.ns_sc = fa(p.ns_sc, fm(ic[i], p.v[i])); p.ns_ty = fa(p.ns_ty, fm(ic[i], p.ty[i])); p.ns_bl = fa(p.ns_bl, fm(ic[i], p.bl[i])); }
+      U256 errs[6];
+      make_error_terms(st, p, bls_ms, bls_nrm, errs);
+      p.blw = blind_blinding_term(bls_lin, bls_nrm, tC, p, errs, p.ns_bl, llen);
+      put_row(b, p.blw);
+    }
+  });
+  { int rc = commit_rows(B); if (rc) return rc; }
+  memcpy(c_bl.data(), h_com.data(), B * 64);
+
+  // ---- t, the combined witness and the argument's linear weights (:438-446)
+  std::vector<uint64_t> a_s(B * 4), a_q(B * 4), a_nx(B * nlen * 4), a_lc(B * llen * 4), a_lx(B * llen * 4);
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    for (size_t b = lo; b < hi; b++) {
+      PState &p = ps[b];
+      const uint64_t *pt = &c_bl[8 * b];
+      oracle(rp->tag, p, &pt, 1, 1, &p.t);
+      U256 psc; std::vector<U256> pn;
+      make_public_consts(st, p, psc, pn);
+      const U256 t2 = fm(p.t, p.t), t3 = fm(t2, p.t), t4 = fm(t2, t2), t5 = fm(t4, p.t), t6 = fm(t3, t3), two_t5 = fdbl(t5);
+      // wit = pub + blWit + t mWit + t^2 dmWit + t^3 rWit + 2 t^5 nWitSum
+      U256 sc = fa(fa(psc, p.blw.sc), fa(fa(fm(p.t, p.m.sc), fm(t2, p.dm.sc)), fa(fm(t3, p.r.sc), fm(two_t5, p.ns_sc))));
+      sc.store(&a_s[4 * b]); p.q.store(&a_q[4 * b]);
+      for (size_t i = 0; i < llen; i++) {
+        U256 v = fa(fa(p.blw.lin[i], fm(p.t, p.m.lin[i])), fa(fm(t2, p.dm.lin[i]), fm(t3, p.r.lin[i])));
+        if (i == 0) v = fa(v, fm(two_t5, p.ns_ty));
+        if (i == 1) v = fa(v, fm(two_t5, p.ns_bl));
+        v.store(&a_lx[(b * llen + i) * 4]);
+      }
+      for (size_t i = 0; i < nlen; i++)
+        fa(fa(pn[i], p.blw.nrm[i]), fa(fa(fm(p.t, p.m.nrm[i]), fm(t2, p.dm.nrm[i])), fm(t3, p.r.nrm[i]))).store(&a_nx[(b * nlen + i) * 4]);
+      // makeBpCoeffs (:391-396)
+      const U256 rs = fm(p.r0, p.r1), two_t3 = fdbl(t3);
+      U256 c6[6] = {st.has_types ? fneg(p.xp) : U256::zero(), fm(rs, p.t), fm(rs, t2), fm(rs, t3), fm(p.r0, t4), fm(rs, t6)};
+      for (int i = 0; i < 6; i++) c6[i].store(&a_lc[(b * llen + i) * 4]);
+      for (size_t i = 0; i < p.shared_cs.size(); i++) fm(two_t3, p.shared_cs[i]).store(&a_lc[(b * llen + 6 + i) * 4]);
+      // the phase vectors are no longer needed
+      p.dm = RPW(); p.m = RPW(); p.r = RPW(); p.blw = RPW();
+      p.u.clear(); p.vv.clear(); p.rr.clear(); p.cc.clear(); p.d.clear(); p.mi.clear(); p.pv.clear();
+    }
+  });
+
+  // ---- proveBPM in lockstep (src/Bulletproof.hs:357-359)
+  bppp_nlb *nlb = nullptr;
+  int rc = bppp_nlb_create(ctx, B, a_s.data(), rp->h_g.data(), a_q.data(), a_nx.data(), rp->h_G.data(), nlen, a_lc.data(), a_lx.data(), rp->h_H.data(), llen, &nlb);
+  if (rc) return rc;
+  std::vector<uint64_t> sX(B * 4), sR(B * 4), X(B * 8), R(B * 8), es(B * 4), resp(B * k * 16);
+  for (size_t round = 0; round < k && !rc; round++) {
+    rc = bppp_nlb_round_commit(nlb, sX.data(), X.data(), sR.data(), R.data());
+    if (rc) break;
+    rp_parallel(B, [&](size_t lo, size_t hi) {
+      for (size_t b = lo; b < hi; b++) {
+        const uint64_t *pts[2] = {&X[8 * b], &R[8 * b]};
+        U256 e;
+        oracle(rp->tag, ps[b], pts, 2, 1, &e);
+        e.store(&es[4 * b]);
+        const size_t slot = k - 1 - round;                 // responses LAST round first (:359)
+        memcpy(&resp[(b * k + slot) * 16], pts[0], 64); memcpy(&resp[(b * k + slot) * 16 + 8], pts[1], 64);
+      }
+    });
+    rc = bppp_nlb_round_collapse(nlb, es.data());
+  }
+  std::vector<uint64_t> wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
+  if (!rc) rc = bppp_nlb_get_witness(nlb, wn.data(), wl.data(), nullptr);
+  bppp_nlb_destroy(nlb);
+  if (rc) return rc;
+
+  // ---- encodeProof' (RangeProof.hs:60-66): commitments file = the input commitments; proof file = final witness scalars (norm, linear),
+  // then blCom, rCom, dmCom, mCom and the responses
+  const RpDims &D = rp->D;
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    std::vector<const uint64_t *> pts;
+    for (size_t b = lo; b < hi; b++) {
+      pts.assign(nr, nullptr);
+      for (size_t i = 0; i < nr; i++) pts[i] = &h_in_pt[(b * nr + i) * 8];
+      encode_points(coms_files + b * D.coms_bytes, pts.data(), nr);
+      uint8_t *pf = proof_files + b * D.proof_bytes;
+      for (size_t i = 0; i < st.fn; i++) put_field(pf + 32 * i, U256::load(&wn[(b * st.fn + i) * 4]));
+      for (size_t i = 0; i < st.fl; i++) put_field(pf + 32 * (st.fn + i), U256::load(&wl[(b * st.fl + i) * 4]));
+      pts.assign(4 + 2 * k, nullptr);
+      pts[0] = &c_bl[8 * b]; pts[1] = &c_r[8 * b]; pts[2] = &c_dm[8 * b]; pts[3] = &c_m[8 * b];
+      for (size_t j = 0; j < 2 * k; j++) pts[4 + j] = &resp[(b * k) * 16 + 8 * j];
+      encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 4 + 2 * k);
+    }
+  });
+  return BPPP_OK;
+}

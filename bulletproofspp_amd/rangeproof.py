@@ -868,6 +868,30 @@ class NativeRangeProofs:
         except Exception:
             pass
 
+    def prove_batch(self, inputs: Sequence[Sequence[Tuple[int, int, int]]], rand_prefixes: Sequence[bytes]) -> List[Tuple[bytes, bytes]]:
+        """bppp_rp_prove_batch: inputs[b] = [(amount, type, blinding) per range]; rand_prefixes[b] = the hashToScalar prefix of
+        proof b (all of one length).  Returns [(commitments file, proof file)] — the bytes encoding.encode_proof(prove(...)) gives."""
+        import ctypes as C
+        import numpy as np
+        from .capi import scalars_to_array
+        B, nr = len(inputs), len(self.st.rds)
+        if B == 0:
+            return []
+        if len(rand_prefixes) != B or len({len(p_) for p_ in rand_prefixes}) != 1 or any(len(row) != nr for row in inputs):
+            raise ValueError("one equal-length randomness prefix per proof and one (amount, type, blinding) per range are required")
+        amt = scalars_to_array([v for row in inputs for v, _, _ in row])
+        typ = scalars_to_array([t % N for row in inputs for _, t, _ in row])
+        bld = scalars_to_array([b_ % N for row in inputs for _, _, b_ in row])
+        plen = len(rand_prefixes[0])
+        pre = np.frombuffer(b"".join(rand_prefixes) or b"\0", dtype=np.uint8)
+        cf = np.zeros(B * self.shape["coms_bytes"], dtype=np.uint8)
+        pf = np.zeros(B * self.shape["proof_bytes"], dtype=np.uint8)
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        rc = self.gpu.lib.bppp_rp_prove_batch(self.h, B, vp(amt), vp(typ), vp(bld), vp(pre), plen, vp(cf), vp(pf))
+        self.gpu._check(rc, "bppp_rp_prove_batch")
+        cb, pb = self.shape["coms_bytes"], self.shape["proof_bytes"]
+        return [(cf[b * cb:(b + 1) * cb].tobytes(), pf[b * pb:(b + 1) * pb].tobytes()) for b in range(B)]
+
     def verify_batch(self, coms_files: Sequence[bytes], proof_files: Sequence[bytes], seed: bytes, want_status: bool = False, want_challenges: bool = False):
         """bppp_rp_verify_batch on host byte strings: returns accept, or (accept, status list, challenges per proof) as asked"""
         import ctypes as C

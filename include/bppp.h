@@ -312,6 +312,20 @@ int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, c
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
                                 uint32_t *proof_status, uint64_t *challenges_out);
 
+/* Batch prover: `batch` proofs of this setup in lockstep — proveM of RangeProof (src/RangeProof.hs:93-97) = proveTRRPM
+ * (src/RangeProof/TypedReciprocal.hs:399-446; blinding algebra src/RangeProof/Internal.hs:118-196) followed by proveBPM
+ * (src/Bulletproof.hs:357-359), then encodeProof' (src/RangeProof.hs:60-66).  Per proof b: amounts / types / blinds are
+ * [batch][nranges][4] (amount: a plain integer inside its range; type, blinding: canonical scalars), and the prover's randomness
+ * is the CLI's: random n = decode(SHA-256(prefix_b <> show n)) for n = 0, 1, ... (hashToScalar, app/Main.hs:83-87, :189;
+ * ZKPT.random, src/ZKP.hs:88-92) with prefix_b = rand_prefix[b * prefix_len ..].  The oracle is the setup's shaOracle (see above).
+ * Outputs are the reference's files: coms_files [batch][coms_bytes], proof_files [batch][proof_bytes].  Every commitment is
+ * computed on the device (input commitments through a fixed-base table of g, H0, H1; the four range-proof commitments of all
+ * proofs as batched MSMs over the registered basis; the argument through bppp_nlb_*); the per-proof field algebra and the
+ * transcript hashing run on the host cores.  Same randomness and inputs => byte-identical files to the host protocol code
+ * (bulletproofspp_amd/rangeproof.py: prove + encoding.encode_proof), which the tests assert. */
+int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
+                        size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files);
+
 /* ---- harness utility: pointX of getPoints (app/Main.hs:68-72) -------------------------------
  * For each candidate x (n x 4 uint64 in HBM) writes the affine point (x, y) with y the EVEN root of
  * x^3 + 7, or the infinity encoding when x^3 + 7 is a non-residue or x >= p.  (Which root

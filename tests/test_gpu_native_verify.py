@@ -88,3 +88,105 @@ def test_native_reject_and_identify(gpu):
     # wrong file length
     assert nat.verify_batch([c for c, _ in files], [files[0][1][:-1]] + [p for _, p in files[1:]], seed) is False
     nat.close()
+
+
+@pytest.mark.parametrize("typed", [False, True])
+def test_native_prover_equals_host_protocol_bytes(gpu, typed):
+    """bppp_rp_prove_batch against rangeproof.prove: same inputs, same hashToScalar randomness, same oracle => the same
+    commitments file and proof file byte for byte (every commitment, response and final witness scalar)."""
+    st = _setup(gpu, typed)
+    nat = RP.NativeRangeProofs(gpu, st)
+    rnd = random.Random(77)
+    B = 6
+    if typed:
+        inputs = [[(v, 7, rnd.randrange(O.N)) for v in (200, 20, 250, 30)] for _ in range(B)]
+    else:
+        inputs = [[(rnd.randrange(256), 0, rnd.randrange(O.N)), (10 + rnd.randrange(256), 0, rnd.randrange(O.N)), (rnd.randrange(2**64), 0, rnd.randrange(O.N)),
+                   (rnd.randrange(100), 0, rnd.randrange(O.N))] for _ in range(B)]
+    inputs[0][0] = (0, inputs[0][0][1], inputs[0][0][2]) if not typed else inputs[0][0]            # range minimum
+    if not typed:
+        inputs[1] = [(255, 0, 1), (265, 0, 2), (2**64 - 1, 0, 3), (99, 0, 4)]                      # every range at its maximum
+    prefixes = [b"native prover %02d" % b for b in range(B)]
+    got = nat.prove_batch(inputs, prefixes)
+    for b in range(B):
+        proof = RP.prove(st, RP.witness(st, inputs[b]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[b]))
+        want = E.encode_proof(4, proof)
+        assert got[b][0] == want[0], "commitments file differs (proof %d)" % b
+        assert got[b][1] == want[1], "proof file differs (proof %d)" % b
+    assert nat.verify_batch([c for c, _ in got], [p for _, p in got], b"\x07" * 32)
+    # a value outside its range is refused
+    bad = [list(r) for r in inputs]
+    bad[2][3] = (100 if not typed else 1000, bad[2][3][1], bad[2][3][2])
+    with pytest.raises(Exception):
+        nat.prove_batch(bad, prefixes)
+    nat.close()
+
+
+def _example_setup(gpu, name, typed_override=None):
+    from test_rangeproof import EXAMPLES
+    schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
+    if typed_override:
+        schema = dict(schema, typed=True)
+    count = sum(int(r.get("count", 1)) for r in schema["ranges"])
+    return RP.setup_from_schema(RP.GpuBackend(gpu), schema), count
+
+
+def test_config5_batch_of_4096_proofs_64by64(gpu):
+    """BASELINE config 5 on one GPU: 2^12 DISTINCT aggregated 64 x 64-bit proofs (examples/64by64: nrmLen 512, linLen 261, 8 rounds)
+    made by the lockstep prover, verified end to end from their bytes with one combined MSM of 344 838 terms; then one of them
+    corrupted => rejected and identified."""
+    st, count = _example_setup(gpu, "64by64")
+    assert (st.nrm_len, st.lin_len, st.rounds, st.final_lens) == (512, 261, 8, (2, 2)) and count == 64
+    nat = RP.NativeRangeProofs(gpu, st)
+    B = 4096
+    rng = np.random.default_rng(5)
+    amounts = rng.integers(0, 2**63, size=(B, count), dtype=np.uint64)
+    blinds = rng.integers(1, 2**63, size=(B, count), dtype=np.uint64)
+    inputs = [[(int(a) * 2 + (i & 1), 0, int(bl)) for i, (a, bl) in enumerate(zip(amounts[b], blinds[b]))] for b in range(B)]
+    files = nat.prove_batch(inputs, [b"cfg5 %06d" % b for b in range(B)])
+    assert len({p for _, p in files}) == B
+    seed = hashlib.sha256(b"cfg5").digest()
+    ok, status, chs = nat.verify_batch([c for c, _ in files], [p for _, p in files], seed, want_status=True, want_challenges=True)
+    assert ok and status == [0] * B
+    # one proof of the batch checked against the host protocol code: same challenges, and it verifies there too
+    proof = E.decode_proof(4, st.rounds, st.final_lens, E.decode_commitments(count, files[17][0], E.gpu_lift_x(gpu))[0], files[17][1], E.gpu_lift_x(gpu))
+    assert chs[17] == tuple(RP.verifier_challenges(st, proof, RP.sha256_oracle())) and RP.verify(st, proof, RP.sha256_oracle())
+    bad = list(files)
+    pf = bytearray(bad[1234][1]); pf[40] ^= 1; bad[1234] = (bad[1234][0], bytes(pf))
+    ok, status, _ = nat.verify_batch([c for c, _ in bad], [p for _, p in bad], seed, want_status=True)
+    assert not ok and [i for i, s_ in enumerate(status) if s_] == [1234] and status[1234] == 1
+    nat.close()
+
+
+def test_config4_typed_conserved_128by64(gpu):
+    """BASELINE config 4: 128 x 64-bit values, typed reciprocal proof WITH conservation (examples/128by64 plus "typed": nrmLen 1152,
+    9 rounds, final (3, 1), a 1564-term verifier MSM per proof), batch-verified end to end; a proof whose public input does not
+    balance cannot be made; a corrupted member is rejected."""
+    from test_rangeproof import EXAMPLES
+    schema = json.load(open(os.path.join(EXAMPLES, "128by64", "schema.json")))
+    schema = dict(schema, typed=True, public=[{"amount": 128 * 10000, "type": 0}])
+    st = RP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    assert (st.nrm_len, st.lin_len, st.rounds, st.final_lens) == (1152, 261, 9, (3, 1)) and st.has_types
+    nat = RP.NativeRangeProofs(gpu, st)
+    B = 256
+    rng = np.random.default_rng(4)
+    inputs = []
+    for b in range(B):
+        # 128 outputs of type 0 that sum to the public input 1 280 000: random split around 10 000 each
+        d = rng.integers(-5000, 5000, size=64)
+        vals = [10000 + int(x) for x in d] + [10000 - int(x) for x in d]
+        inputs.append([(v, 0, int(bl)) for v, bl in zip(vals, rng.integers(1, 2**63, size=128, dtype=np.uint64))])
+    files = nat.prove_batch(inputs, [b"cfg4 %04d" % b for b in range(B)])
+    seed = hashlib.sha256(b"cfg4").digest()
+    assert nat.verify_batch([c for c, _ in files], [p for _, p in files], seed)
+    proof = E.decode_proof(4, st.rounds, st.final_lens, E.decode_commitments(128, files[3][0], E.gpu_lift_x(gpu))[0], files[3][1], E.gpu_lift_x(gpu))
+    assert RP.verify(st, proof, RP.sha256_oracle())
+    unbalanced = [list(r) for r in inputs[:4]]
+    unbalanced[1][0] = (unbalanced[1][0][0] + 1, 0, unbalanced[1][0][2])
+    with pytest.raises(Exception):
+        nat.prove_batch(unbalanced, [b"x%d" % b for b in range(4)])
+    bad = list(files)
+    cf = bytearray(bad[200][0]); cf[0] ^= 2; bad[200] = (bytes(cf), bad[200][1])        # the sign of one input commitment
+    ok, status, _ = nat.verify_batch([c for c, _ in bad], [p for _, p in bad], seed, want_status=True)
+    assert not ok and [i for i, s_ in enumerate(status) if s_] == [200]
+    nat.close()
