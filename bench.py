@@ -101,24 +101,14 @@ SHAPES = {   # (nrmLen, linLen, rounds, final norm, final 
 }
 
 
-def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real: int, steps: int, warmup: int, shape: str = "64by64",
-                 cpu_baseline_leg: bool = False):
-    """Secondary metric (BASELINE.json: "aggregated 64-bit range-proof verifies/sec"): batch verification of `batch`
-    aggregated range proofs of the examples/64by64 shape (64 values of 64 bits, base 256 shared digits, NL argument: nrmLen 512,
-    linLen 261, 8 rounds, 68 transcript commitments + 16 responses per proof) per GPU with ONE combined MSM
-    (bppp_nl_verify_batch_device).  The proofs are REAL typed-reciprocal range proofs: produced here by
-    bulletproofspp_amd.rangeproof (host protocol logic; every commitment and the whole norm-linear argument on the GPU) with a
-    SHA-256 stand-in oracle, `n_real` distinct ones tiled to `batch` with fresh random rho.  Timed, with the proofs (points, final
-    witness scalars) and their challenges resident in HBM: the derivation of every proof's public scalars from its challenges
-    (verifyTRRPM's arithmetic, TypedReciprocal.hs:449-467, as bppp_trrp_public_device), challenge expansion, shared-basis merge and
-    the combined MSM.  Not timed: the Fiat-Shamir hashing that produces the challenges (the injected oracle; reported separately)."""
+def make_rp_setup(gpu, torch, dev, rank: int, shape: str):
+    """One typed-reciprocal setup of an examples/ shape over a synthetic basis (points lifted on the GPU, layout h : g : hs ++ gs,
+    TypedReciprocal.hs:334, :348-349), registered with the library (bppp_rp_create)."""
     from bulletproofspp_amd import rangeproof as RP
-    from bulletproofspp_amd.bulletproof import N_ORDER
-    from bulletproofspp_amd.capi import scalars_to_array, points_to_array, array_to_point, _ptr
+    from bulletproofspp_amd.capi import array_to_point
     nlen, llen, k, fn, fl, ninit = SHAPES[shape]
     count, typed = (64, False) if shape == "64by64" else (128, True)
     rng = np.random.default_rng(0x64B + rank)
-    # basis layout h : g : hs(llen) ++ gs(nlen) (TypedReciprocal.hs:334, :348-349), lifted on the GPU
     need = 2 + llen + nlen
     pts = None
     while pts is None or pts.shape[0] < need:
@@ -129,63 +119,83 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
         pts = dp[(dp != 0).any(dim=1)]
     P = pts[:need].cpu().numpy().view(np.uint64)
     basis_pts = [array_to_point(P[i]) for i in range(need)]
-    rand_fr = lambda n: [int.from_bytes(rng.bytes(32), "little") % N_ORDER for _ in range(n)]
     rd = RP.make_range_data(256, 0, 2**64, True, True, False)
     amount = 10000                                                     # examples/*/witness.json
     pub_vt = [(False, 0, amount * count)] if typed else []             # conservation: one public input balances the outputs
     st = RP.setup(RP.GpuBackend(gpu), basis_pts, typed, pub_vt, [rd] * count)
     assert (st.nrm_len, st.lin_len, st.rounds, st.final_lens) == (nlen, llen, k, (fn, fl)), "shape table out of date"
-    g, hs, gs = st.g, st.hs, st.gs
+    nat = RP.NativeRangeProofs(gpu, st, h=basis_pts[0])
+    return st, nat, count, typed, amount, rng
 
-    proofs = []
-    t_prove0 = time.perf_counter()
-    derive_s = 0.0
-    for j in range(n_real):
-        vals = [amount] * count if (typed or j == 0) else [int(v) for v in rng.integers(0, 2**63, size=count, dtype=np.uint64) * 2]
-        wit = RP.witness(st, [(v, 0, bl) for v, bl in zip(vals, rand_fr(count))])
-        orc = RP.sha256_oracle(b"bench%d-%d" % (rank, j))
-        prf = RP.prove(st, wit, orc, RP.hash_to_scalar(b"bench rand %d-%d" % (rank, j)))
-        t1 = time.perf_counter()
-        ch, es_ = RP.verifier_challenges(st, prf, orc)                  # the host's whole share: the oracle calls
-        derive_s += time.perf_counter() - t1
-        assert len(prf.coms) == ninit and len(es_) == k
-        proofs.append({"ch": ch, "es": es_, "resp": [p_ for xr in prf.responses for p_ in xr], "nw": prf.wit_nrm, "lw": prf.wit_lin, "init": list(prf.coms)})
-    prove_s = (time.perf_counter() - t_prove0 - derive_s) / max(n_real, 1)
-    derive_s /= max(n_real, 1)
 
-    def tile(rows_per_proof):
-        one = np.concatenate(rows_per_proof)
-        reps = (batch + n_real - 1) // n_real
-        return np.concatenate([one] * reps)[: batch * (one.shape[0] // n_real)]
+def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, steps: int, warmup: int, shape: str = "64by64",
+                      cpu_baseline_leg: bool = False, prove_steps: int = 1):
+    """Both range-proof legs on `batch` DISTINCT real proofs of an examples/ shape per GPU, through the library's end-to-end entry points.
 
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
-    d = {
-        "g": up(points_to_array([g])), "G": up(points_to_array(gs)), "H": up(points_to_array(hs)),
-        "rho": up(scalars_to_array([1] + rand_fr(batch - 1))), "ch": up(tile([scalars_to_array(p["ch"]) for p in proofs])),
-        # written by bppp_trrp_public_device every step (the verifier's public scalars, derived from the challenges on the GPU)
-        "q": up(np.zeros((batch, 4), dtype=np.uint64)), "sp": up(np.zeros((batch, 4), dtype=np.uint64)),
-        "pub_norm": up(np.zeros((batch * nlen, 4), dtype=np.uint64)), "pub_lin_c": up(np.zeros((batch * llen, 4), dtype=np.uint64)),
-        "pub_lin_x": up(np.zeros((batch * llen, 4), dtype=np.uint64)), "is": up(np.zeros((batch * ninit, 4), dtype=np.uint64)),
-        "es": up(tile([scalars_to_array(p["es"]) for p in proofs])), "wn": up(tile([scalars_to_array(p["nw"]) for p in proofs])),
-        "wl": up(tile([scalars_to_array(p["lw"]) for p in proofs])),
-        "ip": up(tile([points_to_array(p["init"]) for p in proofs])), "rp": up(tile([points_to_array(p["resp"]) for p in proofs])),
-    }
-    out = np.zeros(8, dtype=np.uint64)
-    tabs = RP.DeviceVerifierTables(gpu, st)
+    prove  (bppp_rp_prove_batch): proveM of RangeProof (src/RangeProof.hs:93-97) for the whole batch in lockstep — phases 1-3 of
+           proveTRRPM, every commitment on the GPU, the norm-linear argument, transcript hashing (shaOracle) and encodeProof';
+           inputs are host arrays (values, blindings), outputs the reference's files.  N > 1: independent replicas.
+    verify (bppp_rp_verify_batch_device): the metric "aggregated 64-bit range-proof verifies/sec".  Timed with the ENCODED proofs
+           (commitments file + proof file per proof, as the reference writes them) resident in HBM: decodeProof (square roots, sign
+           selection), all SHA-256 transcript hashing of verifyTRRPM and verifyBPM, the public scalars, challenge expansion,
+           shared-basis merge and ONE combined MSM.  Nothing of a verification is left outside the timed region.  N > 1: proofs are
+           sharded per GPU; the ranks all-gather their 64-byte combined points and add them (the only exchange)."""
+    import ctypes as C
+    st, nat, count, typed, amount, rng = make_rp_setup(gpu, torch, dev, rank, shape)
+    nlen, llen, k, fn, fl, ninit = SHAPES[shape]
+    shp = nat.shape
+    # distinct inputs: random 64-bit values (typed/conserved: random splits around the example's amount that keep the sum)
+    if typed:
+        dlt = rng.integers(-5000, 5000, size=(batch, count // 2))
+        vals = np.concatenate([amount + dlt, amount - dlt], axis=1).astype(np.uint64)
+    else:
+        vals = rng.integers(0, 2**64, size=(batch, count), dtype=np.uint64)
+    amt = np.zeros((batch, count, 4), dtype=np.uint64); amt[:, :, 0] = vals
+    typ = np.zeros((batch, count, 4), dtype=np.uint64)
+    bld = rng.integers(0, 2**64, size=(batch, count, 4), dtype=np.uint64); bld[:, :, 3] >>= np.uint64(1)
+    plen = 24
+    pre = np.frombuffer(b"".join(b"bench r%03d %012d " % (rank, b) for b in range(batch)), dtype=np.uint8)
+    assert pre.size == batch * plen
+    cf = np.zeros(batch * shp["coms_bytes"], dtype=np.uint8)
+    pf = np.zeros(batch * shp["proof_bytes"], dtype=np.uint8)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+
+    def prove_once():
+        gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bld), vp(pre), plen, vp(cf), vp(pf)), "bppp_rp_prove_batch")
+
+    prove_once()                                     # warm-up (workspaces, fixed-base table)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    for _ in range(prove_steps):
+        prove_once()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    pdt = time.perf_counter() - tp0
+    if dist is not None:
+        t = torch.tensor([pdt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pdt = float(t.item())
+    assert len({pf[b * shp["proof_bytes"]:(b + 1) * shp["proof_bytes"]].tobytes() for b in range(min(batch, 512))}) == min(batch, 512), "proofs are not distinct"
+    prove = {"metric": "range_proofs_proved_per_sec", "value": world * batch * prove_steps / pdt, "unit": "proofs/s", "ms_per_batch": pdt / prove_steps * 1e3,
+             "batch_per_gpu": batch, "replicas": world, "shape": f"{shape}: {count} x 64-bit values per proof, nrmLen {nlen}, linLen {llen}, {k} rounds",
+             "scope": "proveM of RangeProof (src/RangeProof.hs:93-97) end to end: host inputs in, the reference's commitments / proof files out; "
+                      "all group operations on the GPU, per-proof field algebra and SHA-256 transcripts on the host cores (bppp_rp_prove_batch)"}
+
+    # ---- verify
+    d_c = torch.from_numpy(cf).to(dev)
+    d_p = torch.from_numpy(pf).to(dev)
+    seed = bytes((17 * rank + i) & 0xFF for i in range(32))
 
     def step():
-        tabs.public_device(batch, d["ch"].data_ptr(), d["q"].data_ptr(), d["sp"].data_ptr(), d["pub_norm"].data_ptr(), d["pub_lin_c"].data_ptr(),
-                           d["is"].data_ptr())
-        rc = gpu.lib.bppp_nl_verify_batch_device(gpu.h, batch, nlen, llen, k, fn, fl, ninit, *[_ptr(d[x].data_ptr()) for x in
-                                                 ("g", "G", "H", "rho", "q", "sp", "pub_norm", "pub_lin_c", "pub_lin_x", "es", "wn", "wl", "is", "ip", "rp")],
-                                                 _ptr(out))
-        gpu._check(rc, "bppp_nl_verify_batch_device")
-        part = array_to_point(out)
+        ok, part = nat.verify_batch_device_point(batch, d_c.data_ptr(), d_p.data_ptr(), seed)
+        assert ok, "batch of valid proofs did not verify"
         return part if world == 1 else combine(part)
 
-    for _ in range(warmup):
+    for _ in range(max(warmup, 1)):
         res = step()
-    assert res is None, "batch of valid proofs did not verify"
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -201,44 +211,56 @@ def bench_verify(gpu, torch, dev, rank, world, dist, combine, batch: int, n_real
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert res is None
+    # the host-buffer entry point (files in pageable host memory: PCIe-inclusive, never `value`)
+    th0 = time.perf_counter()
+    acc = C.c_int(0)
+    sd = np.frombuffer(seed, dtype=np.uint8)
+    gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(cf), vp(pf), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
+    hdt = time.perf_counter() - th0
+    assert acc.value == 1
+    # a corrupted member must be rejected (one flipped sign bit)
+    pf_bad = pf.copy(); pf_bad[(batch // 2) * shp["proof_bytes"] + 32 * (fn + fl)] ^= 1
+    gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(cf), vp(pf_bad), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
+    assert acc.value == 0, "a corrupted proof was accepted"
     terms = nlen + llen + 1 + batch * (ninit + 2 * k)
-    tabs.close()
     # algorithmic bytes per proof: (ninit + 2k) per-proof pairs x 96 B + (nlen + llen + 1) shared-basis scalars x 32 B
     bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
-    res_d = {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
-            "ms_per_batch": dt / steps * 1e3, "batch_per_gpu": batch, "combined_msm_terms": terms,
-            "algorithmic_bytes_per_proof": bytes_per_proof,
-            "achieved_GBps": world * batch * steps * bytes_per_proof / dt / 1e9, "hbm_frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world),
-            "shape": f"{shape}: nrmLen {nlen}, linLen {llen}, {k} rounds, {ninit}+{2 * k} per-proof points (SURVEY.md App. B)",
-            "proofs": f"{n_real} real range proofs ({count} x 64-bit values each{', typed/conserved' if typed else ''}) from the GPU-backed prover, "
-                      f"tiled to {batch}; all verify (combined MSM = infinity)",
-            "scope": "verifyM of RangeProof (src/RangeProof.hs:103-105) from the challenges on: public scalars (verifyTRRPM's arithmetic, "
-                     "bppp_trrp_public_device) + challenge expansion + shared-basis merge + the combined MSM, all timed, all on the GPU; the "
-                     "Fiat-Shamir hashing (injected oracle, host Python stand-in) is reported as host_hash_ms_per_proof",
-            "gpu_prove_ms_per_proof": prove_s * 1e3, "host_hash_ms_per_proof": derive_s * 1e3}
+    file_bytes = shp["coms_bytes"] + shp["proof_bytes"]
+    verify = {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
+              "ms_per_batch": dt / steps * 1e3, "batch_per_gpu": batch, "combined_msm_terms": terms,
+              "algorithmic_bytes_per_proof": bytes_per_proof, "encoded_bytes_per_proof": file_bytes,
+              "achieved_GBps": world * batch * steps * bytes_per_proof / dt / 1e9, "hbm_frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world),
+              "shape": f"{shape}: nrmLen {nlen}, linLen {llen}, {k} rounds, {ninit}+{2 * k} per-proof points (SURVEY.md App. B)",
+              "proofs": f"{batch} DISTINCT real range proofs per GPU ({count} x 64-bit values each{', typed/conserved' if typed else ''}) made by the lockstep "
+                        "prover in this run; all verify; one corrupted member is rejected",
+              "scope": "verifyM of RangeProof END TO END (src/RangeProof.hs:99-105) from the encoded files resident in HBM: decodeProof (square roots, "
+                       "signs), every SHA-256 transcript hash of verifyTRRPM / verifyBPM (shaOracle, app/Main.hs:64-80), public scalars, challenge "
+                       "expansion, shared-basis merge, ONE combined MSM — all on the GPU, all timed (bppp_rp_verify_batch_device)",
+              "host_buffer_call": {"entry": "bppp_rp_verify_batch (files in pageable host memory, %d B per proof over PCIe)" % file_bytes,
+                                   "ms_per_batch": hdt * 1e3, "value": batch / hdt, "unit": "verifies/s"}}
     if cpu_baseline_leg and rank == 0:
         # the reference verifies ONE proof with ONE 256-row Straus MSM over nlen + llen + 1 + ninit + 2k terms
         # (src/Bulletproof.hs:377): time the oracle's restatement of that on this host (single thread)
-        import ctypes
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
+        from bulletproofspp_amd.capi import points_to_array
         ec = pyoracle.CEC()
         nterm = nlen + llen + 1 + ninit + 2 * k
         sc = rng.integers(0, 2**64, size=(nterm, 4), dtype=np.uint64)
         sc[:, 3] = np.minimum(sc[:, 3], np.uint64(0xFFFFFFFFFFFFFFFD))
-        pts_np = np.ascontiguousarray(np.concatenate([points_to_array(gs), points_to_array(hs), points_to_array([g]),
-                                                      np.concatenate([points_to_array(p["init"]) for p in proofs[:1]]),
-                                                      np.concatenate([points_to_array(p["resp"]) for p in proofs[:1]])]))
-        u64p = ctypes.POINTER(ctypes.c_uint64)
+        basis = points_to_array(list(st.gs) + list(st.hs) + [st.g])
+        pts_np = np.ascontiguousarray(np.concatenate([basis, np.tile(basis[:1], (ninit + 2 * k, 1))]))
+        u64p = C.POINTER(C.c_uint64)
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
             ec.inner_product_raw(sc.ctypes.data_as(u64p), pts_np.ctypes.data_as(u64p), nterm)
         cdt = (time.perf_counter() - t0) / reps
-        res_d["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "verifies/s", "cores": 1, "kind": "port",
-                                 "sample": f"{reps} single-proof verifier MSMs of {nterm} terms (the reference's one commit per verify, Bulletproof.hs:377) "
-                                           "through oracle/bppp_oracle.c's 256-row Straus restatement"}
-    return res_d
+        verify["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                                  "sample": f"{reps} single-proof verifier MSMs of {nterm} terms (the reference's one commit per verify, Bulletproof.hs:377) "
+                                            "through oracle/bppp_oracle.c's 256-row Straus restatement; hashing and decoding not included (they favour the baseline)"}
+    nat.close()
+    return verify, prove
 
 
 def prove_cpu_baseline(shape: str, reps: int = 2):
@@ -258,115 +280,8 @@ def prove_cpu_baseline(shape: str, reps: int = 2):
         O.prove_bp(k, com, O.Transcript(O.sha_oracle_fn(b"cpu%d" % j)), ec)
     dt = (time.perf_counter() - t0) / reps
     return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} arguments of the same shape, proveBPM through the oracle restatement (Straus commits, 129-row pair folds), single thread"}
-
-
-def bench_prove(gpu, torch, dev, rank, batch: int, steps: int, shape: str = "64by64", pipelines: int = 2, world: int = 1, dist=None):
-    """Lockstep batch prover (bppp_nlb_*): `batch` norm-linear arguments of the examples/64by64 shape advanced round by round
-    together (proveBPM, src/Bulletproof.hs:357-359).  The injected oracle is a SHA-256 stand-in over the raw 128 bytes of each
-    proof's (X, R) chained with that proof's previous digest; hashing runs on the host inside the timed region (it is part of
-    a prover's round trip), everything else on the GPU.  The batch is split over `pipelines` contexts (one HIP stream and
-    one host thread each): a round's host share (challenge hashing, half-GCDs) and its latency-bound window combine
-    of one part overlap the other part's kernels."""
-    import ctypes as C
-    import hashlib
-    import threading
-    from bulletproofspp_amd.bulletproof import N_ORDER
-    from bulletproofspp_amd.capi import Bppp, _ptr
-    nlen, llen, k, fn, fl, _ = SHAPES[shape]
-    rng = np.random.default_rng(0x9E0 + rank)
-    need = 1 + llen + nlen
-    pts = None
-    while pts is None or pts.shape[0] < need:
-        xs = rng.integers(0, 2**64, size=(3 * need, 4), dtype=np.uint64)
-        dx = torch.from_numpy(xs.view(np.int64)).to(dev)
-        dp = torch.zeros((3 * need, 8), dtype=torch.int64, device=dev)
-        gpu.lift_x(dx.data_ptr(), 3 * need, dp.data_ptr())
-        pts = dp[(dp != 0).any(dim=1)]
-    P = np.ascontiguousarray(pts[:need].cpu().numpy().view(np.uint64))
-    rnd_fr = lambda shape_: np.minimum(rng.integers(0, 2**64, size=shape_ + (4,), dtype=np.uint64), np.uint64(0xFFFFFFFFFFFFFFFD))
-    xs_, ls_, cs_, qs_ = rnd_fr((batch, nlen)), rnd_fr((batch, llen)), rnd_fr((batch, llen)), rnd_fr((batch,))
-    ss_ = rnd_fr((batch,))        # the scalar on g only shifts the commitments; any value exercises the same work
-    lib = gpu.lib
-    pipelines = max(1, min(pipelines, batch // 64 if batch >= 128 else 1))
-    ctxs = [gpu] + [Bppp(gpu_device(dev)) for _ in range(pipelines - 1)]
-    bounds = [batch * i // pipelines for i in range(pipelines + 1)]
-    tm = {"create": 0.0, "round_commit": 0.0, "oracle_hash": 0.0, "round_collapse": 0.0, "get_witness": 0.0}
-    lock = threading.Lock()
-    errors = []
-
-    def part(g, lo, hi):
-        try:
-            nb = hi - lo
-            loc = dict.fromkeys(tm, 0.0)
-            t = time.perf_counter()
-            h = C.c_void_p()
-            c_ = lambda a: np.ascontiguousarray(a)
-            rc = lib.bppp_nlb_create(g.h, nb, _ptr(c_(ss_[lo:hi])), _ptr(P[0:1]), _ptr(c_(qs_[lo:hi])), _ptr(c_(xs_[lo:hi]).reshape(-1, 4)),
-                                     _ptr(P[1 + llen:1 + llen + nlen]), nlen, _ptr(c_(cs_[lo:hi]).reshape(-1, 4)), _ptr(c_(ls_[lo:hi]).reshape(-1, 4)),
-                                     _ptr(P[1:1 + llen]), llen, C.byref(h))
-            g._check(rc, "bppp_nlb_create")
-            sX, sR = np.zeros((nb, 4), dtype=np.uint64), np.zeros((nb, 4), dtype=np.uint64)
-            X, R = np.zeros((nb, 8), dtype=np.uint64), np.zeros((nb, 8), dtype=np.uint64)
-            digests = [b"bppp%d" % b for b in range(lo, hi)]
-            t2 = time.perf_counter(); loc["create"] += t2 - t; t = t2
-            for _ in range(k):
-                g._check(lib.bppp_nlb_round_commit(h, _ptr(sX), _ptr(X), _ptr(sR), _ptr(R)), "bppp_nlb_round_commit")
-                t2 = time.perf_counter(); loc["round_commit"] += t2 - t; t = t2
-                xb, rb = X.tobytes(), R.tobytes()
-                eb = []
-                for b in range(nb):
-                    d = digests[b] = hashlib.sha256(digests[b] + xb[64 * b:64 * b + 64] + rb[64 * b:64 * b + 64]).digest()
-                    eb.append((int.from_bytes(d, "little") % N_ORDER).to_bytes(32, "little"))
-                es = np.frombuffer(b"".join(eb), dtype=np.uint64).reshape(nb, 4)
-                t2 = time.perf_counter(); loc["oracle_hash"] += t2 - t; t = t2
-                g._check(lib.bppp_nlb_round_collapse(h, _ptr(es)), "bppp_nlb_round_collapse")
-                t2 = time.perf_counter(); loc["round_collapse"] += t2 - t; t = t2
-            nw, lw, s = np.zeros((nb * fn, 4), dtype=np.uint64), np.zeros((nb * fl, 4), dtype=np.uint64), np.zeros((nb, 4), dtype=np.uint64)
-            g._check(lib.bppp_nlb_get_witness(h, _ptr(nw), _ptr(lw), _ptr(s)), "bppp_nlb_get_witness")
-            lib.bppp_nlb_destroy(h)
-            loc["get_witness"] += time.perf_counter() - t
-            with lock:
-                for kk in tm:
-                    tm[kk] += loc[kk] / pipelines
-        except Exception as e:      # surfaced by one_batch
-            errors.append(e)
-
-    def one_batch():
-        th = [threading.Thread(target=part, args=(ctxs[i], bounds[i], bounds[i + 1])) for i in range(1, pipelines)]
-        for t_ in th:
-            t_.start()
-        part(ctxs[0], bounds[0], bounds[1])
-        for t_ in th:
-            t_.join()
-        if errors:
-            raise errors[0]
-
-    one_batch()
-    torch.cuda.synchronize()
-    for kk in tm:
-        tm[kk] = 0.0
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_batch()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:                       # the prover does not shard (sequential challenges): N independent replicas, max time over ranks
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    for g in ctxs[1:]:
-        g.close()
-    return {"metric": "norm_linear_arguments_proved_per_sec", "value": world * batch * steps / dt, "unit": "proofs/s", "ms_per_batch": dt / steps * 1e3,
-            "batch_per_gpu": batch, "replicas": world, "pipelines": pipelines, "rounds": k, "shape": f"{shape}: nrmLen {nlen}, linLen {llen}",
-            "host_call_ms_per_batch": {kk: v / steps * 1e3 for kk, v in tm.items()},
-            "note": "lockstep batch prover (bppp_nlb_*): 2*batch round commitments per round as one batched MSM, all basis folds as one launch; "
-                    "host SHA-256 stand-in oracle inside the timed region; state upload + final opening download included; "
-                    "host_call_ms_per_batch is the mean over pipelines of the wall time inside each call"}
+            "sample": f"{reps} norm-linear arguments of the same shape, proveBPM through the oracle restatement (Straus commits, 129-row pair folds), single "
+                      "thread; the range-proof phases before the argument (4 + #values more commits) are NOT included, which favours the baseline"}
 
 
 def gpu_device(dev) -> int:
@@ -382,11 +297,8 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="Pippenger window bits (0 = library heuristic)")
     ap.add_argument("--cpu-sample-log2", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify-batch", type=int, default=4096, help="proofs per GPU in the batch-verify leg (0 = skip)")
-    ap.add_argument("--verify-real", type=int, default=16, help="distinct real proofs generated by the GPU prover")
+    ap.add_argument("--verify-batch", type=int, default=4096, help="distinct proofs per GPU proved in lockstep and then batch-verified end to end (0 = skip both legs)")
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
-    ap.add_argument("--prove-pipelines", type=int, default=2, help="contexts (stream + host thread) the prover batch is split over")
-    ap.add_argument("--prove-batch", type=int, default=2048, help="proofs advanced in lockstep per GPU in the prover leg (0 = skip); N > 1 runs N independent replicas")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -472,6 +384,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # BASELINE config 2: the 2^16-term MSM (the first 2^16 pairs of the same synthetic inputs), same entry point
+    small = None
+    if world == 1 and args.log2n > 16:
+        n16 = 1 << 16
+        r16 = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), n16, 0)
+        gpu.profile_read(reset=True); gpu.profile_enable(True)
+        torch.cuda.synchronize()
+        t16 = time.perf_counter()
+        reps16 = max(10, args.steps)
+        for _ in range(reps16):
+            r16b = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), n16, 0)
+        torch.cuda.synchronize()
+        d16 = time.perf_counter() - t16
+        st16, c16 = gpu.profile_read(reset=True)
+        gpu.profile_enable(False)
+        assert r16b == r16
+        small = {"workload": "pedersen_msm_2^16_secp256k1 (BASELINE config 2)", "value": n16 * reps16 / d16, "unit": "pairs/s", "ms_per_msm": d16 / reps16 * 1e3,
+                 "stages_ms_per_msm": {k_: v_ / max(c16, 1) for k_, v_ in st16.items()}}
+
     # throughput with several MSMs in flight (one context = one stream + one host thread each): the latency-bound stages of one
     # (bucket reduction, window combine, the host round trip) overlap the accumulate kernel of another.  Reported beside the
     # single-stream headline, whose per-kernel durations are what the roofline and the rocprof summaries refer to.
@@ -516,17 +447,14 @@ def main():
                      "value": n / hdt, "unit": "pairs/s"}
         del sc_h, pt_h
 
-    verify = None
+    verify = prove = None
     if args.verify_batch > 0:
         vsteps = max(3, args.steps // 2)
-        verify = bench_verify(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, args.verify_real, vsteps, 1, "64by64",
-                              cpu_baseline_leg=(world == 1 and not args.no_cpu_baseline))
-        verify["other_shapes"] = [bench_verify(gpu, torch, dev, rank, world, dist, combine, max(1, args.verify_batch // 2), max(2, args.verify_real // 4),
-                                               vsteps, 1, "128by64+typed")]
-
-    prove = None
-    if args.prove_batch > 0:
-        prove = bench_prove(gpu, torch, dev, rank, args.prove_batch, 2, pipelines=args.prove_pipelines, world=world, dist=dist)
+        verify, prove = bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, vsteps, 1, "64by64",
+                                          cpu_baseline_leg=(world == 1 and not args.no_cpu_baseline))
+        v2, p2 = bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, max(1, args.verify_batch // 2), vsteps, 1, "128by64+typed")
+        verify["other_shapes"] = [v2]
+        prove["other_shapes"] = [p2]
         if world == 1 and not args.no_cpu_baseline:
             prove["cpu_baseline"] = prove_cpu_baseline("64by64")
 
@@ -553,6 +481,7 @@ def main():
                        "algorithm": "signed-digit Pippenger, affine in / XYZZ buckets", "sharding": f"terms/{world}" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_acc_points", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload), not measured in this run",
                          "note": "algorithmic 96 B/pair x 2^%d pairs per launch / mean k_acc_points duration (HIP events); "
                                  "the kernel is VALU-bound (256-bit modular multiplies), see DESIGN.md" % args.log2n},
             "stages_ms_per_step": {k: v * calls / launches for k, v in per_call.items()},
@@ -590,6 +519,8 @@ def main():
             mt_rate, mt_cores, mt_dt = cpu_baseline_threads(sc_np, pts_np, per_thread)
             out["cpu_baseline_all_cores"] = {"value": mt_rate, "unit": "pairs/s", "cores": mt_cores, "kind": "port",
                                              "sample": f"{mt_cores} threads x {per_thread} pairs, same restatement, one slice per thread", "seconds": mt_dt}
+        if small is not None:
+            out["msm_2_16"] = small
         if concurrent is not None:
             out["concurrent"] = concurrent
         if host_call is not None:

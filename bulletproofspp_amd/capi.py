@@ -110,8 +110,8 @@ def load_library() -> C.CDLL:
     lib.bppp_rp_destroy.argtypes = [vp]
     lib.bppp_rp_destroy.restype = None
     lib.bppp_rp_info.argtypes = [vp, vp]
-    lib.bppp_rp_verify_batch.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp]
-    lib.bppp_rp_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp]
+    lib.bppp_rp_verify_batch.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp, vp]
+    lib.bppp_rp_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp, vp]
     lib.bppp_rp_prove_batch.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, vp]
     lib.bppp_profile_enable.argtypes = [vp, i]
     lib.bppp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]

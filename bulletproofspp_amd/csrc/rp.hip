@@ -431,11 +431,12 @@ int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t
                                 const void *d_init_scalars, const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
 
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
-                                uint32_t *proof_status, uint64_t *challenges_out) {
+                                uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
   if (!rp || !accept) return BPPP_ERR_ARG;
   bppp_ctx *ctx = rp->ctx;
   if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   *accept = 0;
+  if (combined_xy) memset(combined_xy, 0, 64);
   if (!batch) { *accept = 1; return BPPP_OK; }
   if (!d_coms_files || !d_proof_files || !seed || batch >= (1u << 22)) return fail(ctx, BPPP_ERR_ARG, "rp_verify_batch: bad arguments");
   hipSetDevice(ctx->device);
@@ -487,6 +488,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
   for (size_t b = 0; b < B; b++) any_bad |= hbad[b] != 0;
   auto is_inf = [](const uint64_t *p) { uint64_t o = 0; for (int i = 0; i < 8; i++) o |= p[i]; return o == 0; };
   const bool whole = is_inf(out_xy);
+  if (combined_xy) memcpy(combined_xy, out_xy, 64);
   *accept = (whole && !any_bad) ? 1 : 0;
   if (!proof_status) return BPPP_OK;
   for (size_t b = 0; b < B; b++) proof_status[b] = hbad[b] ? BPPP_RP_MALFORMED : BPPP_RP_VALID;
@@ -517,7 +519,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
 }
 
 int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, const uint8_t *proof_files, const uint8_t seed[32], int *accept,
-                         uint32_t *proof_status, uint64_t *challenges_out) {
+                         uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
   if (!rp || !accept) return BPPP_ERR_ARG;
   bppp_ctx *ctx = rp->ctx;
   if (ctx_closed(ctx)) return BPPP_ERR_ARG;
@@ -538,7 +540,7 @@ int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, c
   if (hipMemcpyAsync(stage, coms_files, cb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
       hipMemcpyAsync((char *)stage + cbp, proof_files, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
     rc = fail(ctx, BPPP_ERR_HIP, "rp_verify_batch: upload failed");
-  if (!rc) rc = bppp_rp_verify_batch_device(rp, batch, stage, (char *)stage + cbp, seed, accept, proof_status, challenges_out);
+  if (!rc) rc = bppp_rp_verify_batch_device(rp, batch, stage, (char *)stage + cbp, seed, accept, proof_status, challenges_out, combined_xy);
   hipStreamSynchronize(ctx->stream);
   return rc;
 }

@@ -908,6 +908,18 @@ class NativeRangeProofs:
         import ctypes as C
         return self._verify(self.gpu.lib.bppp_rp_verify_batch_device, batch, C.c_void_p(d_coms), C.c_void_p(d_proofs), seed, want_status, want_challenges, None)
 
+    def verify_batch_device_point(self, batch: int, d_coms: int, d_proofs: int, seed: bytes) -> Tuple[bool, Point]:
+        """(accept, the combined point) — the partial result of one rank when the batch is sharded proof-per-GPU"""
+        import ctypes as C
+        import numpy as np
+        from .capi import array_to_point
+        acc, out = C.c_int(0), np.zeros(8, dtype=np.uint64)
+        sd = np.frombuffer(seed, dtype=np.uint8)
+        rc = self.gpu.lib.bppp_rp_verify_batch_device(self.h, batch, C.c_void_p(d_coms), C.c_void_p(d_proofs), C.c_void_p(sd.ctypes.data), C.byref(acc), None, None,
+                                                      C.c_void_p(out.ctypes.data))
+        self.gpu._check(rc, "bppp_rp_verify_batch_device")
+        return bool(acc.value), array_to_point(out)
+
     def _verify(self, fn, B, pc, pp, seed, want_status, want_challenges, keep):
         import ctypes as C
         import numpy as np
@@ -918,7 +930,7 @@ class NativeRangeProofs:
         chal = np.zeros((max(B, 1) * nch, 4), dtype=np.uint64) if want_challenges else None
         sd = np.frombuffer(seed, dtype=np.uint8)
         rc = fn(self.h, B, pc, pp, C.c_void_p(sd.ctypes.data), C.byref(acc), C.c_void_p(status.ctypes.data) if want_status else None,
-                C.c_void_p(chal.ctypes.data) if want_challenges else None)
+                C.c_void_p(chal.ctypes.data) if want_challenges else None, None)
         self.gpu._check(rc, "bppp_rp_verify_batch")
         if not (want_status or want_challenges):
             return bool(acc.value)

@@ -303,14 +303,17 @@ int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out);
  * the reference); when the batch is rejected the culprits are found by bisection over sub-batches (each a combined MSM).
  * challenges_out (may be NULL, [batch][7 + rounds][4]): (e, x, r0, q, x', r1, t) then the argument's challenges LAST ROUND FIRST
  * (src/Bulletproof.hs:374) — what the injected-oracle route would have been given; for parity tests.
+ * combined_xy (may be NULL): the combined point sum_b rho_b MSM(T_b) itself (infinity = all zero).  With the batch sharded
+ * proof-per-GPU every rank gets its own partial point; the ranks all-gather the 64-byte points (RCCL) and add them with
+ * bppp_sum_points: the whole job verifies iff that sum is the identity and no rank saw a malformed proof.
  * _device: the files are already in HBM (the timed configuration of bench.py); the host variant uploads them first. */
 #define BPPP_RP_VALID 0u
 #define BPPP_RP_INVALID 1u
 #define BPPP_RP_MALFORMED 2u
 int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, const uint8_t *proof_files, const uint8_t seed[32], int *accept,
-                         uint32_t *proof_status, uint64_t *challenges_out);
+                         uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy);
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
-                                uint32_t *proof_status, uint64_t *challenges_out);
+                                uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy);
 
 /* Batch prover: `batch` proofs of this setup in lockstep — proveM of RangeProof (src/RangeProof.hs:93-97) = proveTRRPM
  * (src/RangeProof/TypedReciprocal.hs:399-446; blinding algebra src/RangeProof/Internal.hs:118-196) followed by proveBPM
