@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--check-combined", action="store_true", help="N > 1: rank 0 also computes the whole sharded MSM alone (all ranks' inputs regenerated "
+                                                                  "from their seeds) and asserts the combined point equals it")
     args = ap.parse_args()
 
     import torch
@@ -377,6 +379,15 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    combined_check = None
+    if world > 1 and args.check_combined and rank == 0:
+        # the sharded job as ONE single-rank MSM: every rank's slice regenerated from its seed, concatenated in rank order
+        parts = [make_inputs(gpu, torch, dev, n, seed=0xB9B9 + r) for r in range(world)]
+        all_sc, all_pt = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+        whole = gpu.msm_device(all_sc.data_ptr(), all_pt.data_ptr(), n * world, 0)
+        assert whole == res, "combined point of the sharded MSM differs from the single-rank MSM over all terms"
+        combined_check = "sum of %d rank-local MSMs == single-rank MSM over all %d terms" % (world, n * world)
+        del parts, all_sc, all_pt
     stages, calls = gpu.profile_read(reset=True)
     gpu.profile_enable(False)
     if dist is not None:
@@ -519,6 +530,8 @@ def main():
             mt_rate, mt_cores, mt_dt = cpu_baseline_threads(sc_np, pts_np, per_thread)
             out["cpu_baseline_all_cores"] = {"value": mt_rate, "unit": "pairs/s", "cores": mt_cores, "kind": "port",
                                              "sample": f"{mt_cores} threads x {per_thread} pairs, same restatement, one slice per thread", "seconds": mt_dt}
+        if combined_check is not None:
+            out["combined_check"] = combined_check
         if small is not None:
             out["msm_2_16"] = small
         if concurrent is not None:

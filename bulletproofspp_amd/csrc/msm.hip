@@ -11,12 +11,15 @@
 //                    staged in LDS (<= 128 KiB per workgroup), so HBM sees only coalesced streams.
 //   3. k_acc_points / k_merge / k_merge_heavy
 //                    load-balanced bucket accumulation: every lane owns exactly L consecutive
-//                    sorted entries (not one bucket), sums runs of equal key in an XYZZ register
+//                    sorted entries (4 bytes each: sign | point index; the bucket of a position follows from the
+//                    bucket offsets start[], it is not stored), sums runs of one bucket in an XYZZ register
 //                    accumulator with mixed adds and stores complete buckets; a bucket that
 //                    straddles lanes is finished by k_merge (one lane per bucket) or, when it spans
 //                    many lanes (skewed scalars), by one wavefront in k_merge_heavy.
-//   4. k_reduce1/2   sum_m m*B_m per window by per-lane running sums plus a wavefront suffix scan
-//                    (shuffles of whole points), then across wavefronts.
+//   4. k_reduce_marg / k_reduce_tail
+//                    sum_m m*B_m per window by MARGINAL SUMS (m = LO*hi + lo: plain row and column sums, every lane busy,
+//                    then two short weighted sums); k_reduce1/2 (per-lane running sums + wavefront suffix scans) for windows
+//                    under 256 buckets, k_reduce_groups for thousands of small windows.
 //   5. window combine: Horner over <= 65 window sums — on the host for one MSM (a 256-doubling
 //                    dependency chain), in k_window_combine for batches.
 //
@@ -29,7 +32,6 @@
 
 namespace bppp {
 
-static constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 
 struct RecodeK { uint32_t k[9]; };
 
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 
 __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long long *__restrict__ negmask, uint32_t n, uint32_t stride, int c,
                           int CH, int W, const uint32_t *__restrict__ blockhist, const uint32_t *__restrict__ start,
-                          unsigned long long *__restrict__ sorted) {
+                          uint32_t *__restrict__ sorted) {
   extern __shared__ uint32_t lh[];
   const int M = 1 << (c - 1);
   const uint32_t nbw = blockIdx.x, ch = blockIdx.y;
@@ -191,8 +193,7 @@ __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long 
         uint32_t sneg = (uint32_t)((mw >> (flat & 63)) & 1ull);
         uint32_t sg = (v < 0 ? 1u : 0u) ^ sneg;
         uint32_t pos = atomicAdd(&lh[mb], 1u);
-        uint32_t key = nbw * M + mb;
-        sorted[pos] = ((unsigned long long)key << 32) | ((unsigned long long)sg << 31) | (j0 + k);
+        sorted[pos] = (sg << 31) | (j0 + k);          // 4 bytes: the bucket is implied by start[] (position -> bucket), not stored
       }
     }
   }
@@ -206,40 +207,45 @@ __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long 
 //   lanes g0 < g <= g1 (run continues from g-1) -> head slot 2*g
 // which k_merge (one lane per bucket, short spans) or k_merge_heavy (one wavefront per bucket)
 // add up.  Slots are addressed from start/count alone: no keys are stored, no compaction needed.
-__global__ void __launch_bounds__(256) k_acc_points(const unsigned long long *__restrict__ sorted, const uint32_t *__restrict__ total_p,
+__global__ void __launch_bounds__(256) k_acc_points(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ start, uint32_t FB,
                                                     const uint32_t *__restrict__ points, uint32_t n, uint32_t WM, int shared_pts,
                                                     int L, uint64_t G, uint32_t *__restrict__ buckets, uint32_t *__restrict__ rec_pt) {
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
-  const uint32_t total = *total_p;
-  uint64_t pos0 = g * (uint64_t)L;
+  const uint32_t total = start[FB];
+  const uint64_t pos0 = g * (uint64_t)L;
   if (pos0 >= total) return;
-  uint64_t pos1 = min((uint64_t)total, pos0 + L);
-  uint32_t prev_key = pos0 ? (uint32_t)(sorted[pos0 - 1] >> 32) : KEY_EMPTY;
-  uint32_t next_key = pos1 < total ? (uint32_t)(sorted[pos1] >> 32) : KEY_EMPTY;
-  unsigned long long e = sorted[pos0];
-  uint32_t cur = (uint32_t)(e >> 32);
+  const uint32_t pos1 = (uint32_t)min((uint64_t)total, pos0 + L);
+  // the bucket that holds position pos0: the largest fb with start[fb] <= pos0 (it is non-empty: start[fb + 1] > pos0)
+  uint32_t lo = 0, hi = FB - 1;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo + 1) / 2;
+    if (start[mid] <= (uint32_t)pos0) lo = mid; else hi = mid - 1;
+  }
+  uint32_t cur = lo, end = start[cur + 1];
+  const bool from_prev = start[cur] < (uint32_t)pos0;         // the first run continues one that began in an earlier lane
   bool first = true;
+  uint32_t e = sorted[pos0];
   xyzz acc = xyzz_inf();
-  for (uint64_t p = pos0; p < pos1; p++) {
-    uint32_t k = (uint32_t)(e >> 32);
-    uint32_t idx = (uint32_t)e & 0x7FFFFFFFu;
-    bool sg = ((uint32_t)e >> 31) & 1u;
-    unsigned long long e_next = (p + 1 < pos1) ? sorted[p + 1] : 0ull;
-    if (k != cur) {
+  for (uint32_t p = (uint32_t)pos0; p < pos1; p++) {
+    const uint32_t e_next = (p + 1 < pos1) ? sorted[p + 1] : 0u;
+    if (p == end) {
       // the finished run ends inside this lane: head partial if it came from the previous lane, else complete
-      if (first && cur == prev_key) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
+      if (first && from_prev) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
       else xyzz_store(buckets + (size_t)cur * XYZZ_WORDS, acc);
-      first = false; cur = k; acc = xyzz_inf();
+      first = false; acc = xyzz_inf();
+      do { cur++; end = start[cur + 1]; } while (end <= p);   // next non-empty bucket
     }
+    const uint32_t idx = e & 0x7FFFFFFFu;
+    const bool sg = (e >> 31) & 1u;
     // shared_pts: 1 = one point array for every instance, 0 = one per instance, d >= 2 = one per d consecutive instances
-    size_t pidx = shared_pts == 1 ? (size_t)idx : (size_t)((k / WM) / (shared_pts ? shared_pts : 1)) * n + idx;
+    size_t pidx = shared_pts == 1 ? (size_t)idx : (size_t)((cur / WM) / (shared_pts ? shared_pts : 1)) * n + idx;
     aff P = aff_cneg(aff_load(points + pidx * 16), sg);
     xyzz_madd(acc, P);
     e = e_next;
   }
-  bool hi = first && cur == prev_key, ti = cur == next_key;
-  if (hi) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
+  const bool hi_part = first && from_prev, ti = end > pos1;   // the last run goes on in the next lane
+  if (hi_part) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
   else if (ti) xyzz_store(rec_pt + (2 * g + 1) * XYZZ_WORDS, acc);
   else xyzz_store(buckets + (size_t)cur * XYZZ_WORDS, acc);
 }
@@ -383,6 +389,83 @@ __global__ void __launch_bounds__(64) k_reduce2(const uint32_t *__restrict__ red
   if (lane == 0) xyzz_store(winsum + (size_t)nbw * XYZZ_WORDS, v);
 }
 
+// ---- 4'. bucket reduction by marginal sums (windows with M >= 256 buckets).
+// A dependent chain of point additions runs at ONE wavefront's instruction rate (~6 us per addition), so the running-sum scheme
+// above costs its depth: ~23 chained additions in k_reduce1 at 2 wavefronts per SIMD plus ~21 in k_reduce2 on 17 wavefronts.
+// Here the bucket index splits as i = hi * LO + lo (weight i + 1 = LO * hi + (lo + 1)):
+//     sum_i (i + 1) B_i  =  LO * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,     R_hi = sum_lo B,   C_lo = sum_hi B
+// R and C are PLAIN sums: k_reduce_marg gives every lane S consecutive (rows) or strided (columns) buckets — no scan, every
+// lane busy, one wavefront per SIMD — and finishes them with a short segmented tree.  The two weighted sums left are over HI and
+// LO (<= 256) elements: k_reduce_tail, one element per lane (suffix scan + tree, ~18 chained additions).  The factor LO is not
+// applied on the device at all: the window combine, which doubles c times per window anyway, takes (W1, W2) and does
+// r = (r * 2^(c-a) + W1) * 2^a + W2.
+struct MargGeom { int a, LO, HI, PR, PC, SR, SC; uint32_t row_tiles, col_tiles; };
+
+__global__ void __launch_bounds__(64) k_reduce_marg(const uint32_t *__restrict__ buckets, int M, MargGeom Gm, uint32_t *__restrict__ R, uint32_t *__restrict__ C) {
+  const uint32_t nbw = blockIdx.y, lane = threadIdx.x;
+  const uint32_t *wb = buckets + (size_t)nbw * M * XYZZ_WORDS;
+  xyzz acc = xyzz_inf();
+  if (blockIdx.x < Gm.row_tiles) {
+    const uint32_t r = blockIdx.x * 64 + lane, hi = r / (uint32_t)Gm.PR, part = r % (uint32_t)Gm.PR;
+    const bool act = hi < (uint32_t)Gm.HI;
+    if (act) {
+      const uint32_t *b = wb + ((size_t)hi * Gm.LO + (size_t)part * Gm.SR) * XYZZ_WORDS;
+      acc = xyzz_load(b);
+      for (int k = 1; k < Gm.SR; k++) { xyzz B = xyzz_load(b + (size_t)k * XYZZ_WORDS); xyzz_add(acc, B); }
+    }
+    for (int d = Gm.PR >> 1; d >= 1; d >>= 1) {
+      xyzz o = xyzz_shfl_down(acc, d);
+      if ((int)part + d < Gm.PR) xyzz_add(acc, o);
+    }
+    if (act && part == 0) xyzz_store(R + ((size_t)nbw * Gm.HI + hi) * XYZZ_WORDS, acc);
+  } else {
+    const uint32_t q = (blockIdx.x - Gm.row_tiles) * 64 + lane, lo = q / (uint32_t)Gm.PC, part = q % (uint32_t)Gm.PC;
+    const bool act = lo < (uint32_t)Gm.LO;
+    if (act) {
+      const uint32_t *b = wb + ((size_t)part * Gm.SC * Gm.LO + lo) * XYZZ_WORDS;
+      acc = xyzz_load(b);
+      for (int k = 1; k < Gm.SC; k++) { xyzz B = xyzz_load(b + (size_t)k * Gm.LO * XYZZ_WORDS); xyzz_add(acc, B); }
+    }
+    for (int d = Gm.PC >> 1; d >= 1; d >>= 1) {
+      xyzz o = xyzz_shfl_down(acc, d);
+      if ((int)part + d < Gm.PC) xyzz_add(acc, o);
+    }
+    if (act && part == 0) xyzz_store(C + ((size_t)nbw * Gm.LO + lo) * XYZZ_WORDS, acc);
+  }
+}
+
+// one workgroup per window: wavefronts [0, wr) hold R (one element per lane), wavefronts [wr, wr + wc) hold C
+__global__ void __launch_bounds__(512) k_reduce_tail(const uint32_t *__restrict__ R, const uint32_t *__restrict__ C, MargGeom Gm, uint32_t *__restrict__ winsum2) {
+  __shared__ __attribute__((aligned(16))) uint32_t tot[8 * XYZZ_WORDS];
+  const uint32_t nbw = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t wr = (uint32_t)(Gm.HI + 63) / 64, wc = (uint32_t)(Gm.LO + 63) / 64;
+  const bool isC = wv >= wr;
+  const uint32_t gw = isC ? wv - wr : wv, gn = isC ? wc : wr, gbase = isC ? wr : 0u;     // wavefront within its group, group size, first wavefront
+  const uint32_t idx = gw * 64 + lane, n = isC ? (uint32_t)Gm.LO : (uint32_t)Gm.HI;
+  xyzz suf = xyzz_inf();
+  if (idx < n) suf = xyzz_load((isC ? C + ((size_t)nbw * Gm.LO + idx) * XYZZ_WORDS : R + ((size_t)nbw * Gm.HI + idx) * XYZZ_WORDS));
+  for (int d = 1; d < 64; d <<= 1) {             // inclusive suffix scan inside the wavefront
+    xyzz o = xyzz_shfl_down(suf, d);
+    if ((int)lane + d < 64) xyzz_add(suf, o);
+  }
+  if (lane == 0) xyzz_store(tot + wv * XYZZ_WORDS, suf);
+  __syncthreads();
+  for (uint32_t w = gw + 1; w < gn; w++) { xyzz t = xyzz_load(tot + (gbase + w) * XYZZ_WORDS); xyzz_add(suf, t); }     // later wavefronts of the group
+  // R: sum_hi hi * R_hi = sum_{hi >= 1} suffix(hi);   C: sum_lo (lo + 1) * C_lo = sum_{lo >= 0} suffix(lo)
+  xyzz v = (!isC && idx == 0) ? xyzz_inf() : suf;
+  for (int d = 32; d >= 1; d >>= 1) {
+    xyzz o = xyzz_shfl_down(v, d);
+    if ((int)lane + d < 64) xyzz_add(v, o);
+  }
+  __syncthreads();
+  if (lane == 0) xyzz_store(tot + wv * XYZZ_WORDS, v);
+  __syncthreads();
+  if (lane == 0 && gw == 0) {
+    for (uint32_t w = 1; w < gn; w++) { xyzz t = xyzz_load(tot + (gbase + w) * XYZZ_WORDS); xyzz_add(v, t); }
+    xyzz_store(winsum2 + ((size_t)nbw * 2 + (isC ? 1 : 0)) * XYZZ_WORDS, v);
+  }
+}
+
 // Many small windows (batched MSMs of a few hundred terms: M <= 256 buckets per window, thousands of windows): a whole
 // wavefront per window leaves most lanes idle and pays two 6-step scans.  Here a GROUP of G lanes (G | 64, G <= M) owns one
 // window: lane g sums its Lw = M/G buckets serially, the G lane sums go through a log2(G)-step suffix scan inside the
@@ -416,14 +499,24 @@ __global__ void __launch_bounds__(64) k_reduce_groups(const uint32_t *__restrict
 }
 
 // 5. batched window combine: one lane per MSM instance
-__global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restrict__ winsum, int W, int c, uint32_t batch, uint32_t *__restrict__ out_aff) {
+// `a` > 0: every window comes as two points (W1, W2) with window value 2^a * W1 + W2 (marginal-sum reduction)
+__global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restrict__ winsum, int W, int c, int a, uint32_t batch, uint32_t *__restrict__ out_aff) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
   xyzz r = xyzz_inf();
   for (int w = W - 1; w >= 0; w--) {
-    for (int k = 0; k < c; k++) r = xyzz_dbl(r);
-    xyzz t = xyzz_load(winsum + ((size_t)b * W + w) * XYZZ_WORDS);
-    xyzz_add(r, t);
+    if (a) {
+      for (int k = 0; k < c - a; k++) r = xyzz_dbl(r);
+      xyzz t1 = xyzz_load(winsum + ((size_t)b * W + w) * 2 * XYZZ_WORDS);
+      xyzz_add(r, t1);
+      for (int k = 0; k < a; k++) r = xyzz_dbl(r);
+      xyzz t2 = xyzz_load(winsum + (((size_t)b * W + w) * 2 + 1) * XYZZ_WORDS);
+      xyzz_add(r, t2);
+    } else {
+      for (int k = 0; k < c; k++) r = xyzz_dbl(r);
+      xyzz t = xyzz_load(winsum + ((size_t)b * W + w) * XYZZ_WORDS);
+      xyzz_add(r, t);
+    }
   }
   aff_store(out_aff + (size_t)b * 16, xyzz_to_aff(r));
 }
@@ -456,6 +549,7 @@ struct MsmPlan {
   uint64_t NB, FB, total_max;
   int L; uint64_t G;           // sorted entries per lane, number of lanes
   int RG;                      // k_reduce_groups lanes per window (0 = wave-per-window path)
+  bool marg; MargGeom mg;      // marginal-sum reduction (M >= 256, not the grouped path)
   int ntiles;
 };
 
@@ -479,6 +573,21 @@ static MsmPlan make_plan(size_t n, size_t batch, int c) {
   }
   p.RG = 0;
   if (p.M <= 256 && p.NB >= 4096) p.RG = std::min(8, p.M);   // M is a power of two >= 2
+  p.marg = !p.RG && p.M >= 256 && p.NB <= 65535 && !getenv("BPPP_REDUCE_OLD");
+  memset(&p.mg, 0, sizeof p.mg);
+  if (p.marg) {
+    MargGeom &g = p.mg;
+    g.a = (c - 1 + 1) / 2; g.LO = 1 << g.a; g.HI = p.M / g.LO;          // LO >= HI, both <= 256
+    // serial length S per lane: about one wavefront per SIMD over the whole launch (2 * FB bucket reads over ~64K lanes)
+    int S = 1;
+    while (S < 16 && (2.0 * (double)p.FB) / S > 98304.0) S <<= 1;
+    if (const char *e = getenv("BPPP_MARG_S")) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = v; }
+    g.SR = std::min(S, g.LO); g.SC = std::min(S, g.HI);
+    g.PR = g.LO / g.SR; g.PC = g.HI / g.SC;
+    while (g.PR > 64) { g.PR >>= 1; g.SR <<= 1; }                        // the segmented tree lives inside one wavefront
+    while (g.PC > 64) { g.PC >>= 1; g.SC <<= 1; }
+    g.row_tiles = (uint32_t)(((size_t)g.HI * g.PR + 63) / 64); g.col_tiles = (uint32_t)(((size_t)g.LO * g.PC + 63) / 64);
+  }
   // slice length: long enough that few buckets straddle lanes, short enough to keep >= ~64K lanes
   p.L = 4;
   while (p.L < 64 && p.total_max / (uint64_t)(2 * p.L) >= 65536) p.L <<= 1;
@@ -523,7 +632,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     uint32_t *count = cv.take<uint32_t>(p.FB + 1);
     uint32_t *start = cv.take<uint32_t>(p.FB + 1);
     uint32_t *tiles = cv.take<uint32_t>(p.ntiles + 1);
-    unsigned long long *sorted = cv.take<unsigned long long>(p.total_max + 1);
+    uint32_t *sorted = cv.take<uint32_t>(p.total_max + 4);
     uint32_t *buckets = cv.take<uint32_t>((size_t)p.FB * XYZZ_WORDS);
     uint32_t *rec_pt = cv.take<uint32_t>((size_t)p.G * 2 * XYZZ_WORDS);
     // heavy buckets span > 9 lanes: at most G/9 of them, and at most G/256 + G/9 (bucket, chunk) items
@@ -532,8 +641,8 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     uint4 *heavy_buckets = cv.take<uint4>(hmax);
     uint32_t *chunk_sums = cv.take<uint32_t>(hmax * XYZZ_WORDS);
     uint32_t *heavy_count = cv.take<uint32_t>(4);
-    uint32_t *red = cv.take<uint32_t>((size_t)p.NB * p.WPW * 2 * XYZZ_WORDS);
-    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * XYZZ_WORDS);
+    uint32_t *red = cv.take<uint32_t>(p.marg ? (size_t)p.NB * (p.mg.HI + p.mg.LO) * XYZZ_WORDS : (size_t)p.NB * p.WPW * 2 * XYZZ_WORDS);
+    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * 2 * XYZZ_WORDS);
     uint32_t *out_aff = cv.take<uint32_t>((size_t)batch * 16);
     if (!pass) { need = cv.off; int rc = ensure_workspace(ctx, need); if (rc) return rc; continue; }
 
@@ -561,7 +670,7 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     prof_mark(ctx, 2);
     if (ctx->pre_acc) { auto f = ctx->pre_acc; ctx->pre_acc = nullptr; int rc_ = f(ctx->pre_acc_arg); if (rc_) return rc_; }
     // 3. accumulate
-    k_acc_points<<<dim3((unsigned)((p.G + 255) / 256)), dim3(256), 0, st>>>(sorted, start + p.FB, (const uint32_t *)d_points, (uint32_t)n,
+    k_acc_points<<<dim3((unsigned)((p.G + 255) / 256)), dim3(256), 0, st>>>(sorted, start, (uint32_t)p.FB, (const uint32_t *)d_points, (uint32_t)n,
                                                                            (uint32_t)(p.W * p.M), shared_points, p.L, p.G, buckets, rec_pt);
     prof_mark(ctx, 3);
     k_merge<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(start, count, p.FB, p.L, rec_pt, buckets, heavy_items, heavy_buckets, heavy_count);
@@ -571,6 +680,11 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     // 4. bucket reduce
     if (p.RG) {
       k_reduce_groups<<<dim3((unsigned)((p.NB * p.RG + 63) / 64)), dim3(64), 0, st>>>(buckets, p.M, p.RG, (uint32_t)p.NB, winsum);
+    } else if (p.marg) {
+      uint32_t *Rm = red, *Cm = red + (size_t)p.NB * p.mg.HI * XYZZ_WORDS;
+      k_reduce_marg<<<dim3(p.mg.row_tiles + p.mg.col_tiles, (unsigned)p.NB), dim3(64), 0, st>>>(buckets, p.M, p.mg, Rm, Cm);
+      const unsigned tail_threads = 64u * (unsigned)((p.mg.HI + 63) / 64 + (p.mg.LO + 63) / 64);
+      k_reduce_tail<<<dim3((unsigned)p.NB), dim3(tail_threads), 0, st>>>(Rm, Cm, p.mg, winsum);
     } else {
       k_reduce1<<<dim3((unsigned)p.NB, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
       k_reduce2<<<dim3((unsigned)p.NB), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
@@ -578,12 +692,12 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     prof_mark(ctx, 5);
     // 5. window combine
     if (batch > 4) {
-      k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.W, c, (uint32_t)batch, out_aff);
+      k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.W, c, p.marg ? p.mg.a : 0, (uint32_t)batch, out_aff);
       BPPP_HIP(ctx, hipMemcpyAsync(out_xy, out_aff, batch * 64, hipMemcpyDeviceToHost, st));
       prof_mark(ctx, 6);
       BPPP_HIP(ctx, hipStreamSynchronize(st));
     } else {
-      size_t bytes = (size_t)p.NB * XYZZ_WORDS * 4;
+      size_t bytes = (size_t)p.NB * (p.marg ? 2 : 1) * XYZZ_WORDS * 4;
       int rc = ensure_pinned(ctx, bytes); if (rc) return rc;
       BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
       prof_mark(ctx, 6);
@@ -591,10 +705,18 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
       const uint32_t *ws = (const uint32_t *)ctx->pinned;
       for (size_t b = 0; b < batch; b++) {
         HJac r = hj_inf();
+        auto pt = [&](const uint32_t *q) { return hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)); };
         for (int w = p.W - 1; w >= 0; w--) {
-          for (int k = 0; k < c; k++) r = hj_dbl(r);
-          const uint32_t *q = ws + ((size_t)b * p.W + w) * XYZZ_WORDS;
-          r = hj_add(r, hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)));
+          if (p.marg) {                               // window value = 2^a * W1 + W2: the c doublings are split around W1
+            const uint32_t *q = ws + ((size_t)b * p.W + w) * 2 * XYZZ_WORDS;
+            for (int k = 0; k < c - p.mg.a; k++) r = hj_dbl(r);
+            r = hj_add(r, pt(q));
+            for (int k = 0; k < p.mg.a; k++) r = hj_dbl(r);
+            r = hj_add(r, pt(q + XYZZ_WORDS));
+          } else {
+            for (int k = 0; k < c; k++) r = hj_dbl(r);
+            r = hj_add(r, pt(ws + ((size_t)b * p.W + w) * XYZZ_WORDS));
+          }
         }
         HAff a = hj_to_aff(r);
         a.x.store(out_xy + 8 * b); a.y.store(out_xy + 8 * b + 4);

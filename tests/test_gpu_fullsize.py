@@ -55,6 +55,19 @@ def test_msm_2_20_sharding_identity(gpu, big, oracle_lib):
     assert acc == full
 
 
+def test_msm_2_16_distinct_points_matches_oracle(gpu, big, oracle_lib):
+    """BASELINE config 2 proper: 2^16 DISTINCT points (the first 2^16 of the lifted set) with full-width scalars, bit-exact
+    against the oracle's 256-row Straus restatement (~5 s of CPU); through both entry points and a second window width."""
+    n = 1 << 16
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    sc, pts = np.ascontiguousarray(big["sc"][:n]), np.ascontiguousarray(big["pts"][:n])
+    assert len({bytes(r) for r in pts[:, :4]}) >= n - 1          # distinct x coordinates (one row is the infinity encoding)
+    want = oracle_lib.inner_product_raw(sc.ctypes.data_as(u64p), pts.ctypes.data_as(u64p), n)
+    assert gpu.msm_device(big["d_sc"], big["d_pts"], n, 0) == want
+    assert gpu.msm_device(big["d_sc"], big["d_pts"], n, 11) == want
+    assert gpu.msm(sc, pts) == want
+
+
 def test_msm_2_20_negation_and_prefix_oracle(gpu, big, oracle_lib):
     n = 1 << 14
     u64p = ctypes.POINTER(ctypes.c_uint64)
