@@ -28,6 +28,7 @@ SYMBOLS = [
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
+    "bppp_basis_create", "bppp_basis_create_device", "bppp_basis_destroy", "bppp_basis_info", "bppp_msm_basis",
     "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_prove_batch",
 ]
 
@@ -106,6 +107,12 @@ def load_library() -> C.CDLL:
     lib.bppp_device_free.argtypes = [vp, vp]
     lib.bppp_upload.argtypes = [vp, vp, vp, sz]
     lib.bppp_download.argtypes = [vp, vp, vp, sz]
+    lib.bppp_basis_create.argtypes = [vp, vp, sz, i, sz, C.POINTER(vp)]
+    lib.bppp_basis_create_device.argtypes = [vp, vp, sz, i, sz, C.POINTER(vp)]
+    lib.bppp_basis_destroy.argtypes = [vp]
+    lib.bppp_basis_destroy.restype = None
+    lib.bppp_basis_info.argtypes = [vp, C.POINTER(sz), C.POINTER(i), C.POINTER(sz)]
+    lib.bppp_msm_basis.argtypes = [vp, vp, sz, sz, vp]
     lib.bppp_rp_create.argtypes = [vp, i, i, vp, sz, vp, sz, vp, sz, C.c_char_p, C.POINTER(vp)]
     lib.bppp_rp_destroy.argtypes = [vp]
     lib.bppp_rp_destroy.restype = None
@@ -266,6 +273,10 @@ class Bppp:
                     "bppp_msm_batch_device")
         return [array_to_point(out[b]) for b in range(batch)]
 
+    def basis(self, points, window_bits: int = 0, batch_hint: int = 1, device: bool = False, n: int = 0) -> "Basis":
+        """register a basis: `points` is an (n, 8) uint64 array, or a device pointer with device=True and n given"""
+        return Basis(self, points, window_bits, batch_hint, device, n)
+
     def msm_glv_device(self, d_scalars: int, d_points: int, n: int):
         """the MSM through the reference's endomorphism decomposition (same group element as msm_device)"""
         out = np.zeros(8, dtype=np.uint64)
@@ -382,3 +393,38 @@ class Bppp:
         calls = C.c_uint64(0)
         self._check(self.lib.bppp_profile_read(self.h, ms, C.byref(calls), int(reset)), "bppp_profile_read")
         return {STAGE_NAMES[k]: ms[k] for k in range(NUM_STAGES)}, int(calls.value)
+
+
+class Basis:
+    """bppp_basis: points registered once with their fixed-base table; msm() runs over the first n_terms of them."""
+
+    def __init__(self, gpu: Bppp, points, window_bits: int = 0, batch_hint: int = 1, device: bool = False, n: int = 0):
+        self.gpu, self.h = gpu, None
+        h = C.c_void_p()
+        if device:
+            rc = gpu.lib.bppp_basis_create_device(gpu.h, _ptr(points), n, window_bits, batch_hint, C.byref(h))
+        else:
+            pts = np.ascontiguousarray(points)
+            rc = gpu.lib.bppp_basis_create(gpu.h, _ptr(pts), pts.shape[0], window_bits, batch_hint, C.byref(h))
+        gpu._check(rc, "bppp_basis_create")
+        self.h = h
+        gpu._adopt(self)
+        n_, c_, tb = C.c_size_t(0), C.c_int(0), C.c_size_t(0)
+        gpu._check(gpu.lib.bppp_basis_info(h, C.byref(n_), C.byref(c_), C.byref(tb)), "bppp_basis_info")
+        self.n, self.window_bits, self.table_bytes = int(n_.value), int(c_.value), int(tb.value)
+
+    def close(self):
+        if self.h:
+            self.gpu.lib.bppp_basis_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def msm(self, d_scalars: int, n_terms: int, batch: int = 1):
+        out = np.zeros((batch, 8), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.bppp_msm_basis(self.h, _ptr(d_scalars), n_terms, batch, _ptr(out)), "bppp_msm_basis")
+        return [array_to_point(out[b]) for b in range(batch)]

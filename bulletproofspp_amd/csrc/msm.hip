@@ -166,12 +166,14 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 
 __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long long *__restrict__ negmask, uint32_t n, uint32_t stride, int c,
                           int CH, int W, const uint32_t *__restrict__ blockhist, const uint32_t *__restrict__ start,
-                          uint32_t *__restrict__ sorted) {
+                          uint32_t *__restrict__ sorted, uint32_t flat_stride) {
   extern __shared__ uint32_t lh[];
   const int M = 1 << (c - 1);
   const uint32_t nbw = blockIdx.x, ch = blockIdx.y;
   const uint32_t *bh = blockhist + ((size_t)nbw * CH + ch) * M;
-  const uint32_t *st = start + (size_t)nbw * M;
+  // flat_stride != 0: the windows of an instance share one bucket set and the entry indexes the table row of its window
+  const uint32_t *st = start + (size_t)(flat_stride ? nbw / W : nbw) * M;
+  const uint32_t idx_base = flat_stride ? (nbw % W) * flat_stride : 0u;
   for (int t = threadIdx.x; t < M; t += blockDim.x) lh[t] = st[t] + bh[t];
   __syncthreads();
   uint32_t per = (((n + CH - 1) / CH) + 7u) & ~7u, lo = ch * per, hi = min(n, lo + per);
@@ -193,7 +195,7 @@ __global__ void k_scatter(const uint16_t *__restrict__ dig, const unsigned long 
         uint32_t sneg = (uint32_t)((mw >> (flat & 63)) & 1ull);
         uint32_t sg = (v < 0 ? 1u : 0u) ^ sneg;
         uint32_t pos = atomicAdd(&lh[mb], 1u);
-        sorted[pos] = (sg << 31) | (j0 + k);          // 4 bytes: the bucket is implied by start[] (position -> bucket), not stored
+        sorted[pos] = (sg << 31) | (idx_base + j0 + k);   // 4 bytes: the bucket is implied by start[] (position -> bucket), not stored
       }
     }
   }
@@ -434,23 +436,23 @@ __global__ void __launch_bounds__(64) k_reduce_marg(const uint32_t *__restrict__
   }
 }
 
-// one workgroup per window: wavefronts [0, wr) hold R (one element per lane), wavefronts [wr, wr + wc) hold C
-__global__ void __launch_bounds__(512) k_reduce_tail(const uint32_t *__restrict__ R, const uint32_t *__restrict__ C, MargGeom Gm, uint32_t *__restrict__ winsum2) {
-  __shared__ __attribute__((aligned(16))) uint32_t tot[8 * XYZZ_WORDS];
-  const uint32_t nbw = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t wr = (uint32_t)(Gm.HI + 63) / 64, wc = (uint32_t)(Gm.LO + 63) / 64;
-  const bool isC = wv >= wr;
-  const uint32_t gw = isC ? wv - wr : wv, gn = isC ? wc : wr, gbase = isC ? wr : 0u;     // wavefront within its group, group size, first wavefront
-  const uint32_t idx = gw * 64 + lane, n = isC ? (uint32_t)Gm.LO : (uint32_t)Gm.HI;
+// one workgroup per (window, R | C) — blockIdx.y = 0: R, 1: C — of at most four wavefronts, one per SIMD of its CU: a dependent
+// chain of point additions runs at one wavefront's instruction rate, and two chains on one SIMD would each run at half of it.
+// Both kinds are launched with 64 * ceil(LO / 64) threads; the spare wavefronts of an R workgroup hold infinity.
+__global__ void __launch_bounds__(256) k_reduce_tail(const uint32_t *__restrict__ R, const uint32_t *__restrict__ C, MargGeom Gm, uint32_t *__restrict__ winsum2) {
+  __shared__ __attribute__((aligned(16))) uint32_t tot[4 * XYZZ_WORDS];
+  const uint32_t nbw = blockIdx.x, lane = threadIdx.x & 63, gw = threadIdx.x >> 6, gn = blockDim.x >> 6;
+  const bool isC = blockIdx.y != 0;
+  const uint32_t n = isC ? (uint32_t)Gm.LO : (uint32_t)Gm.HI, idx = gw * 64 + lane;
   xyzz suf = xyzz_inf();
   if (idx < n) suf = xyzz_load((isC ? C + ((size_t)nbw * Gm.LO + idx) * XYZZ_WORDS : R + ((size_t)nbw * Gm.HI + idx) * XYZZ_WORDS));
   for (int d = 1; d < 64; d <<= 1) {             // inclusive suffix scan inside the wavefront
     xyzz o = xyzz_shfl_down(suf, d);
     if ((int)lane + d < 64) xyzz_add(suf, o);
   }
-  if (lane == 0) xyzz_store(tot + wv * XYZZ_WORDS, suf);
+  if (lane == 0) xyzz_store(tot + gw * XYZZ_WORDS, suf);
   __syncthreads();
-  for (uint32_t w = gw + 1; w < gn; w++) { xyzz t = xyzz_load(tot + (gbase + w) * XYZZ_WORDS); xyzz_add(suf, t); }     // later wavefronts of the group
+  for (uint32_t w = gw + 1; w < gn; w++) { xyzz t = xyzz_load(tot + w * XYZZ_WORDS); xyzz_add(suf, t); }     // later wavefronts of the group
   // R: sum_hi hi * R_hi = sum_{hi >= 1} suffix(hi);   C: sum_lo (lo + 1) * C_lo = sum_{lo >= 0} suffix(lo)
   xyzz v = (!isC && idx == 0) ? xyzz_inf() : suf;
   for (int d = 32; d >= 1; d >>= 1) {
@@ -458,10 +460,10 @@ __global__ void __launch_bounds__(512) k_reduce_tail(const uint32_t *__restrict_
     if ((int)lane + d < 64) xyzz_add(v, o);
   }
   __syncthreads();
-  if (lane == 0) xyzz_store(tot + wv * XYZZ_WORDS, v);
+  if (lane == 0) xyzz_store(tot + gw * XYZZ_WORDS, v);
   __syncthreads();
   if (lane == 0 && gw == 0) {
-    for (uint32_t w = 1; w < gn; w++) { xyzz t = xyzz_load(tot + (gbase + w) * XYZZ_WORDS); xyzz_add(v, t); }
+    for (uint32_t w = 1; w < gn; w++) { xyzz t = xyzz_load(tot + w * XYZZ_WORDS); xyzz_add(v, t); }
     xyzz_store(winsum2 + ((size_t)nbw * 2 + (isC ? 1 : 0)) * XYZZ_WORDS, v);
   }
 }
@@ -546,17 +548,20 @@ static int choose_window(size_t n, size_t batch) {
 
 struct MsmPlan {
   size_t n, batch; int c, W, M, CH, hist_threads, Lw, WPW;
-  uint64_t NB, FB, total_max;
+  bool flat;                   // precomputed table 2^(c w) P_i: all windows of an instance share ONE bucket set
+  int Wc;                      // windows left for the window combine (1 when flat)
+  uint64_t NB, NS, FB, total_max;   // digit rows (batch * W), bucket sets (batch * W, or batch when flat), buckets, sorted entries
   int L; uint64_t G;           // sorted entries per lane, number of lanes
   int RG;                      // k_reduce_groups lanes per window (0 = wave-per-window path)
   bool marg; MargGeom mg;      // marginal-sum reduction (M >= 256, not the grouped path)
   int ntiles;
 };
 
-static MsmPlan make_plan(size_t n, size_t batch, int c) {
+static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
   MsmPlan p;
   p.n = n; p.batch = batch; p.c = c; p.W = 256 / c + 1; p.M = 1 << (c - 1);
-  p.NB = (uint64_t)batch * p.W; p.FB = p.NB * p.M; p.total_max = p.NB * n;
+  p.flat = flat; p.Wc = flat ? 1 : p.W;
+  p.NB = (uint64_t)batch * p.W; p.NS = flat ? batch : p.NB; p.FB = p.NS * p.M; p.total_max = p.NB * n;
   p.hist_threads = p.M >= 8192 ? 1024 : 256;
   size_t per_block = (size_t)p.hist_threads * 64;
   p.CH = (int)std::max<size_t>(1, std::min<size_t>(64, (n + per_block - 1) / per_block));
@@ -572,8 +577,8 @@ static MsmPlan make_plan(size_t n, size_t batch, int c) {
     if (p.WPW < 1) p.WPW = 1;
   }
   p.RG = 0;
-  if (p.M <= 256 && p.NB >= 4096) p.RG = std::min(8, p.M);   // M is a power of two >= 2
-  p.marg = !p.RG && p.M >= 256 && p.NB <= 65535 && !getenv("BPPP_REDUCE_OLD");
+  if (p.M <= 256 && p.NS >= 4096) p.RG = std::min(8, p.M);   // M is a power of two >= 2
+  p.marg = !p.RG && p.M >= 256 && p.NS <= 65535 && !getenv("BPPP_REDUCE_OLD");
   memset(&p.mg, 0, sizeof p.mg);
   if (p.marg) {
     MargGeom &g = p.mg;
@@ -607,8 +612,16 @@ static RecodeK make_recode_k(int c, int W) {
   return K;
 }
 
+int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points, int window_bits, uint64_t *out_xy,
+               size_t table_stride);
 int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points,
             int window_bits, uint64_t *out_xy) {
+  return msm_run_ex(ctx, d_scalars, d_points, n, batch, shared_points, window_bits, out_xy, 0);
+}
+// table_stride != 0: d_points is a precomputed table [W][table_stride] of 2^(c w) P_i for the given window_bits = c (bppp_basis):
+// all windows of an instance share one bucket set, so there is one bucket reduction per instance and no window combine
+int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points, int window_bits, uint64_t *out_xy,
+               size_t table_stride) {
   using namespace bppp_host;
   if (!out_xy) return fail(ctx, BPPP_ERR_ARG, "msm: null output");
   if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
@@ -617,7 +630,10 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
   int c = window_bits ? window_bits : choose_window(n, batch);
   if (!window_bits) if (const char *e = getenv("BPPP_WINDOW_BATCHED")) { int v = atoi(e); if (batch > 4 && v >= 2 && v <= 16) c = v; }   // tuning sweeps
   if (c < 2 || c > 16) return fail(ctx, BPPP_ERR_ARG, "msm: window_bits must be in [2,16]");
-  MsmPlan p = make_plan(n, batch, c);
+  const bool flat = table_stride != 0;
+  if (flat && (!window_bits || shared_points != 1 || n > table_stride || (uint64_t)(256 / c + 1) * table_stride >= (1ull << 31)))
+    return fail(ctx, BPPP_ERR_ARG, "msm: bad precomputed-table arguments");
+  MsmPlan p = make_plan(n, batch, c, flat);
   if (p.FB >= (1ull << 32) - 1 || p.total_max >= (1ull << 32) - 1)
     return fail(ctx, BPPP_ERR_ARG, "msm: batch*windows*buckets or batch*n*windows exceeds 2^32; split the batch");
 
@@ -641,8 +657,8 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     uint4 *heavy_buckets = cv.take<uint4>(hmax);
     uint32_t *chunk_sums = cv.take<uint32_t>(hmax * XYZZ_WORDS);
     uint32_t *heavy_count = cv.take<uint32_t>(4);
-    uint32_t *red = cv.take<uint32_t>(p.marg ? (size_t)p.NB * (p.mg.HI + p.mg.LO) * XYZZ_WORDS : (size_t)p.NB * p.WPW * 2 * XYZZ_WORDS);
-    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NB * 2 * XYZZ_WORDS);
+    uint32_t *red = cv.take<uint32_t>(p.marg ? (size_t)p.NS * (p.mg.HI + p.mg.LO) * XYZZ_WORDS : (size_t)p.NS * p.WPW * 2 * XYZZ_WORDS);
+    uint32_t *winsum = cv.take<uint32_t>((size_t)p.NS * 2 * XYZZ_WORDS);
     uint32_t *out_aff = cv.take<uint32_t>((size_t)batch * 16);
     if (!pass) { need = cv.off; int rc = ensure_workspace(ctx, need); if (rc) return rc; continue; }
 
@@ -660,18 +676,20 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     prof_mark(ctx, 1);
     // 2. sort
     k_hist<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, (uint32_t)n, stride, c, p.CH, blockhist);
-    k_chunk_prefix<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(blockhist, p.M, p.CH, p.FB, count);
+    // flat: the (window, chunk) histograms of an instance are W * CH chunks of ONE bucket set (same memory layout)
+    k_chunk_prefix<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(blockhist, p.M, p.flat ? p.W * p.CH : p.CH, p.FB, count);
     k_scan_tile_sums<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles);
     k_scan_top<<<dim3(1), dim3(1024), 0, st>>>(tiles, (uint32_t)p.ntiles, start + p.FB);
     k_scan_apply<<<dim3(p.ntiles), dim3(256), 0, st>>>(count, p.FB, tiles, start);
-    k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, stride, c, p.CH, p.W, blockhist, start, sorted);
+    k_scatter<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, negmask, (uint32_t)n, stride, c, p.CH, p.W, blockhist, start, sorted,
+                                                                             p.flat ? (uint32_t)table_stride : 0u);
     BPPP_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)p.FB * XYZZ_WORDS * 4, st));
     BPPP_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     prof_mark(ctx, 2);
     if (ctx->pre_acc) { auto f = ctx->pre_acc; ctx->pre_acc = nullptr; int rc_ = f(ctx->pre_acc_arg); if (rc_) return rc_; }
     // 3. accumulate
     k_acc_points<<<dim3((unsigned)((p.G + 255) / 256)), dim3(256), 0, st>>>(sorted, start, (uint32_t)p.FB, (const uint32_t *)d_points, (uint32_t)n,
-                                                                           (uint32_t)(p.W * p.M), shared_points, p.L, p.G, buckets, rec_pt);
+                                                                           (uint32_t)(p.Wc * p.M), shared_points, p.L, p.G, buckets, rec_pt);
     prof_mark(ctx, 3);
     k_merge<<<dim3((unsigned)((p.FB + 255) / 256)), dim3(256), 0, st>>>(start, count, p.FB, p.L, rec_pt, buckets, heavy_items, heavy_buckets, heavy_count);
     k_merge_heavy<<<dim3(2048), dim3(64), 0, st>>>(start, count, p.L, rec_pt, buckets, heavy_items, heavy_count, chunk_sums);
@@ -679,25 +697,24 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
     prof_mark(ctx, 4);
     // 4. bucket reduce
     if (p.RG) {
-      k_reduce_groups<<<dim3((unsigned)((p.NB * p.RG + 63) / 64)), dim3(64), 0, st>>>(buckets, p.M, p.RG, (uint32_t)p.NB, winsum);
+      k_reduce_groups<<<dim3((unsigned)((p.NS * p.RG + 63) / 64)), dim3(64), 0, st>>>(buckets, p.M, p.RG, (uint32_t)p.NS, winsum);
     } else if (p.marg) {
-      uint32_t *Rm = red, *Cm = red + (size_t)p.NB * p.mg.HI * XYZZ_WORDS;
-      k_reduce_marg<<<dim3(p.mg.row_tiles + p.mg.col_tiles, (unsigned)p.NB), dim3(64), 0, st>>>(buckets, p.M, p.mg, Rm, Cm);
-      const unsigned tail_threads = 64u * (unsigned)((p.mg.HI + 63) / 64 + (p.mg.LO + 63) / 64);
-      k_reduce_tail<<<dim3((unsigned)p.NB), dim3(tail_threads), 0, st>>>(Rm, Cm, p.mg, winsum);
+      uint32_t *Rm = red, *Cm = red + (size_t)p.NS * p.mg.HI * XYZZ_WORDS;
+      k_reduce_marg<<<dim3(p.mg.row_tiles + p.mg.col_tiles, (unsigned)p.NS), dim3(64), 0, st>>>(buckets, p.M, p.mg, Rm, Cm);
+      k_reduce_tail<<<dim3((unsigned)p.NS, 2), dim3(64u * (unsigned)((p.mg.LO + 63) / 64)), 0, st>>>(Rm, Cm, p.mg, winsum);
     } else {
-      k_reduce1<<<dim3((unsigned)p.NB, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
-      k_reduce2<<<dim3((unsigned)p.NB), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
+      k_reduce1<<<dim3((unsigned)p.NS, p.WPW), dim3(64), 0, st>>>(buckets, p.M, p.Lw, p.WPW, red);
+      k_reduce2<<<dim3((unsigned)p.NS), dim3(64), 0, st>>>(red, p.Lw, p.WPW, winsum);
     }
     prof_mark(ctx, 5);
     // 5. window combine
     if (batch > 4) {
-      k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.W, c, p.marg ? p.mg.a : 0, (uint32_t)batch, out_aff);
+      k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.Wc, c, p.marg ? p.mg.a : 0, (uint32_t)batch, out_aff);
       BPPP_HIP(ctx, hipMemcpyAsync(out_xy, out_aff, batch * 64, hipMemcpyDeviceToHost, st));
       prof_mark(ctx, 6);
       BPPP_HIP(ctx, hipStreamSynchronize(st));
     } else {
-      size_t bytes = (size_t)p.NB * (p.marg ? 2 : 1) * XYZZ_WORDS * 4;
+      size_t bytes = (size_t)p.NS * (p.marg ? 2 : 1) * XYZZ_WORDS * 4;
       int rc = ensure_pinned(ctx, bytes); if (rc) return rc;
       BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
       prof_mark(ctx, 6);
@@ -706,16 +723,16 @@ int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n
       for (size_t b = 0; b < batch; b++) {
         HJac r = hj_inf();
         auto pt = [&](const uint32_t *q) { return hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)); };
-        for (int w = p.W - 1; w >= 0; w--) {
+        for (int w = p.Wc - 1; w >= 0; w--) {
           if (p.marg) {                               // window value = 2^a * W1 + W2: the c doublings are split around W1
-            const uint32_t *q = ws + ((size_t)b * p.W + w) * 2 * XYZZ_WORDS;
+            const uint32_t *q = ws + ((size_t)b * p.Wc + w) * 2 * XYZZ_WORDS;
             for (int k = 0; k < c - p.mg.a; k++) r = hj_dbl(r);
             r = hj_add(r, pt(q));
             for (int k = 0; k < p.mg.a; k++) r = hj_dbl(r);
             r = hj_add(r, pt(q + XYZZ_WORDS));
           } else {
             for (int k = 0; k < c; k++) r = hj_dbl(r);
-            r = hj_add(r, pt(ws + ((size_t)b * p.W + w) * XYZZ_WORDS));
+            r = hj_add(r, pt(ws + ((size_t)b * p.Wc + w) * XYZZ_WORDS));
           }
         }
         HAff a = hj_to_aff(r);

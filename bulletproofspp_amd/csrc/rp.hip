@@ -334,6 +334,8 @@ int rp_build_plan(bppp_rp *rp) {
 
 }  // namespace
 
+extern "C" void bppp_basis_destroy(bppp_basis *basis);
+
 extern "C" {
 
 void bppp_rp_destroy(bppp_rp *rp) {
@@ -347,6 +349,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->work) hipFree(rp->work);
   if (rp->stage) hipFree(rp->stage);
   if (rp->d_fixed) hipFree(rp->d_fixed);
+  if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
   delete rp;
   ctx_release(ctx);

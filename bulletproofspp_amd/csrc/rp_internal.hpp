@@ -10,6 +10,7 @@
 
 struct bppp_trrp;
 struct bppp_nlb;
+struct bppp_basis;
 
 namespace bppp {
 
@@ -65,6 +66,7 @@ struct bppp_rp {
   bppp::RpDims D{};
   // prover side (csrc/rpprove.hip): fixed-base window table of g, H[0], H[1] for the input commitments, prover workspace
   uint32_t *d_fixed = nullptr;
+  bppp_basis *commit_basis = nullptr;           // [g | H | G] registered with its fixed-base table: the range-proof commitments
   void *pwork = nullptr; size_t pwork_bytes = 0;
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
   void *work = nullptr; size_t work_bytes = 0;

@@ -60,6 +60,8 @@ void bppp_nlb_destroy(bppp_nlb *nlb);
 int bppp_nlb_round_commit(bppp_nlb *nlb, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy);
 int bppp_nlb_round_collapse(bppp_nlb *nlb, const uint64_t *es);
 int bppp_nlb_get_witness(bppp_nlb *nlb, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s);
+int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, int window_bits, size_t batch_hint, bppp_basis **out);
+int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, size_t batch, uint64_t *out_xy);
 }
 
 namespace {
@@ -475,6 +477,8 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
   if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");
   { int rc = build_fixed_table(rp); if (rc) return rc; }
+  // the basis of commitRPW is fixed per setup: registered once with its fixed-base table (one bucket set for all windows)
+  if (!rp->commit_basis) { int rc = bppp_basis_create_device(ctx, rp->d_basis, T, 0, 4096, &rp->commit_basis); if (rc) return rc; }
   // device workspace: [input scalars B nr 3 | input commitments B nr | commitment rows 2B T]
   const size_t in_sc = B * nr * 3 * 32, in_pt = B * nr * 64, rows = 2 * B * T * 32;
   { int rc = ensure_pwork(rp, in_sc + in_pt + rows + 1024); if (rc) return rc; }
@@ -492,7 +496,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   };
   auto commit_rows = [&](size_t nrows) -> int {            // one batched MSM over the registered basis: h_com[row] = commit(row)
     BPPP_HIP(ctx, hipMemcpyAsync(d_rows, h_rows.data(), nrows * T * 32, hipMemcpyHostToDevice, stream));
-    return msm_run(ctx, d_rows, rp->d_basis, T, nrows, 1, 0, h_com.data());
+    return bppp_msm_basis(rp->commit_basis, d_rows, T, nrows, h_com.data());
   };
 
   // ---- phase 1: witness, dmWit / mWit (TypedReciprocal.hs:402-410)

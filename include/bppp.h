@@ -21,7 +21,7 @@
  *
  * Every function returns BPPP_OK (0) or a negative BPPP_ERR_* code; bppp_last_error() gives text.
  *
- * Handle lifetime: every child handle (bppp_nl, bppp_nlb, bppp_ip, bppp_trrp, bppp_rp) holds a reference on its context.
+ * Handle lifetime: every child handle (bppp_nl, bppp_nlb, bppp_ip, bppp_trrp, bppp_rp, bppp_basis) holds a reference on its context.
  * bppp_ctx_destroy closes the context (further calls through it or its children fail with BPPP_ERR_ARG) and drops the caller's
  * reference; the stream and workspaces are released when the last child is destroyed, so finalisers may run in any order.
  *
@@ -76,6 +76,21 @@ int bppp_msm_batch_device(bppp_ctx *ctx, const void *d_scalars, const void *d_po
 /* Sum of n affine points (complete group law): the local tail of a sharded MSM after the ranks all-gathered their partial points
  * (SURVEY.md 8e).  Host arithmetic, microseconds for the 2..64 points it is meant for. */
 int bppp_sum_points(bppp_ctx *ctx, const uint64_t *points_xy, size_t n, uint64_t out_xy[8]);
+
+/* ---- registered basis with fixed-base precomputation (SURVEY.md 8(b) "Ownership": basis points "may be registered once and
+ * referenced by handle since G, H are fixed per setup", src/RangeProof/TypedReciprocal.hs:348-359) ---------------------------
+ * The handle owns a copy of the n points in HBM plus the table T[w][i] = 2^(c w) P_i (W = 256 / c + 1 rows of n affine points,
+ * W * n * 64 bytes; built on the device at creation).  bppp_msm_basis is `innerProduct` (src/Commitment.hs:325-335) over the first
+ * n_terms registered points — `batch` instances, d_scalars [batch][n_terms] in HBM, out_xy [batch][8] on the host — with all
+ * windows sharing ONE bucket set: one bucket reduction per instance instead of W, no window combine.  Results equal
+ * bppp_msm_batch_device over the same points bit for bit.  window_bits = 0 lets the library choose for `batch_hint` instances
+ * of n terms.  The arbitrary-point entry points above stay the general route (and the headline of bench.py). */
+typedef struct bppp_basis bppp_basis;
+int bppp_basis_create(bppp_ctx *ctx, const uint64_t *points_xy, size_t n, int window_bits, size_t batch_hint, bppp_basis **out);
+int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, int window_bits, size_t batch_hint, bppp_basis **out);
+void bppp_basis_destroy(bppp_basis *basis);
+int bppp_basis_info(const bppp_basis *basis, size_t *n, int *window_bits, size_t *table_bytes);
+int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, size_t batch, uint64_t *out_xy);
 
 /* ---- a7: SplitScalar.rationalReduceScalar (host) ------------------------------------------
  * Replaces rationalReduceScalar for `Prime p` (src/Commitment.hs:242-255, instance :269-288):

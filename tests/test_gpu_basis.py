@@ -1,0 +1,90 @@
+"""Registered basis with fixed-base precomputation (bppp_basis_*): the same group elements as the arbitrary-point MSM and as the
+oracle's Straus restatement, for every window width, prefixes of the basis, batches, zero scalars and infinity points."""
+import random
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from bulletproofspp_amd.capi import points_to_array, scalars_to_array
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(n, seed):
+    rnd = random.Random(seed)
+    pts = O.hash_points(b"basis%d" % seed, n)
+    if n > 5:
+        pts[3] = None
+    return pts, rnd
+
+
+@pytest.mark.parametrize("c", [0, 2, 4, 7, 9, 10, 13, 16])
+def test_basis_msm_equals_oracle_and_plain_msm(gpu, oracle_lib, c):
+    n = 200
+    pts, rnd = _case(n, 11)
+    bas = gpu.basis(points_to_array(pts), window_bits=c)
+    assert bas.n == n and (c == 0 or bas.window_bits == c) and bas.table_bytes == (256 // bas.window_bits + 1) * n * 64
+    for n_terms, batch in ((n, 1), (n, 6), (57, 3), (1, 2)):
+        sc = [[rnd.randrange(O.N) for _ in range(n_terms)] for _ in range(batch)]
+        sc[0][0] = 0
+        if n_terms > 2:
+            sc[-1][2] = O.N - 1
+            sc[-1][1] = (O.N + 1) // 2
+        d_s = gpu.to_device(np.concatenate([scalars_to_array(r) for r in sc]))
+        d_p = gpu.to_device(points_to_array(pts[:n_terms]))
+        try:
+            got = bas.msm(d_s, n_terms, batch)
+            plain = gpu.msm_batch_device(d_s, d_p, n_terms, batch, shared_points=True)
+        finally:
+            gpu.free(d_s); gpu.free(d_p)
+        assert got == plain
+        for b in range(batch):
+            assert got[b] == oracle_lib.inner_product(list(zip(sc[b], pts[:n_terms])))
+    bas.close()
+
+
+def test_basis_many_small_instances(gpu, oracle_lib):
+    """the prover's shape: thousands of instances over one short basis (grouped bucket reduction, one bucket set per instance)"""
+    n, batch = 97, 4500
+    pts, rnd = _case(n, 12)
+    rng = np.random.default_rng(3)
+    sc = rng.integers(0, 2**64, size=(batch * n, 4), dtype=np.uint64)
+    sc[:, 3] >>= np.uint64(1)
+    sc[5] = 0
+    d_s = gpu.to_device(sc)
+    d_p = gpu.to_device(points_to_array(pts))
+    bas = gpu.basis(points_to_array(pts), batch_hint=batch)
+    try:
+        got = bas.msm(d_s, n, batch)
+        plain = gpu.msm_batch_device(d_s, d_p, n, batch, shared_points=True)
+    finally:
+        gpu.free(d_s); gpu.free(d_p)
+    assert got == plain
+    from bulletproofspp_amd.capi import array_to_scalars
+    for b in (0, 1, 2222, batch - 1):
+        assert got[b] == oracle_lib.inner_product(list(zip(array_to_scalars(sc[b * n:(b + 1) * n]), pts)))
+    bas.close()
+
+
+def test_basis_2_14_and_lifetime(gpu, oracle_lib):
+    import ctypes
+    n = 1 << 14
+    rng = np.random.default_rng(14)
+    xs = rng.integers(0, 2**64, size=(3 * n, 4), dtype=np.uint64)
+    dx, dp = gpu.to_device(xs), gpu.alloc(3 * n * 64)
+    gpu.lift_x(dx, 3 * n, dp)
+    pts = gpu.download(dp, (3 * n, 8))
+    gpu.free(dx); gpu.free(dp)
+    pts = np.ascontiguousarray(pts[(pts != 0).any(axis=1)][:n])
+    sc = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] = np.minimum(sc[:, 3], np.uint64(0xFFFFFFFFFFFFFFFD))
+    d_pts = gpu.to_device(pts)
+    bas = gpu.basis(d_pts, device=True, n=n)
+    gpu.free(d_pts)                                   # the handle keeps its own table
+    d_s = gpu.to_device(sc)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    want = oracle_lib.inner_product_raw(sc.ctypes.data_as(u64p), pts.ctypes.data_as(u64p), n)
+    assert bas.msm(d_s, n, 1) == [want]
+    gpu.free(d_s)
+    bas.close()
