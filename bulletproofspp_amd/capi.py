@@ -16,7 +16,7 @@ STAGE_NAMES = ["digits", "sort", "acc_points", "acc_records", "reduce", "finish"
 SYMBOLS = [
     "bppp_ctx_create", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_last_error", "bppp_version",
     "bppp_msm", "bppp_msm_device", "bppp_msm_batch_device", "bppp_sum_points", "bppp_rational_reduce",
-    "bppp_fold_points", "bppp_fold_points_device",
+    "bppp_fold_points", "bppp_fold_points_device", "bppp_rational_reduce_eis", "bppp_fold_points_eis_device",
     "bppp_norm_round_sums_device", "bppp_lin_round_sums_device",
     "bppp_norm_round_openings_device", "bppp_lin_round_openings_device",
     "bppp_fold_scalars_device", "bppp_tensor_device", "bppp_batch_inverse_device",
@@ -62,6 +62,8 @@ def load_library() -> C.CDLL:
     lib.bppp_glv_decompose_device.argtypes = [vp, vp, sz, vp, vp, vp]
     lib.bppp_msm_glv_device.argtypes = [vp, vp, vp, sz, vp]
     lib.bppp_rational_reduce.argtypes = [vp, vp, C.POINTER(i), vp, C.POINTER(i)]
+    lib.bppp_rational_reduce_eis.argtypes = [vp, vp, vp, vp, vp]
+    lib.bppp_fold_points_eis_device.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
     lib.bppp_fold_points.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
     lib.bppp_fold_points_device.argtypes = [vp, vp, i, vp, i, vp, sz, vp]
     lib.bppp_norm_round_sums_device.argtypes = [vp, vp, sz, vp, vp, vp]
@@ -314,6 +316,31 @@ class Bppp:
             raise BpppError(f"bppp_rational_reduce failed ({rc})")
         a, b = limbs_to_int(am), limbs_to_int(bm)
         return (-a if an.value else a, -b if bn.value else b)
+
+    def rational_reduce_eis(self, x: int):
+        """((a0, a1), (b0, b1)): the Eisenstein rational reduction x = (a0 + a1 w) / (b0 + b1 w) of the FastPrime configuration"""
+        am, bm = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        an, bn = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)
+        rc = self.lib.bppp_rational_reduce_eis(_ptr(int_to_limbs(x)), _ptr(am), C.c_void_p(an.ctypes.data), _ptr(bm), C.c_void_p(bn.ctypes.data))
+        if rc != 0:
+            raise BpppError(f"bppp_rational_reduce_eis failed ({rc})")
+        comp = lambda m, s, k: (-1 if s[k] else 1) * (int(m[2 * k]) | (int(m[2 * k + 1]) << 64))
+        return (comp(am, an, 0), comp(am, an, 1)), (comp(bm, bn, 0), comp(bm, bn, 1))
+
+    def fold_points_eis(self, b, a, points: np.ndarray) -> np.ndarray:
+        """out[j] = b * pts[2j] + a * pts[2j+1] for Eisenstein reduced scalars b = (b0, b1), a = (a0, a1)"""
+        n = points.shape[0]
+        mags = lambda e: np.array([abs(e[0]) & (2**64 - 1), abs(e[0]) >> 64, abs(e[1]) & (2**64 - 1), abs(e[1]) >> 64], dtype=np.uint64)
+        negs = lambda e: np.array([int(e[0] < 0), int(e[1] < 0)], dtype=np.int32)
+        d_p = self.to_device(np.ascontiguousarray(points))
+        d_o = self.alloc(((n + 1) // 2) * 64)
+        bn, an = negs(b), negs(a)
+        try:
+            self._check(self.lib.bppp_fold_points_eis_device(self.h, _ptr(mags(b)), C.c_void_p(bn.ctypes.data), _ptr(mags(a)), C.c_void_p(an.ctypes.data), _ptr(d_p), n,
+                                                             _ptr(d_o)), "bppp_fold_points_eis_device")
+            return self.download(d_o, ((n + 1) // 2, 8))
+        finally:
+            self.free(d_p); self.free(d_o)
 
     def fold_points(self, b: int, a: int, points: np.ndarray) -> np.ndarray:
         n = points.shape[0]

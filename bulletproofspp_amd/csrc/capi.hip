@@ -4,6 +4,7 @@
 #include <string.h>
 #include "ctx.hpp"
 #include "hostmath.hpp"
+#include "hosteis.hpp"
 
 namespace bppp {
 int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
@@ -15,6 +16,7 @@ int fold_scalars_run(bppp_ctx *, const uint64_t *, const uint64_t *, const void 
 int tensor_run(bppp_ctx *, const uint64_t *, size_t, const uint64_t *, const uint64_t *, size_t, void *);
 int lift_x_run(bppp_ctx *, const void *, size_t, void *);
 int batch_inverse_run(bppp_ctx *, const void *, size_t, int, void *);
+int fold_points_eis_run(bppp_ctx *, const uint64_t *, const int *, const uint64_t *, const int *, const void *, size_t, void *);
 
 void ctx_retain(bppp_ctx *ctx) { ctx->refs.fetch_add(1); }
 void ctx_release(bppp_ctx *ctx) {
@@ -181,6 +183,30 @@ int bppp_rational_reduce(const uint64_t x[4], uint64_t a_mag[3], int *a_neg, uin
   auto ab = bppp_host::rational_reduce_scalar(v);
   memcpy(a_mag, ab.first.m, 24); *a_neg = ab.first.neg;
   memcpy(b_mag, ab.second.m, 24); *b_neg = ab.second.neg;
+  return BPPP_OK;
+}
+
+// rationalReduceScalar of the FastPrime / Eisenstein configuration (Commitment.hs:242-255 over :293-306; Eis.hs:72-82)
+int bppp_rational_reduce_eis(const uint64_t x[4], uint64_t a_mag[4], int a_neg[2], uint64_t b_mag[4], int b_neg[2]) {
+  if (!x || !a_mag || !a_neg || !b_mag || !b_neg) return BPPP_ERR_ARG;
+  bppp_host::U256 v = bppp_host::U256::load(x);
+  if (bppp_host::cmp(v, bppp_host::FR().m) >= 0) return BPPP_ERR_ARG;
+  auto ab = bppp_eis::rational_reduce_eis(v);
+  const bppp_eis::Big *comp[4] = {&ab.first.a, &ab.first.b, &ab.second.a, &ab.second.b};
+  for (int k = 0; k < 4; k++) {
+    for (int i = 2; i < bppp_eis::Big::L; i++) if (comp[k]->m[i]) return BPPP_ERR_ARG;      // cannot happen: components are ~65 bits
+    uint64_t *dst = (k < 2 ? a_mag : b_mag) + 2 * (k & 1);
+    dst[0] = comp[k]->m[0]; dst[1] = comp[k]->m[1];
+    (k < 2 ? a_neg : b_neg)[k & 1] = comp[k]->neg ? 1 : 0;
+  }
+  return BPPP_OK;
+}
+int bppp_fold_points_eis_device(bppp_ctx *ctx, const uint64_t b_mag[4], const int b_neg[2], const uint64_t a_mag[4], const int a_neg[2], const void *d_points_xy,
+                                size_t n, void *d_out_xy) {
+  CTX_ENTER(ctx);
+  int rc = fold_points_eis_run(ctx, b_mag, b_neg, a_mag, a_neg, d_points_xy, n, d_out_xy);
+  if (rc) return rc;
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BPPP_OK;
 }
 

@@ -51,6 +51,49 @@ __global__ void __launch_bounds__(64) k_fold_points_multi(FoldSegs S_) {
   if (active) aff_store(sg->out + (size_t)j * 16, r);
 }
 
+// The same fold for the reference's Eisenstein configuration (SplitScalar (FastPrime p), src/Commitment.hs:293-306; FastInnerProduct
+// of the FastPrime instance, :374-398; rationalReducedScalarLength = 65): the reduced scalars are Eisenstein integers
+// b' = b0 + b1 w, a' = a0 + a1 w with ~65-bit components and w acts on a point as the endomorphism lambda (x, y) = (beta x, y)
+// (cmConj, src/Data/Curve/CM.hs:25-27):   out = b0 GL + b1 lambda GL + a0 GR + a1 lambda GR.
+// Each half is a two-scalar joint-sparse-form walk over (P, lambda P) — 66 rows instead of 130, but two of them and one more
+// addition: the same work as the integer fold (measured: no faster), so this is the PARITY option for that configuration.
+struct FoldEisK { uint32_t digb[FOLD_DIGIT_WORDS], diga[FOLD_DIGIT_WORDS]; int b0neg, b1neg, a0neg, a1neg; };
+BPPP_DI aff aff_lambda(const aff &p) {             // (beta x, y); infinity stays infinity
+  const fe beta = {{0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu}};
+  aff r; r.x = fq_normalize(fq_mul(p.x, fq_from_fe(beta))); r.y = p.y;
+  return r;
+}
+__global__ void __launch_bounds__(64) k_fold_points_eis(const uint32_t *__restrict__ pts, uint32_t n, FoldEisK K, uint32_t *__restrict__ out) {
+  __shared__ uint32_t tab[FOLD_TAB_WORDS];
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, np = (n + 1) / 2;
+  aff GL = aff_inf(), GR = aff_inf();
+  if (j < np) {
+    GL = aff_load(pts + (size_t)(2 * j) * 16);
+    if (2 * j + 1 < n) GR = aff_load(pts + (size_t)(2 * j + 1) * 16);
+  }
+  const aff A = fold_pair_jsf(aff_cneg(GL, K.b0neg != 0), aff_cneg(aff_lambda(GL), K.b1neg != 0), K.digb, tab, threadIdx.x);
+  const aff B = fold_pair_jsf(aff_cneg(GR, K.a0neg != 0), aff_cneg(aff_lambda(GR), K.a1neg != 0), K.diga, tab, threadIdx.x);
+  xyzz acc = xyzz_from_aff(A);
+  xyzz_madd(acc, B);
+  if (j < np) aff_store(out + (size_t)j * 16, xyzz_to_aff(acc));
+}
+int fold_points_eis_run(bppp_ctx *ctx, const uint64_t b_mag[4], const int b_neg[2], const uint64_t a_mag[4], const int a_neg[2], const void *d_pts, size_t n,
+                        void *d_out) {
+  if (n == 0) return BPPP_OK;
+  if (!d_pts || !d_out || !b_mag || !a_mag || !b_neg || !a_neg || n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "fold_points_eis: bad arguments");
+  FoldEisK K; memset(&K, 0, sizeof K);
+  for (int k = 0; k < 2; k++)
+    if ((b_mag[2 * k + 1] >> 2) || (a_mag[2 * k + 1] >> 2)) return fail(ctx, BPPP_ERR_ARG, "fold_points_eis: component exceeds 66 bits");
+  const uint64_t b0[3] = {b_mag[0], b_mag[1], 0}, b1[3] = {b_mag[2], b_mag[3], 0}, a0[3] = {a_mag[0], a_mag[1], 0}, a1[3] = {a_mag[2], a_mag[3], 0};
+  bppp_host::jsf_recode(b0, b1, K.digb);
+  bppp_host::jsf_recode(a0, a1, K.diga);
+  K.b0neg = b_neg[0]; K.b1neg = b_neg[1]; K.a0neg = a_neg[0]; K.a1neg = a_neg[1];
+  const uint32_t np = (uint32_t)((n + 1) / 2);
+  k_fold_points_eis<<<dim3((np + 63) / 64), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_pts, (uint32_t)n, K, (uint32_t *)d_out);
+  BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
+
 // pointX (app/Main.hs:68-72): y = sqrt(x^3 + 7) = (x^3+7)^((p+1)/4) since p = 3 mod 4; even root.
 __global__ void __launch_bounds__(64) k_lift_x(const uint32_t *__restrict__ xs, uint32_t n, uint32_t *__restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

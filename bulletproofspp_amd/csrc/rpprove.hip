@@ -16,6 +16,9 @@
 #include <string.h>
 #include <array>
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -73,7 +76,7 @@ using bppp_rps::Setup;
 inline const Mod &MR() { return FR(); }
 inline U256 fa(const U256 &a, const U256 &b) { return madd(a, b, MR()); }
 inline U256 fs(const U256 &a, const U256 &b) { return msub(a, b, MR()); }
-inline U256 fm(const U256 &a, const U256 &b) { return mmul(a, b, MR()); }
+inline U256 fm(const U256 &a, const U256 &b) { return frmul(a, b); }
 inline U256 fneg(const U256 &a) { return mneg(a, MR()); }
 inline U256 fdbl(const U256 &a) { return madd(a, a, MR()); }
 inline U256 fpow(U256 b, uint64_t e) { U256 r = U256::one(); while (e) { if (e & 1) r = fm(r, b); b = fm(b, b); e >>= 1; } return r; }
@@ -239,7 +242,28 @@ RPW blind_err_witness(const U256 &err7, const std::vector<U256> &ns, Rnd &rnd, s
   return w;
 }
 
-void batch_inv(std::vector<U256> &v) { if (!v.empty()) batch_minv(v.data(), v.size(), MR()); }
+// a^(n-2) with the dedicated multiply; 0 -> 0
+U256 finv(const U256 &a) {
+  U256 e; sub_raw(e, MR().m, U256::from_u64(2));
+  U256 acc = U256::one(), base = a;
+  for (int i = 0; i < 256; i++) { if (e.bit(i)) acc = fm(acc, base); base = fm(base, base); }
+  return acc;
+}
+// batchInverse (src/Data/Field/BatchInverse.hs:18-39): Montgomery's trick, 0 -> 0
+void batch_inv(std::vector<U256> &v) {
+  const size_t n = v.size();
+  if (!n) return;
+  std::vector<U256> pre(n);
+  U256 acc = U256::one();
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!v[i].is_zero()) acc = fm(acc, v[i]); }
+  U256 y = finv(acc);
+  for (size_t i = n; i-- > 0;) {
+    if (v[i].is_zero()) continue;
+    const U256 inv = fm(y, pre[i]);
+    y = fm(y, v[i]);
+    v[i] = inv;
+  }
+}
 
 // makeBaseMap: sortedBases zipped with x^3, x^5, ... (TypedReciprocal.hs:349)
 std::vector<U256> base_map(const Setup &st, const U256 &x) {
@@ -485,6 +509,11 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   uint32_t *d_in_sc = (uint32_t *)rp->pwork, *d_in_pt = (uint32_t *)((char *)rp->pwork + ((in_sc + 255) & ~(size_t)255)),
            *d_rows = (uint32_t *)((char *)d_in_pt + ((in_pt + 255) & ~(size_t)255));
 
+  // BPPP_RP_TIMING=1: wall time of each phase on stderr (tuning aid)
+  const bool timing = getenv("BPPP_RP_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = now();
+  auto lap = [&](const char *what) { if (timing) { double t = now(); fprintf(stderr, "[rp_prove] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
   std::vector<PState> ps(B);
   std::vector<uint64_t> h_in_sc(B * nr * 12), h_in_pt(B * nr * 8), h_rows(2 * B * T * 4), h_com(2 * B * 8);
   std::atomic<int> failed{-1};
@@ -512,6 +541,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
     }
   });
   if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((int)failed) + ": " + ps[failed].err);
+  lap("phase 1 host");
   BPPP_HIP(ctx, hipMemcpyAsync(d_in_sc, h_in_sc.data(), in_sc, hipMemcpyHostToDevice, stream));
   {
     const uint64_t n = (uint64_t)B * nr;
@@ -520,6 +550,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
     BPPP_HIP(ctx, hipMemcpyAsync(h_in_pt.data(), d_in_pt, in_pt, hipMemcpyDeviceToHost, stream));
   }
   { int rc = commit_rows(2 * B); if (rc) return rc; }       // synchronises the stream
+  lap("inputs + dm/m commits (GPU)");
   std::vector<uint64_t> c_dm(B * 8), c_m(B * 8), c_r(B * 8), c_bl(B * 8);
   for (size_t b = 0; b < B; b++) { memcpy(&c_dm[8 * b], &h_com[16 * b], 64); memcpy(&c_m[8 * b], &h_com[16 * b + 8], 64); }
 
@@ -533,7 +564,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
       U256 ch[3];
       oracle(rp->tag, p, pts.data(), pts.size(), 3, ch);
       p.e = ch[0]; p.x = ch[1]; p.r0 = ch[2];
-      p.e_inv = minv(p.e, MR()); p.r0_inv = minv(p.r0, MR());
+      p.e_inv = finv(p.e); p.r0_inv = finv(p.r0);
       make_phase2(st, p);
       U256 s = U256::zero();
       for (size_t i = 0; i < nlen; i++) s = fa(s, fdbl(fm(p.rr[i], p.cc[i])));
@@ -542,8 +573,10 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
       put_row(b, p.r);
     }
   });
+  lap("phase 2 host");
   { int rc = commit_rows(B); if (rc) return rc; }
   memcpy(c_r.data(), h_com.data(), B * 64);
+  lap("r commit (GPU)");
 
   // ---- phase 3: (q, x', r1), error terms, the blinding commitment (:421-437)
   rp_parallel(B, [&](size_t lo, size_t hi) {
@@ -554,7 +587,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
       oracle(rp->tag, p, &pt, 1, 3, ch);
       p.q = ch[0]; p.xp = ch[1]; p.r1 = ch[2];
       p.q0 = fm(p.q, p.q);                                  // qPowers' of the NL norm: powers' (q^2) (NormArgument.hs:148)
-      p.q0_inv = minv(p.q0, MR()); p.r1_inv = minv(p.r1, MR());
+      p.q0_inv = finv(p.q0); p.r1_inv = finv(p.r1);
       p.shared_cs = make_shared_coeffs(st, p);
       const U256 tC = st.has_types ? p.xp : U256::zero();
       std::vector<U256> bls_lin(llen - 5), bls_nrm(nlen);
@@ -570,8 +603,10 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
       put_row(b, p.blw);
     }
   });
+  lap("phase 3 host");
   { int rc = commit_rows(B); if (rc) return rc; }
   memcpy(c_bl.data(), h_com.data(), B * 64);
+  lap("bl commit (GPU)");
 
   // ---- t, the combined witness and the argument's linear weights (:438-446)
   std::vector<uint64_t> a_s(B * 4), a_q(B * 4), a_nx(B * nlen * 4), a_lc(B * llen * 4), a_lx(B * llen * 4);
@@ -605,14 +640,19 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
     }
   });
 
+  lap("witness combination host");
   // ---- proveBPM in lockstep (src/Bulletproof.hs:357-359)
   bppp_nlb *nlb = nullptr;
   int rc = bppp_nlb_create(ctx, B, a_s.data(), rp->h_g.data(), a_q.data(), a_nx.data(), rp->h_G.data(), nlen, a_lc.data(), a_lx.data(), rp->h_H.data(), llen, &nlb);
   if (rc) return rc;
+  lap("nlb_create");
+  double t_commit = 0, t_hash = 0, t_collapse = 0;
   std::vector<uint64_t> sX(B * 4), sR(B * 4), X(B * 8), R(B * 8), es(B * 4), resp(B * k * 16);
   for (size_t round = 0; round < k && !rc; round++) {
+    double ta = now();
     rc = bppp_nlb_round_commit(nlb, sX.data(), X.data(), sR.data(), R.data());
     if (rc) break;
+    double tb = now(); t_commit += tb - ta;
     rp_parallel(B, [&](size_t lo, size_t hi) {
       for (size_t b = lo; b < hi; b++) {
         const uint64_t *pts[2] = {&X[8 * b], &R[8 * b]};
@@ -623,8 +663,12 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
         memcpy(&resp[(b * k + slot) * 16], pts[0], 64); memcpy(&resp[(b * k + slot) * 16 + 8], pts[1], 64);
       }
     });
+    double tc = now(); t_hash += tc - tb;
     rc = bppp_nlb_round_collapse(nlb, es.data());
+    t_collapse += now() - tc;
   }
+  if (timing) fprintf(stderr, "[rp_prove] argument: commits %.2f ms, hashing %.2f ms, collapses %.2f ms\n", t_commit, t_hash, t_collapse);
+  t_last = now();
   std::vector<uint64_t> wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
   if (!rc) rc = bppp_nlb_get_witness(nlb, wn.data(), wl.data(), nullptr);
   bppp_nlb_destroy(nlb);
@@ -648,5 +692,6 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
       encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 4 + 2 * k);
     }
   });
+  lap("witness download + encode");
   return BPPP_OK;
 }

@@ -88,14 +88,20 @@ inline bool make_range_data(uint32_t base, const U256 &lo, const U256 &hi, bool 
 }
 
 // digits (TypedReciprocal.hs:125-127): greedy mixed-radix digits of n (already shifted by the range minimum); the first digit
-// is binary when has_bit.  d = min (radix - 1) (n div coeff) by repeated subtraction (radix is small).
+// is binary when has_bit.  d = min (radix - 1) (n div coeff): the largest d <= radix - 1 with d * coeff <= n, by bisection.
 inline std::vector<uint32_t> digits(const RangeData &rd, U256 n) {
   std::vector<uint32_t> out;
   for (size_t i = 0; i < rd.coeffs.size(); i++) {
     const uint32_t radix = (rd.has_bit && i == 0) ? 2u : rd.base;
-    uint32_t d = 0;
-    while (d < radix - 1 && !u_lt(n, rd.coeffs[i])) { n = u_sub(n, rd.coeffs[i]); d++; }
-    out.push_back(d);
+    uint32_t lo = 0, hi = radix - 1;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo + 1) / 2;
+      bool ovf = false;
+      const U256 prod = u_mul64(rd.coeffs[i], mid, &ovf);
+      if (!ovf && !u_lt(n, prod)) lo = mid; else hi = mid - 1;
+    }
+    if (lo) n = u_sub(n, u_mul64(rd.coeffs[i], lo));
+    out.push_back(lo);
   }
   return out;
 }

@@ -108,6 +108,20 @@ int bppp_fold_points(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const ui
 int bppp_fold_points_device(bppp_ctx *ctx, const uint64_t b_mag[3], int b_neg, const uint64_t a_mag[3], int a_neg,
                             const void *d_points_xy, size_t n, void *d_out_xy);
 
+/* ---- a7 / a8, Eisenstein variant: the reference's FastPrime configuration (src/Commitment.hs:293-306) -------------------------
+ * ReducedScalar = Eis Integer: a reduced scalar is a0 + a1*w (w^3 = 1; w acts on scalars as lambda, on points as the
+ * endomorphism (x, y) -> (beta x, y), src/Data/Curve/CM.hs:25-27) with components of about 65 bits
+ * (rationalReducedScalarLength = 65).  bppp_rational_reduce_eis is the class default rationalReduceScalar (Commitment.hs:242-255)
+ * over that instance: reducedChar = conjEis . charEis, reduceScalar = decomposeEis (FastPrime.hs:186-205), Euclid with the
+ * nearest-integer quotRem of Integral (Eis a) (src/Data/Field/Eis.hs:72-82), stop at the first r with (normEis r)^2 <= 2n.
+ * Components: mag[2*k], mag[2*k+1] = the two 64-bit limbs of |component k|, neg[k] its sign (k = 0: rational part, 1: w part).
+ * bppp_fold_points_eis_device is projectivePairIP of that configuration (Commitment.hs:343-353 with the FastInnerProduct instance
+ * :374-398, 65 rows) mapped over adjacent pairs: out[j] = b' * pts[2j] + a' * pts[2j+1].  Same cost as the integer fold
+ * (two 66-row walks instead of one 130-row walk): provided for parity with that configuration, not as the fast path. */
+int bppp_rational_reduce_eis(const uint64_t x[4], uint64_t a_mag[4], int a_neg[2], uint64_t b_mag[4], int b_neg[2]);
+int bppp_fold_points_eis_device(bppp_ctx *ctx, const uint64_t b_mag[4], const int b_neg[2], const uint64_t a_mag[4], const int a_neg[2],
+                                const void *d_points_xy, size_t n, void *d_out_xy);
+
 /* ---- a10/a11/a16: scalar halves of the Norm / Linear round (NL flavour) ---------------------
  * makeScalarsComs scalar sums (src/Bulletproof/NormArgument.hs:113-118 via foldXR :20-29):
  *   sx = sum_j q^(4j) xL_j xR_j,  sr = sum_j q^(4j) xR_j^2   over adjacent pairs (odd tail: xR = 0)

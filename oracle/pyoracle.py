@@ -343,6 +343,32 @@ def tensor(bs: Sequence[int], es: Sequence[int], qs_fn: Callable[[int], int]) ->
     return [b * t % N for b in bs for t in ts]
 
 
+def tensor_vector(bs: Sequence[int], es: Sequence[int], qs: Sequence[int]) -> List[int]:
+    """tensor' of the Data.Vector instance (src/Bulletproof.hs:114-122): V.generate (2^k * |bs|) multIndex with
+    multIndex n = bs ! (n div 2^k) * product [if testBit n j then e else q | (j, e, q) <- zip3 [0..] (reverse es) qs]."""
+    xs = list(zip(range(len(es)), reversed(list(es)), qs))
+    l_exp = 1 << len(xs)
+    out = []
+    for n in range(l_exp * len(bs)):
+        v = bs[n // l_exp]
+        for j, e, q in xs:
+            v = v * (e if (n >> j) & 1 else q) % N
+        out.append(v)
+    return out
+
+
+def contract_vector(xs: Sequence[int], ys: Sequence[int]) -> List[int]:
+    """contract' of the Data.Vector instance (src/Bulletproof.hs:147-159): one dot product per chunk of |xs| elements of ys, the
+    last chunk possibly short (V.zipWith truncates)."""
+    x_len, y_len = len(xs), len(ys)
+    n, r = divmod(y_len, x_len)
+    out = []
+    for i in range(n + (1 if r else 0)):
+        chunk = ys[y_len - r:] if i == n else ys[i * x_len:(i + 1) * x_len]
+        out.append(sum(a * b for a, b in zip(xs, chunk)) % N)
+    return out
+
+
 def contract(xs: Sequence[int], ys: Sequence[int]) -> List[int]:
     """contract' for lists (src/Bulletproof.hs:97)."""
     return [dot_zip(xs, ch) for ch in chunks(len(xs), list(ys))]
@@ -971,4 +997,81 @@ def glv_inner_product(sgs: Sequence[Tuple[int, Point]], ec) -> Point:
             elif db:
                 q = cm_mul(p00)
                 v = ec.add(ec.neg(q) if diff else q, v)
+    return v
+
+
+# ============================================================================= Eisenstein rational reduction and pair fold
+# rationalReduceScalar for the FastPrime configuration: the class default (src/Commitment.hs:242-255) over SplitScalar (FastPrime p)
+# (:293-306): reducedChar = conjEis . charEis, normScalar = normEis, reduceScalar = decomposeEis; `quot` is the Integral (Eis a)
+# instance's nearest-integer division (src/Data/Field/Eis.hs:72-82).  projectivePairIP (:343-353) then runs 65 rows
+# (rationalReducedScalarLength, :304) over the FastInnerProduct instance of FastPrime points (:374-398).
+
+
+def eis_norm(e) -> int:
+    """normEis (Eis.hs:23-24)"""
+    return e[0] * e[0] - e[0] * e[1] + e[1] * e[1]
+
+
+def eis_sub(x, y):
+    return (x[0] - y[0], x[1] - y[1])
+
+
+def eis_quot(x, m):
+    """quot of Integral (Eis a) (Eis.hs:72-82): (x * conj m) / norm m, each component rounded to the nearest integer"""
+    m_n = eis_norm(m)
+    u, v = eis_mul(x, eis_conj(m))
+
+    def rnd(n):
+        q, r = divmod(n, m_n)               # Haskell divMod: floor, 0 <= r < m_n
+        sg = (r > 0) - (r < 0)
+        return q + sg if m_n - abs(r) < abs(r) else q
+    return (rnd(u), rnd(v))
+
+
+def eis_recompose(e) -> int:
+    """recomposeEis (Eis.hs:59-60) in Fr"""
+    return (e[0] + LAMBDA * e[1]) % N
+
+
+def rational_reduce_scalar_eis(x: int):
+    """(a, b) as Eisenstein integers with x = a / b: egcd (pRed, 0) (reduceScalar x, 1), the list starting at its second argument
+    (Commitment.hs:252), first (r, s) with (normEis r)^2 <= 2n (:247)."""
+    prev = (eis_conj(CHAR_EIS_FR), (0, 0))
+    cur = (decompose_eis(x), (1, 0))
+    while eis_norm(cur[0]) ** 2 > 2 * N:
+        q = eis_quot(prev[0], cur[0])
+        nxt = (eis_sub(prev[0], eis_mul(q, cur[0])), eis_sub(prev[1], eis_mul(q, cur[1])))
+        prev, cur = cur, nxt
+    return cur
+
+
+def pair_ip_eis(s0, g0: Point, s1, g1: Point, ec) -> Point:
+    """projectivePairIP (s0, g0) (s1, g1) (Commitment.hs:343-353) for Eisenstein reduced scalars: normalizeBasis of the FastPrime
+    instance (:387-398: absolute components, sign folded into p00, p11 = p00 +- lambda p00), 65 rows of dbl' + addBasis (:382-385).
+    (The a == 0 corner of that normalizeBasis is mis-signed in the reference, see glv_inner_product; the group element is computed.)"""
+    terms = []
+    for (a, b), g in ((s0, g0), (s1, g1)):
+        sa, sb = (a > 0) - (a < 0), (b > 0) - (b < 0)
+        p00 = ec.neg(g) if sa == -1 else g
+        lam = cm_mul(p00)
+        if sa == sb:
+            p11, diff = ec.neg(cm_mul(lam)), False
+        else:
+            p11, diff = ec.add(p00, ec.neg(lam)), True
+        if sa == 0 and sb == 1:
+            diff = False
+        terms.append((abs(a), abs(b), diff, p00, p11))
+    assert all(a < 2**65 and b < 2**65 for a, b, _, _, _ in terms), "component exceeds rationalReducedScalarLength"
+    v = None
+    for row in range(65, 0, -1):
+        v = ec.add(v, v)
+        for a, b, diff, p00, p11 in terms:
+            da, db = (a >> (row - 1)) & 1, (b >> (row - 1)) & 1
+            if da and db:
+                v = ec.add(p11, v)
+            elif da:
+                v = ec.add(p00, v)
+            elif db:
+                lam = cm_mul(p00)
+                v = ec.add(ec.neg(lam) if diff else lam, v)
     return v

@@ -98,6 +98,25 @@ def test_tensor_matches_list_instance(gpu, nb, k):
         gpu.free(dout)
 
 
+@pytest.mark.parametrize("nb,k", [(2, 8), (3, 9), (1, 6), (4, 2)])
+def test_tensor_is_the_vector_instance(gpu, nb, k):
+    """The device kernel indexes bits exactly as the Data.Vector instance of tensor' does (src/Bulletproof.hs:114-122:
+    V.generate, multIndex n = bs ! (n div 2^k) * product [testBit n j ? e : q]) — one output element per lane, no list recursion —
+    so the V.Vector semantics of SURVEY.md row a15 / f4 are what runs on the GPU; the list instance gives the same vector."""
+    rnd = random.Random(nb * 131 + k)
+    bs = [rnd.randrange(O.N) for _ in range(nb)]
+    es = [rnd.randrange(O.N) for _ in range(k)]
+    qs = [rnd.randrange(O.N) for _ in range(k)]
+    want = O.tensor_vector(bs, es, qs)
+    assert want == O.tensor(bs, es, lambda r: qs[r])
+    dout = gpu.alloc(max(1, nb << k) * 32)
+    try:
+        gpu.tensor(bs, es, qs, dout)
+        assert array_to_scalars(gpu.download(dout, (nb << k, 4))) == want
+    finally:
+        gpu.free(dout)
+
+
 @pytest.mark.parametrize("mod,m", [(0, O.P), (1, O.N)])
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 1000])
 def test_batch_inverse_matches_reference_semantics(gpu, mod, m, n):

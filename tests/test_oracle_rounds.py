@@ -84,6 +84,19 @@ def test_tensor_list_equals_vector_instance():
         assert got == want
 
 
+def test_vector_instance_equals_list_instance():
+    """BPCollection V.Vector (Bulletproof.hs:102-162) and BPCollection [] (:68-99) are the same functions: tensor' and contract'
+    restated from both instances agree on the shapes the verifier uses (final witness 2 x 8 rounds, 3 x 9 rounds) and on ragged ones."""
+    rnd = random.Random(14)
+    r = lambda n: [rnd.randrange(O.N) for _ in range(n)]
+    for nb, k in [(1, 0), (2, 8), (3, 9), (2, 1), (5, 3), (1, 6)]:
+        bs, es, qs = r(nb), r(k), r(k)
+        assert O.tensor_vector(bs, es, qs) == O.tensor(bs, es, lambda i: qs[i])
+    for nx, ny in [(1, 1), (4, 261), (2, 4), (3, 10), (8, 8), (5, 4)]:
+        xs, ys = r(nx), r(ny)
+        assert O.contract_vector(xs, ys) == O.contract(xs, ys)
+
+
 def test_rational_reduce_properties(oracle_lib):
     rnd = random.Random(8)
     for x in [0, 1, O.N - 1, 2**128, 2**200] + [rnd.randrange(O.N) for _ in range(500)]:
