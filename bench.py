@@ -301,6 +301,7 @@ def main():
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--headline-only", action="store_true", help="only the 2^log2n MSM leg (profiling passes: one launch shape per kernel)")
     ap.add_argument("--check-combined", action="store_true", help="N > 1: rank 0 also computes the whole sharded MSM alone (all ranks' inputs regenerated "
                                                                   "from their seeds) and asserts the combined point equals it")
     args = ap.parse_args()
@@ -397,7 +398,7 @@ def main():
 
     # BASELINE config 2: the 2^16-term MSM (the first 2^16 pairs of the same synthetic inputs), same entry point
     small = None
-    if world == 1 and args.log2n > 16:
+    if world == 1 and args.log2n > 16 and not args.headline_only:
         n16 = 1 << 16
         r16 = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), n16, 0)
         gpu.profile_read(reset=True); gpu.profile_enable(True)
@@ -417,7 +418,7 @@ def main():
     # fixed Pedersen basis: the SAME 2^log2n points registered once (bppp_basis: table 2^(c w) P_i built outside the timed region), then
     # MSMs over fresh scalars with one bucket set for all windows.  A separate leg: the headline stays the arbitrary-point MSM.
     fixed = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         tb0 = time.perf_counter()
         bas = gpu.basis(dpts.data_ptr(), device=True, n=n)
         torch.cuda.synchronize()
@@ -443,7 +444,7 @@ def main():
     # (bucket reduction, window combine, the host round trip) overlap the accumulate kernel of another.  Reported beside the
     # single-stream headline, whose per-kernel durations are what the roofline and the rocprof summaries refer to.
     concurrent = None
-    if world == 1 and args.msm_streams > 1:
+    if world == 1 and args.msm_streams > 1 and not args.headline_only:
         import threading
         ctxs = [b.Bppp(local) for _ in range(args.msm_streams)]
         for c_ in ctxs:
@@ -470,7 +471,7 @@ def main():
 
     # the drop-in entry point takes HOST buffers (bppp_msm, what innerProduct's FFI stub calls): PCIe-inclusive rate, never `value`
     host_call = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         sc_h = np.ascontiguousarray(dsc.cpu().numpy().view(np.uint64))
         pt_h = np.ascontiguousarray(dpts.cpu().numpy().view(np.uint64))
         assert gpu.msm(sc_h, pt_h) == res
@@ -484,7 +485,7 @@ def main():
         del sc_h, pt_h
 
     verify = prove = None
-    if args.verify_batch > 0:
+    if args.verify_batch > 0 and not args.headline_only:
         vsteps = max(3, args.steps // 2)
         verify, prove = bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, vsteps, 1, "64by64",
                                           cpu_baseline_leg=(world == 1 and not args.no_cpu_baseline))
@@ -525,6 +526,8 @@ def main():
         # the bound that actually binds: modular multiplications of the accumulate kernel against the
         # measured rate of a multiply-only kernel on this chip (test hook bppp_test_mulmod_rate)
         try:
+            if args.headline_only:
+                raise RuntimeError("skipped (--headline-only)")
             import ctypes as C
             from bulletproofspp_amd.capi import load_test_library
             rate = C.c_double(0.0)

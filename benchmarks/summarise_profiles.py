@@ -3,7 +3,7 @@
   python benchmarks/summarise_profiles.py <round-tag>
 
 Inputs (written on the GPU box, see DESIGN.md section 4 for the exact commands):
-  gpurun_out/prof_msm/msm_kernel_stats.csv        rocprofv3 --kernel-trace --stats, bench.py MSM leg only
+  gpurun_out/prof_msm/msm_kernel_stats.csv        rocprofv3 --kernel-trace --stats, bench.py --headline-only --no-cpu-baseline (the 2^20 MSM alone)
   gpurun_out/prof_bench/bench_kernel_stats.csv    same, whole default bench.py (MSM + verify + prove legs)
   gpurun_out/pmc_fetch/fetch_counter_collection.csv   rocprofv3 --pmc FETCH_SIZE   (own pass)
   gpurun_out/pmc_write/write_counter_collection.csv   rocprofv3 --pmc WRITE_SIZE   (own pass)
@@ -63,7 +63,7 @@ def main():
             if k.startswith("bppp::") and k in out["WRITE_SIZE"]:
                 per_kernel[k] = out["FETCH_SIZE"][k][0] * 1024 * 2 + out["WRITE_SIZE"][k][0] * 1024
         traffic = {
-            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py MSM leg, 2^20 pairs, auto window (c = 16)",
+            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --headline-only, 2^20 pairs, auto window (c = 16)",
             "k_acc_points_FETCH_SIZE_KB_raw": fk,
             "k_acc_points_WRITE_SIZE_KB": wk,
             "correction": "gfx950 FETCH_SIZE counts 128-B requests at 64 B: x2 (MI355X_MICROARCH.md, HBM section); the accumulate kernel's point gathers are "
