@@ -202,10 +202,13 @@ __global__ void __launch_bounds__(256) k_nlb_broadcast(const uint4 *__restrict__
   for (uint32_t b = blockIdx.y; b < batch; b += gridDim.y) dst[(size_t)b * words4 + i] = v;
 }
 }  // namespace bppp
-extern "C" {
-int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
+namespace bppp {
+// on_device: every array argument (scalars AND basis points) is already resident in HBM (the batch range-proof prover builds the
+// start state of the argument on the device, csrc/rpprove_dev.hip); otherwise they are host arrays (the C ABI entry point)
+int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t *g_xy, const uint64_t *q, const uint64_t *norm_x,
                     const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
-                    bppp_nlb **out) {
+                    bppp_nlb **out, bool on_device) {
+  const hipMemcpyKind KIND = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (!ctx || !out || !s || !g_xy || !q || !batch || ctx_closed(ctx)) return BPPP_ERR_ARG;
   if ((nlen && (!norm_x || !norm_g_xy)) || (llen && (!lin_c || !lin_x || !lin_h_xy)) || nlen + llen == 0 || nlen >= (1u << 24) || llen >= (1u << 24) ||
       batch >= (1u << 20))
@@ -231,23 +234,31 @@ int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   NLB_HIP(o, hipMemsetAsync(o->x[0], 0, batch * o->xstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lx[0], 0, batch * o->lstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lc[0], 0, batch * o->lstride * 32, st));
-  if (nlen) NLB_HIP(o, hipMemcpy2DAsync(o->x[0], o->xstride * 32, norm_x, nlen * 32, nlen * 32, batch, hipMemcpyHostToDevice, st));
+  if (nlen) NLB_HIP(o, hipMemcpy2DAsync(o->x[0], o->xstride * 32, norm_x, nlen * 32, nlen * 32, batch, KIND, st));
   if (llen) {
-    NLB_HIP(o, hipMemcpy2DAsync(o->lc[0], o->lstride * 32, lin_c, llen * 32, llen * 32, batch, hipMemcpyHostToDevice, st));
-    NLB_HIP(o, hipMemcpy2DAsync(o->lx[0], o->lstride * 32, lin_x, llen * 32, llen * 32, batch, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemcpy2DAsync(o->lc[0], o->lstride * 32, lin_c, llen * 32, llen * 32, batch, KIND, st));
+    NLB_HIP(o, hipMemcpy2DAsync(o->lx[0], o->lstride * 32, lin_x, llen * 32, llen * 32, batch, KIND, st));
   }
   {   // the shared starting basis: uploaded once (staged in the not-yet-used second buffer), then one copy per proof (they diverge after round 1)
     uint32_t *stg = o->P[1];
     NLB_HIP(o, hipMemsetAsync(stg, 0, o->cap * 64, st));
-    if (nlen) NLB_HIP(o, hipMemcpyAsync(stg, norm_g_xy, nlen * 64, hipMemcpyHostToDevice, st));
-    if (llen) NLB_HIP(o, hipMemcpyAsync(stg + evb(nlen) * 16, lin_h_xy, llen * 64, hipMemcpyHostToDevice, st));
-    NLB_HIP(o, hipMemcpyAsync(stg + (evb(nlen) + evb(llen)) * 16, g_xy, 64, hipMemcpyHostToDevice, st));
+    if (nlen) NLB_HIP(o, hipMemcpyAsync(stg, norm_g_xy, nlen * 64, KIND, st));
+    if (llen) NLB_HIP(o, hipMemcpyAsync(stg + evb(nlen) * 16, lin_h_xy, llen * 64, KIND, st));
+    NLB_HIP(o, hipMemcpyAsync(stg + (evb(nlen) + evb(llen)) * 16, g_xy, 64, KIND, st));
     const size_t words4 = o->cap * 4;     // uint4 per basis
     k_nlb_broadcast<<<dim3((unsigned)((words4 + 255) / 256), (unsigned)std::min<size_t>(batch, 65535)), dim3(256), 0, st>>>(
         (const uint4 *)stg, (uint32_t)words4, (uint4 *)o->P[0], (uint32_t)batch);
   }
   o->q.resize(batch); o->qinv.resize(batch); o->nn.assign(batch, U256::one()); o->ln.assign(batch, U256::one());
   o->s.resize(batch); o->sX.resize(batch); o->sR.resize(batch);
+  std::vector<uint64_t> hq, hs;
+  if (on_device) {                           // the host keeps q, q^-1 and s of every proof (round bookkeeping): bring them over
+    hq.resize(4 * batch); hs.resize(4 * batch);
+    NLB_HIP(o, hipMemcpyAsync(hq.data(), q, batch * 32, hipMemcpyDeviceToHost, st));
+    NLB_HIP(o, hipMemcpyAsync(hs.data(), s, batch * 32, hipMemcpyDeviceToHost, st));
+    NLB_HIP(o, hipStreamSynchronize(st));
+    q = hq.data(); s = hs.data();
+  }
   for (size_t b = 0; b < batch; b++) { o->q[b] = U256::load(q + 4 * b); o->qinv[b] = o->q[b]; o->s[b] = U256::load(s + 4 * b); }
   batch_minv(o->qinv.data(), batch, M);
   NLB_HIP(o, hipStreamSynchronize(st));
@@ -256,6 +267,13 @@ int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   if (int rc = fill()) { bppp_nlb_destroy(o); return rc; }
   *out = o;
   return BPPP_OK;
+}
+}  // namespace bppp
+extern "C" {
+int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
+                    const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
+                    bppp_nlb **out) {
+  return nlb_create_impl(ctx, batch, s, g_xy, q, norm_x, norm_g_xy, nlen, lin_c, lin_x, lin_h_xy, llen, out, false);
 }
 
 int bppp_nlb_lengths(const bppp_nlb *o, size_t *batch, size_t *nlen, size_t *llen) {

@@ -30,6 +30,7 @@
 #include "rpsetup.hpp"
 #include "sha256.hip.h"
 #include "rp_internal.hpp"
+#include "rphash.hip.h"
 
 namespace bppp {
 
@@ -105,47 +106,7 @@ __global__ void __launch_bounds__(64) k_rp_decode_scalars(RpDims D, uint32_t bat
   else fe_store(wit_lin + ((size_t)b * D.fl + (i - D.fn)) * 8, v);
 }
 
-// ------------------------------------------------------------------------------------------------ transcript text
-// `show` of a field element = its decimal integer.  v is split into nine 9-digit chunks (10^81 > 2^256) by repeated division.
-struct Dec { uint32_t ch[9]; uint32_t top, len; };
-BPPP_DI uint32_t ndigits9(uint32_t v) {
-  return v >= 100000000u ? 9 : v >= 10000000u ? 8 : v >= 1000000u ? 7 : v >= 100000u ? 6 : v >= 10000u ? 5 : v >= 1000u ? 4 : v >= 100u ? 3 : v >= 10u ? 2 : 1;
-}
-BPPP_DI Dec dec_convert(fe v) {
-  Dec d;
-#pragma unroll
-  for (int c = 0; c < 9; c++) {
-    uint64_t rem = 0;
-#pragma unroll
-    for (int i = 7; i >= 0; i--) {
-      const uint64_t cur = (rem << 32) | v.v[i];
-      const uint64_t q = cur / 1000000000ull;
-      v.v[i] = (uint32_t)q; rem = cur - q * 1000000000ull;
-    }
-    d.ch[c] = (uint32_t)rem;
-  }
-  d.top = 0;
-#pragma unroll
-  for (int c = 1; c < 9; c++) if (d.ch[c]) d.top = c;
-  uint32_t tv = 0;
-#pragma unroll
-  for (int c = 0; c < 9; c++) if ((uint32_t)c == d.top) tv = d.ch[c];
-  d.len = 9 * d.top + ndigits9(tv);
-  return d;
-}
-// writes the d.len characters so that they END at `end` (exclusive); returns the start
-BPPP_DI uint8_t *dec_write_backward(const Dec &d, uint8_t *end) {
-  uint8_t *p = end;
-#pragma unroll
-  for (int c = 0; c < 9; c++) {
-    if ((uint32_t)c > d.top) continue;
-    uint32_t v = d.ch[c];
-    const uint32_t n = (uint32_t)c == d.top ? ndigits9(v) : 9u;
-    for (uint32_t j = 0; j < n; j++) { *--p = (uint8_t)('0' + v % 10u); v /= 10u; }
-  }
-  return p;
-}
-
+// ------------------------------------------------------------------------------------------------ transcript text (helpers: rphash.hip.h)
 BPPP_DI const uint32_t *rp_point_ptr(const RpDims &D, const uint32_t *init_pts, const uint32_t *resp_pts, uint32_t b, uint32_t t) {
   return t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16 : init_pts + ((size_t)b * (4 + D.nr) + (t - 2 * D.k)) * 16;
 }
@@ -195,14 +156,6 @@ __global__ void __launch_bounds__(256) k_rp_text(RpDims D, const uint32_t *__res
 //                                 7 + j -> e of round j + 1 (first round first), (X, R) prepended    (Bulletproof.hs:374)
 // The hashed message is  header_h <> text[b][off[start_h] ..]  with header_h = tag <> show n <> show (length ps), identical for
 // every proof (precomputed on the host, HashPlan).  Hash 7 + k is the batch weight rho_b = H(seed <> b) (b = 0: rho = 1).
-BPPP_DI uint32_t load_unaligned_be32(const uint8_t *p) {
-  const uintptr_t a = (uintptr_t)p;
-  const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
-  const uint32_t sh = (uint32_t)(a & 3) * 8;
-  const uint64_t two = ((uint64_t)q[1] << 32) | q[0];
-  return __builtin_bswap32((uint32_t)(two >> sh));
-}
-
 __global__ void __launch_bounds__(64) k_rp_hash(RpDims D, uint32_t batch, uint32_t nhash, const HashPlan *__restrict__ plan, const uint8_t *__restrict__ text,
                                                 const uint32_t *__restrict__ text_off, const uint8_t *__restrict__ seed, uint32_t *__restrict__ ch,
                                                 uint32_t *__restrict__ es, uint32_t *__restrict__ rho) {
@@ -229,40 +182,10 @@ __global__ void __launch_bounds__(64) k_rp_hash(RpDims D, uint32_t batch, uint32
     return;
   }
   const HashPlan *pl = plan + h;
-  const uint32_t npts = rp_npts(D), hlen = pl->hlen;
+  const uint32_t npts = rp_npts(D);
   const uint32_t *off = text_off + (size_t)b * (npts + 1);
   const uint32_t t0 = off[pl->start_pt], t1 = off[npts];
-  const uint8_t *tx = text + (size_t)b * D.text_stride + t0;     // the suffix of the proof's text this call hashes
-  const uint32_t mlen = hlen + (t1 - t0);
-  const uint32_t nblk = (mlen + 9 + 63) / 64;
-  for (uint32_t blk = 0; blk < nblk; blk++) {
-    const uint32_t p0 = blk * 64;
-    if (p0 >= hlen && p0 + 64 <= mlen) {
-      const uint8_t *src = tx + (p0 - hlen);
-#pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = load_unaligned_be32(src + 4 * i);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t p = p0 + 4 * i + j;
-          uint32_t byte = 0;
-          if (p < hlen) byte = pl->hdr[p];
-          else if (p < mlen) byte = tx[p - hlen];
-          else if (p == mlen) byte = 0x80;
-          word = (word << 8) | byte;
-        }
-        w[i] = word;
-      }
-      if (blk == nblk - 1) { w[14] = 0; w[15] = mlen * 8; }     // mlen < 2^29 bytes
-    }
-    sha256_compress(st, w);
-  }
-  fe v; sha256_digest_to_limbs(st, v.v);
-  fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
-  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  const fe v = rp_hash_to_fr(pl->hdr, pl->hlen, text + (size_t)b * D.text_stride + t0, t1 - t0);   // the suffix of the proof's text this call hashes
   const uint32_t slot = pl->out_slot;
   if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
   else fe_store(es + ((size_t)b * D.k + (slot - 7)) * 8, v);

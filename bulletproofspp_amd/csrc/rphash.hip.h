@@ -1,0 +1,99 @@
+// rphash.hip.h — device helpers of the Fiat-Shamir transcript: `show` of a coordinate (decimal text) and the SHA-256 of
+// header <> text with the digest read as a field element (shaOracle, app/Main.hs:64-80).  Shared by the batch verifier
+// (csrc/rp.hip) and the batch prover (csrc/rpprove_dev.hip).
+#pragma once
+#include "fe.hip.h"
+#include "sha256.hip.h"
+
+namespace bppp {
+
+// `show` of a field element = its decimal integer.  v is split into nine 9-digit chunks (10^81 > 2^256) by repeated division.
+struct Dec { uint32_t ch[9]; uint32_t top, len; };
+BPPP_DI uint32_t ndigits9(uint32_t v) {
+  return v >= 100000000u ? 9 : v >= 10000000u ? 8 : v >= 1000000u ? 7 : v >= 100000u ? 6 : v >= 10000u ? 5 : v >= 1000u ? 4 : v >= 100u ? 3 : v >= 10u ? 2 : 1;
+}
+BPPP_DI Dec dec_convert(fe v) {
+  Dec d;
+#pragma unroll
+  for (int c = 0; c < 9; c++) {
+    uint64_t rem = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+      const uint64_t cur = (rem << 32) | v.v[i];
+      const uint64_t q = cur / 1000000000ull;
+      v.v[i] = (uint32_t)q; rem = cur - q * 1000000000ull;
+    }
+    d.ch[c] = (uint32_t)rem;
+  }
+  d.top = 0;
+#pragma unroll
+  for (int c = 1; c < 9; c++) if (d.ch[c]) d.top = c;
+  uint32_t tv = 0;
+#pragma unroll
+  for (int c = 0; c < 9; c++) if ((uint32_t)c == d.top) tv = d.ch[c];
+  d.len = 9 * d.top + ndigits9(tv);
+  return d;
+}
+// writes the d.len characters so that they END at `end` (exclusive); returns the start
+BPPP_DI uint8_t *dec_write_backward(const Dec &d, uint8_t *end) {
+  uint8_t *p = end;
+#pragma unroll
+  for (int c = 0; c < 9; c++) {
+    if ((uint32_t)c > d.top) continue;
+    uint32_t v = d.ch[c];
+    const uint32_t n = (uint32_t)c == d.top ? ndigits9(v) : 9u;
+    for (uint32_t j = 0; j < n; j++) { *--p = (uint8_t)('0' + v % 10u); v /= 10u; }
+  }
+  return p;
+}
+
+BPPP_DI uint32_t load_unaligned_be32(const uint8_t *p) {
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+  const uint32_t sh = (uint32_t)(a & 3) * 8;
+  const uint64_t two = ((uint64_t)q[1] << 32) | q[0];
+  return __builtin_bswap32((uint32_t)(two >> sh));
+}
+
+
+// SHA-256 (hdr <> tx[0 .. tlen)), digest -> Fr by Binary (Prime p) (src/Encoding.hs:75-79), toP.  hdr: <= 64 bytes anywhere in global
+// memory; tx: any alignment, readable up to 8 bytes past its end (the callers pad their buffers).
+BPPP_DI fe rp_hash_to_fr(const uint8_t *hdr, uint32_t hlen, const uint8_t *tx, uint32_t tlen) {
+  uint32_t st[8];
+  sha256_init(st);
+  uint32_t w[16];
+  const uint32_t mlen = hlen + tlen;
+  const uint32_t nblk = (mlen + 9 + 63) / 64;
+  for (uint32_t blk = 0; blk < nblk; blk++) {
+    const uint32_t p0 = blk * 64;
+    if (p0 >= hlen && p0 + 64 <= mlen) {
+      const uint8_t *src = tx + (p0 - hlen);
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = load_unaligned_be32(src + 4 * i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t p = p0 + 4 * i + j;
+          uint32_t byte = 0;
+          if (p < hlen) byte = hdr[p];
+          else if (p < mlen) byte = tx[p - hlen];
+          else if (p == mlen) byte = 0x80;
+          word = (word << 8) | byte;
+        }
+        w[i] = word;
+      }
+      if (blk == nblk - 1) { w[14] = 0; w[15] = mlen * 8; }     // mlen < 2^29 bytes
+    }
+    sha256_compress(st, w);
+  }
+  fe v; sha256_digest_to_limbs(st, v.v);
+  fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
+#pragma unroll
+  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  return v;
+}
+
+}  // namespace bppp

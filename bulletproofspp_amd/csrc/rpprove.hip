@@ -24,6 +24,7 @@
 #include <vector>
 #include "ec.hip.h"
 #include "rp_internal.hpp"
+#include "rpprove_dev.hpp"
 #include "sha256.hip.h"
 
 namespace bppp {
@@ -59,10 +60,6 @@ using namespace bppp_host;
 extern "C" {
 int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x, const uint64_t *norm_g_xy,
                     size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out);
-void bppp_nlb_destroy(bppp_nlb *nlb);
-int bppp_nlb_round_commit(bppp_nlb *nlb, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy);
-int bppp_nlb_round_collapse(bppp_nlb *nlb, const uint64_t *es);
-int bppp_nlb_get_witness(bppp_nlb *nlb, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s);
 int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, int window_bits, size_t batch_hint, bppp_basis **out);
 int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, size_t batch, uint64_t *out_xy);
 }
@@ -487,6 +484,45 @@ int ensure_pwork(bppp_rp *rp, size_t bytes) {
 
 }  // namespace
 
+namespace bppp {
+int rpp_ensure_pwork(bppp_rp *rp, size_t bytes) { return ensure_pwork(rp, bytes); }
+int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *d_out) {
+  bppp_ctx *ctx = rp->ctx;
+  k_rp_commit_inputs<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream>>>(rp->d_fixed, d_in_sc, (uint64_t)n, d_out);
+  BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
+int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t *host_out) {
+  return bppp_msm_basis(rp->commit_basis, d_rows, 1 + rp->st.llen + rp->st.nlen, nrows, host_out);
+}
+}  // namespace bppp
+
+static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
+                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files);
+
+// encodeProof' (src/RangeProof.hs:60-66): commitments file = the input commitments; proof file = final witness scalars (norm, linear),
+// then blCom, rCom, dmCom, mCom and the responses
+static void encode_batch(const bppp_rp *rp, size_t B, const RppOutputs &o, uint8_t *coms_files, uint8_t *proof_files) {
+  const Setup &st = rp->st;
+  const RpDims &D = rp->D;
+  const size_t nr = st.rds.size(), k = st.rounds;
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    std::vector<const uint64_t *> pts;
+    for (size_t b = lo; b < hi; b++) {
+      pts.assign(nr, nullptr);
+      for (size_t i = 0; i < nr; i++) pts[i] = o.input_coms + (b * nr + i) * 8;
+      encode_points(coms_files + b * D.coms_bytes, pts.data(), nr);
+      uint8_t *pf = proof_files + b * D.proof_bytes;
+      for (size_t i = 0; i < st.fn; i++) put_field(pf + 32 * i, U256::load(o.wit_norm + (b * st.fn + i) * 4));
+      for (size_t i = 0; i < st.fl; i++) put_field(pf + 32 * (st.fn + i), U256::load(o.wit_lin + (b * st.fl + i) * 4));
+      pts.assign(4 + 2 * k, nullptr);
+      pts[0] = o.c_bl + 8 * b; pts[1] = o.c_r + 8 * b; pts[2] = o.c_dm + 8 * b; pts[3] = o.c_m + 8 * b;
+      for (size_t j = 0; j < 2 * k; j++) pts[4 + j] = o.resp + (b * k) * 16 + 8 * j;
+      encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 4 + 2 * k);
+    }
+  });
+}
+
 extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
                                    size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files) {
   if (!rp) return BPPP_ERR_ARG;
@@ -495,6 +531,56 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   if (!batch) return BPPP_OK;
   if (!amounts || !types || !blinds || (prefix_len && !rand_prefix) || !coms_files || !proof_files || batch >= (1u << 20) || prefix_len > 4096)
     return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: bad arguments");
+  const Setup &st = rp->st;
+  uint32_t max_base = 0;
+  for (const RangeData &rd : st.rds) max_base = std::max(max_base, rd.base);
+  // the device algebra looks digits up in a 256-entry table of reciprocals; wider bases (and BPPP_RP_HOST_ALGEBRA=1, kept for
+  // comparison) take the host-algebra path: same bytes out
+  if (max_base > 256 || getenv("BPPP_RP_HOST_ALGEBRA")) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files);
+  hipSetDevice(ctx->device);
+  const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
+  if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");
+  { int rc = build_fixed_table(rp); if (rc) return rc; }
+  if (!rp->commit_basis) { int rc = bppp_basis_create_device(ctx, rp->d_basis, T, 0, 4096, &rp->commit_basis); if (rc) return rc; }
+  const bool timing = getenv("BPPP_RP_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = now();
+  auto lap = [&](const char *what) { if (timing) { double t = now(); fprintf(stderr, "[rp_prove] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
+  // ---- the witness on the host: digits and multiplicities are integer work on the plain amounts (TypedReciprocal.hs:125-161)
+  std::vector<uint64_t> h_in_sc(B * nr * 12);
+  std::vector<uint32_t> dig(B * nlen), mul(B * nlen), mss(B * (llen - 6) + 1);
+  std::atomic<int> failed{-1};
+  std::vector<std::string> errs(B);
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    PState p;
+    for (size_t b = lo; b < hi; b++) {
+      if (!make_witness(st, p, amounts + 4 * nr * b, types + 4 * nr * b, blinds + 4 * nr * b)) { failed = (int)b; errs[b] = p.err; continue; }
+      for (size_t i = 0; i < nr; i++) { p.v[i].store(&h_in_sc[(b * nr + i) * 12]); p.ty[i].store(&h_in_sc[(b * nr + i) * 12 + 4]); p.bl[i].store(&h_in_sc[(b * nr + i) * 12 + 8]); }
+      for (size_t i = 0; i < nlen; i++) {
+        const bool typing = (st.pos[i].kind & 0xFFu) == bppp_rps::POS_TYPING;
+        dig[b * nlen + i] = typing ? 0u : (uint32_t)p.d[i].w[0];
+        mul[b * nlen + i] = (uint32_t)p.mi[i].w[0];
+      }
+      for (size_t j = 0; j + 6 < llen; j++) mss[b * (llen - 6) + j] = (uint32_t)p.ms_shared[j].w[0];
+    }
+  });
+  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((int)failed) + ": " + errs[failed]);
+  lap("witness digits (host)");
+  std::vector<uint64_t> in_pt(B * nr * 8), c_dm(B * 8), c_m(B * 8), c_r(B * 8), c_bl(B * 8), resp(B * k * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
+  RppHostInputs in{B, h_in_sc.data(), dig.data(), mul.data(), mss.data(), rand_prefix, prefix_len};
+  RppOutputs out{in_pt.data(), c_dm.data(), c_m.data(), c_r.data(), c_bl.data(), resp.data(), wn.data(), wl.data()};
+  { int rc = rpp_device_prove(rp, in, out); if (rc) return rc; }
+  lap("phases + argument (device)");
+  encode_batch(rp, B, out, coms_files, proof_files);
+  lap("encode (host)");
+  return BPPP_OK;
+}
+
+static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
+                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files) {
+  if (!rp) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = rp->ctx;
+  if (!batch) return BPPP_OK;
   hipSetDevice(ctx->device);
   hipStream_t stream = ctx->stream;
   const Setup &st = rp->st;

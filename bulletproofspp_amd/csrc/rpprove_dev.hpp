@@ -1,0 +1,43 @@
+// rpprove_dev.hpp — interface between the two halves of the batch range-proof prover: csrc/rpprove.hip (entry point, witness digits,
+// commitments, encoding; the host-algebra reference path) and csrc/rpprove_dev.hip (field algebra and transcript on the device).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "rp_internal.hpp"
+
+namespace bppp {
+
+struct PDims { uint32_t nlen, llen, nr, T, nd, has_types; };     // T = 1 + llen + nlen (one commitment row), nd = random scalars per proof
+
+struct RppHostInputs {
+  size_t batch;
+  const uint64_t *in_sc;     // [batch][nr][3][4]: amount, type, blinding as field elements
+  const uint32_t *dig;       // [batch][nlen]: the digit of every norm position (unused at typing positions)
+  const uint32_t *mul;       // [batch][nlen]: the inline multiplicity (0 elsewhere)
+  const uint32_t *mss;       // [batch][llen - 6]: the shared multiplicities
+  const uint8_t *prefix; size_t prefix_len;
+};
+struct RppOutputs {          // host arrays
+  uint64_t *input_coms;      // [batch][nr][8]
+  uint64_t *c_dm, *c_m, *c_r, *c_bl;   // [batch][8] each
+  uint64_t *resp;            // [batch][rounds][16]: (X, R), last round first
+  uint64_t *wit_norm, *wit_lin;        // [batch][fn][4], [batch][fl][4]
+};
+
+int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out);
+
+// provided by rpprove.hip
+int rpp_ensure_pwork(bppp_rp *rp, size_t bytes);
+int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *d_out);                 // asynchronous on the context's stream
+int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t *host_out);              // synchronises the stream
+int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t *g_xy, const uint64_t *q, const uint64_t *norm_x, const uint64_t *norm_g_xy,
+                    size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out, bool on_device);
+
+}  // namespace bppp
+
+extern "C" {
+void bppp_nlb_destroy(bppp_nlb *nlb);
+int bppp_nlb_round_commit(bppp_nlb *nlb, uint64_t *sX, uint64_t *X_xy, uint64_t *sR, uint64_t *R_xy);
+int bppp_nlb_round_collapse(bppp_nlb *nlb, const uint64_t *es);
+int bppp_nlb_get_witness(bppp_nlb *nlb, uint64_t *norm_w, uint64_t *lin_w, uint64_t *s);
+}

@@ -14,6 +14,7 @@
 #include "ctx.hpp"
 #include "fe.hip.h"
 #include "modinv.hip.h"
+#include "trrp.hpp"
 #include "../../include/bppp.h"
 
 namespace bppp {
@@ -22,7 +23,6 @@ namespace bppp {
 // times the instruction cache) for a kernel whose wavefronts all sit in different phases
 __device__ __noinline__ fe frm(fe a, fe b) { return fe_mul<1>(a, b); }
 __device__ __noinline__ fe frs(fe a) { return fe_sqr<1>(a); }
-struct TrrpDims { uint32_t nlen, llen, nr, nsyms, npub, has_types, flavour; };
 
 BPPP_DI fe fr_pow_u32(fe base, uint32_t e) {
   fe acc = fe_one();
@@ -32,10 +32,6 @@ BPPP_DI fe fr_pow_u32(fe base, uint32_t e) {
 BPPP_DI fe lds_get(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8; k++) r.v[k] = p[i * 8 + k]; return r; }
 BPPP_DI void lds_put(uint32_t *p, uint32_t i, const fe &a) { for (int k = 0; k < 8; k++) p[i * 8 + k] = a.v[k]; }
 
-// position kinds (Phase1 constructors, TypedReciprocal.hs:56-60)
-static constexpr uint32_t K_TYPING = 0, K_INLINE = 1, F_IO = 1u << 8, F_IA = 1u << 9, NO_SYM = 0xFFFFFFFFu;
-
-static constexpr int TRRP_MAX_SLOTS = 16;      // distinct digit bases of one setup (base map x^3, x^5, ...)
 
 // One WAVEFRONT per proof (64 lanes): lane t owns the contiguous chunks [t*C, (t+1)*C) of every list, so the running powers of
 // q0 advance by one multiplication per position.  ~9 k Fr multiplications per 64by64-shaped proof, half of them start-up
@@ -186,11 +182,6 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
 
 using namespace bppp;
 
-struct bppp_trrp {
-  bppp_ctx *ctx;
-  TrrpDims D;
-  uint32_t *pos_kind, *pos_range, *pos_slot, *pos_sym, *pos_coeff, *range_min, *range_assumed, *syms, *cs_slot, *cs_sym, *pub_is_out, *pub_amount, *pub_sym;
-};
 
 extern "C" {
 

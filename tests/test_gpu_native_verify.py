@@ -114,6 +114,13 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
         assert got[b][0] == want[0], "commitments file differs (proof %d)" % b
         assert got[b][1] == want[1], "proof file differs (proof %d)" % b
     assert nat.verify_batch([c for c, _ in got], [p for _, p in got], b"\x07" * 32)
+    # the host-algebra path of the library (per-proof field work and hashing in C++ on the host cores; the default does both on the
+    # device, csrc/rpprove_dev.hip) writes the same bytes
+    os.environ["BPPP_RP_HOST_ALGEBRA"] = "1"
+    try:
+        assert nat.prove_batch(inputs, prefixes) == got
+    finally:
+        del os.environ["BPPP_RP_HOST_ALGEBRA"]
     # a value outside its range is refused
     bad = [list(r) for r in inputs]
     bad[2][3] = (100 if not typed else 1000, bad[2][3][1], bad[2][3][2])
