@@ -64,12 +64,28 @@ BPPP_DI fe rp_hash_to_fr(const uint8_t *hdr, uint32_t hlen, const uint8_t *tx, u
   uint32_t w[16];
   const uint32_t mlen = hlen + tlen;
   const uint32_t nblk = (mlen + 9 + 63) / 64;
+  // Interior blocks (all 64 bytes inside the text) are read as 17 aligned dwords and shifted into place.  One wavefront per
+  // SIMD is all this kernel gets at batch sizes of a few thousand (15 hashes per proof), so nothing else hides the load latency:
+  // the dwords of block k + 1 are requested BEFORE block k is compressed (~2 300 instructions).
+  const uint32_t first_fast = (hlen + 63) / 64, last_fast = mlen / 64;            // fast blocks: [first_fast, last_fast)
+  const uintptr_t a0 = (uintptr_t)(tx + ((size_t)first_fast * 64 - hlen));
+  const uint32_t sh = (uint32_t)(a0 & 3) * 8;
+  const uint32_t *q = (const uint32_t *)(a0 & ~(uintptr_t)3);                       // dword holding the first byte of block first_fast
+  uint32_t nx[17];
+  if (first_fast < last_fast) {
+#pragma unroll
+    for (int i = 0; i < 17; i++) nx[i] = q[i];
+  }
   for (uint32_t blk = 0; blk < nblk; blk++) {
     const uint32_t p0 = blk * 64;
-    if (p0 >= hlen && p0 + 64 <= mlen) {
-      const uint8_t *src = tx + (p0 - hlen);
+    if (blk >= first_fast && blk < last_fast) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = load_unaligned_be32(src + 4 * i);
+      for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32((uint32_t)((((uint64_t)nx[i + 1] << 32) | nx[i]) >> sh));
+      if (blk + 1 < last_fast) {
+        const uint32_t *qn = q + (size_t)(blk + 1 - first_fast) * 16;
+#pragma unroll
+        for (int i = 0; i < 17; i++) nx[i] = qn[i];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; i++) {
