@@ -28,6 +28,12 @@ template <int OP> __global__ void __launch_bounds__(256) k(uint32_t *out, uint32
     if (OP == 10) { REP16(asm volatile("v_lshrrev_b64 %0, 29, %0\n v_lshrrev_b64 %1, 29, %1\n v_lshrrev_b64 %2, 29, %2\n v_lshrrev_b64 %3, 29, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));) }
     if (OP == 11) { REP16(asm volatile("v_mad_i32_i24 %0, %4, %5, %0\n v_mad_i32_i24 %1, %4, %5, %1\n v_mad_i32_i24 %2, %4, %5, %2\n v_mad_i32_i24 %3, %4, %5, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b));) }
     if (OP == 12) { REP16(asm volatile("v_add3_u32 %0, %4, %5, %0\n v_add3_u32 %1, %4, %5, %1\n v_add3_u32 %2, %4, %5, %2\n v_add3_u32 %3, %4, %5, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b));) }
+    if (OP == 14) { REP16(asm volatile("v_alignbit_b32 %0, %0, %0, 7\n v_alignbit_b32 %1, %1, %1, 7\n v_alignbit_b32 %2, %2, %2, 7\n v_alignbit_b32 %3, %3, %3, 7" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+    if (OP == 15) { REP16(asm volatile("v_bitop3_b32 %0, %4, %5, %0 bitop3:0x96\n v_bitop3_b32 %1, %4, %5, %1 bitop3:0x96\n v_bitop3_b32 %2, %4, %5, %2 bitop3:0x96\n v_bitop3_b32 %3, %4, %5, %3 bitop3:0x96" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b));) }
+    if (OP == 16) { REP16(asm volatile("v_lshl_or_b32 %0, %0, 25, %4\n v_lshl_or_b32 %1, %1, 25, %4\n v_lshl_or_b32 %2, %2, 25, %4\n v_lshl_or_b32 %3, %3, 25, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a));) }
+    if (OP == 17) { REP16(asm volatile("v_lshrrev_b32 %0, 7, %0\n v_lshrrev_b32 %1, 7, %1\n v_lshrrev_b32 %2, 7, %2\n v_lshrrev_b32 %3, 7, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+    if (OP == 18) { REP16(asm volatile("v_xor_b32 %0, %4, %0\n v_xor_b32 %1, %4, %1\n v_xor_b32 %2, %4, %2\n v_xor_b32 %3, %4, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a));) }
+    if (OP == 19) { REP16(asm volatile("v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b));) }
     if (OP == 13) { REP16(asm volatile("v_mad_u64_u32 %0, s[6:7], %4, %5, %1\n v_mad_u64_u32 %1, s[6:7], %4, %5, %2\n v_mad_u64_u32 %2, s[6:7], %4, %5, %3\n v_mad_u64_u32 %3, s[6:7], %4, %5, %0" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "s6", "s7");) }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(c0 + c1 + c2 + c3) + d0 + d1 + d2 + d3 + (uint32_t)(f0 + f1 + f2 + f3);
@@ -52,7 +58,7 @@ template <int OP> void run(const char *name, int waves_per_simd) {
 }
 
 int main() {
-  for (int w : {1, 4, 8}) {
+  for (int w : {1, 2, 8}) {
     run<0>("v_mad_u64_u32 (4 chains)", w);
     run<13>("v_mad_u64_u32 (rotating)", w);
     run<1>("v_mul_lo_u32", w);
@@ -67,6 +73,12 @@ int main() {
     run<12>("v_add3_u32", w);
     run<7>("v_add_co/addc_co chain", w);
     run<8>("v_mov_b32", w);
+    run<14>("v_alignbit_b32", w);
+    run<15>("v_bitop3_b32", w);
+    run<16>("v_lshl_or_b32", w);
+    run<17>("v_lshrrev_b32", w);
+    run<18>("v_xor_b32", w);
+    run<19>("v_perm_b32", w);
   }
   return 0;
 }

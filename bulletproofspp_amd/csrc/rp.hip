@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64) k_rp_hash(RpDims D, uint32_t batch, uint32
   const uint32_t npts = rp_npts(D);
   const uint32_t *off = text_off + (size_t)b * (npts + 1);
   const uint32_t t0 = off[pl->start_pt], t1 = off[npts];
-  const fe v = rp_hash_to_fr(pl->hdr, pl->hlen, text + (size_t)b * D.text_stride + t0, t1 - t0);   // the suffix of the proof's text this call hashes
+  const fe v = rp_hash_to_fr(pl->hdr_be, pl->hlen, text + (size_t)b * D.text_stride + t0, t1 - t0);   // the suffix of the proof's text this call hashes
   const uint32_t slot = pl->out_slot;
   if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
   else fe_store(es + ((size_t)b * D.k + (slot - 7)) * 8, v);
@@ -238,7 +238,7 @@ int rp_build_plan(bppp_rp *rp) {
     HashPlan p; memset(&p, 0, sizeof p);
     std::string h = rp->tag + dec_str(n) + dec_str(count);
     if (h.size() > RP_HDR_MAX) return false;
-    memcpy(p.hdr, h.data(), h.size());
+    rp_pack_header(h, p.hdr_be);
     p.hlen = (uint32_t)h.size(); p.start_pt = start; p.out_slot = slot;
     plan.push_back(p);
     return true;

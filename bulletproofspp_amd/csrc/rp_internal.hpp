@@ -22,7 +22,12 @@ struct RpDims {
 __host__ __device__ inline uint32_t rp_npts(const RpDims &D) { return 4 + D.nr + 2 * D.k; }
 
 static constexpr int RP_HDR_MAX = 64;
-struct HashPlan { uint8_t hdr[RP_HDR_MAX]; uint32_t hlen, start_pt, out_slot; };   // out_slot: index into ch[7] (< 7) or 7 + index into es[k]
+struct HashPlan { uint32_t hdr_be[RP_HDR_MAX / 4]; uint32_t hlen, start_pt, out_slot; };   // header as big-endian words, zero-padded
+// header bytes -> big-endian words
+inline void rp_pack_header(const std::string &h, uint32_t be[RP_HDR_MAX / 4]) {
+  for (int i = 0; i < RP_HDR_MAX / 4; i++) be[i] = 0;
+  for (size_t i = 0; i < h.size() && i < (size_t)RP_HDR_MAX; i++) be[i >> 2] |= (uint32_t)(uint8_t)h[i] << (24 - 8 * (i & 3));
+}   // out_slot: index into ch[7] (< 7) or 7 + index into es[k]
 
 
 // f(lo, hi) on disjoint ranges covering [0, n), one host thread each (at most 16: the GPU box's CPU share per GPU)

@@ -56,9 +56,27 @@ BPPP_DI uint32_t load_unaligned_be32(const uint8_t *p) {
 }
 
 
-// SHA-256 (hdr <> tx[0 .. tlen)), digest -> Fr by Binary (Prime p) (src/Encoding.hs:75-79), toP.  hdr: <= 64 bytes anywhere in global
-// memory; tx: any alignment, readable up to 8 bytes past its end (the callers pad their buffers).
-BPPP_DI fe rp_hash_to_fr(const uint8_t *hdr, uint32_t hlen, const uint8_t *tx, uint32_t tlen) {
+// bytes p .. p+3 (big-endian) of the message  hdr <> tx[0 .. mlen - hlen) <> 0x80 <> 0 ...  without a branch: the header comes as 16
+// big-endian words, the text through the unaligned read; words that straddle a boundary are masked together.  (A bytewise
+// assembly of the first and last blocks cost ~130 dependent byte loads behind divergent branches per hash.)
+BPPP_DI uint32_t rp_msg_word(const uint32_t *hdr_be, uint32_t hlen, const uint8_t *tx, uint32_t mlen, uint32_t p) {
+  int32_t off = (int32_t)p - (int32_t)hlen;
+  off = off < -4 ? -4 : off;                                   // bytes before the text are masked out below; stay next to the buffer
+  const uint32_t T = load_unaligned_be32(tx + off);
+  const uint32_t H = hdr_be[(p >> 2) & 15u];
+  const int32_t kh = (int32_t)hlen - (int32_t)p;               // header bytes in this word: >= 4 all of it, <= 0 none
+  const uint32_t hm = kh >= 4 ? ~0u : kh <= 0 ? 0u : (~0u << (8 * (4 - kh)));
+  uint32_t w = (H & hm) | (T & ~hm);
+  const int32_t k = (int32_t)mlen - (int32_t)p;                // message bytes in this word
+  const uint32_t mm = k >= 4 ? ~0u : k <= 0 ? 0u : (~0u << (8 * (4 - k)));
+  const uint32_t pad = (k >= 0 && k < 4) ? (0x80u << (8 * (3 - k))) : 0u;
+  return (w & mm) | pad;
+}
+
+// SHA-256 (hdr <> tx[0 .. tlen)), digest -> Fr by Binary (Prime p) (src/Encoding.hs:75-79), toP.  hdr_be: the header (<= 64 bytes) as 16
+// big-endian words, zero-padded, in global memory; tx: any alignment, readable from 4 bytes before it to 8 bytes past its end
+// (the callers' buffers have that slack).
+BPPP_DI fe rp_hash_to_fr(const uint32_t *hdr_be, uint32_t hlen, const uint8_t *tx, uint32_t tlen) {
   uint32_t st[8];
   sha256_init(st);
   uint32_t w[16];
@@ -66,7 +84,7 @@ BPPP_DI fe rp_hash_to_fr(const uint8_t *hdr, uint32_t hlen, const uint8_t *tx, u
   const uint32_t nblk = (mlen + 9 + 63) / 64;
   // Interior blocks (all 64 bytes inside the text) are read as 17 aligned dwords and shifted into place.  One wavefront per
   // SIMD is all this kernel gets at batch sizes of a few thousand (15 hashes per proof), so nothing else hides the load latency:
-  // the dwords of block k + 1 are requested BEFORE block k is compressed (~2 300 instructions).
+  // the dwords of block k + 1 are requested BEFORE block k is compressed.
   const uint32_t first_fast = (hlen + 63) / 64, last_fast = mlen / 64;            // fast blocks: [first_fast, last_fast)
   const uintptr_t a0 = (uintptr_t)(tx + ((size_t)first_fast * 64 - hlen));
   const uint32_t sh = (uint32_t)(a0 & 3) * 8;
@@ -88,19 +106,7 @@ BPPP_DI fe rp_hash_to_fr(const uint8_t *hdr, uint32_t hlen, const uint8_t *tx, u
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t p = p0 + 4 * i + j;
-          uint32_t byte = 0;
-          if (p < hlen) byte = hdr[p];
-          else if (p < mlen) byte = tx[p - hlen];
-          else if (p == mlen) byte = 0x80;
-          word = (word << 8) | byte;
-        }
-        w[i] = word;
-      }
+      for (int i = 0; i < 16; i++) w[i] = rp_msg_word(hdr_be, hlen, tx, mlen, p0 + 4 * i);
       if (blk == nblk - 1) { w[14] = 0; w[15] = mlen * 8; }     // mlen < 2^29 bytes
     }
     sha256_compress(st, w);

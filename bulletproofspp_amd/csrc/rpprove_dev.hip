@@ -410,14 +410,14 @@ __global__ void __launch_bounds__(256) k_rpp_text_prepend(const uint32_t *__rest
 
 // challenge n (1 <= n <= count) of every proof: SHA-256 (hdr_n <> text from the current start); out slot of challenge n: ch_slot[n-1]
 // into ch[b][7] (slot < 7) or es[b] (slot = 7)
-struct RppHdrs { uint8_t hdr[3][64]; uint32_t hlen[3]; uint32_t slot[3]; };
+struct RppHdrs { uint32_t hdr_be[3][RP_HDR_MAX / 4]; uint32_t hlen[3]; uint32_t slot[3]; };
 __global__ void __launch_bounds__(64) k_rpp_hash(const RppHdrs *__restrict__ H, uint32_t count, uint32_t batch, const uint8_t *__restrict__ text, uint32_t stride,
                                                  const uint32_t *__restrict__ tstart, uint32_t tend, uint32_t *__restrict__ ch, uint32_t *__restrict__ es) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (uint64_t)batch * count) return;
   const uint32_t n = (uint32_t)(g / batch), b = (uint32_t)(g % batch);
   const uint32_t s = tstart[b];
-  const fe v = rp_hash_to_fr(H->hdr[n], H->hlen[n], text + (size_t)b * stride + s, tend - s);
+  const fe v = rp_hash_to_fr(H->hdr_be[n], H->hlen[n], text + (size_t)b * stride + s, tend - s);
   const uint32_t slot = H->slot[n];
   if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
   else fe_store(es + (size_t)b * 8, v);
@@ -491,7 +491,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     for (int n = 1; n <= count; n++) {
       const std::string s = rp->tag + std::to_string(n) + std::to_string(npoints);
       if (s.size() > 64) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: oracle tag too long");
-      memcpy(h.hdr[n - 1], s.data(), s.size()); h.hlen[n - 1] = (uint32_t)s.size(); h.slot[n - 1] = slots[n - 1];
+      rp_pack_header(s, h.hdr_be[n - 1]); h.hlen[n - 1] = (uint32_t)s.size(); h.slot[n - 1] = slots[n - 1];
     }
     BPPP_HIP(ctx, hipMemcpyAsync(hdrs, &h, sizeof h, hipMemcpyHostToDevice, st));
     BPPP_HIP(ctx, hipStreamSynchronize(st));          // h and the caller's staging are on the stack / reused

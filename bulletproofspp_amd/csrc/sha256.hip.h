@@ -22,6 +22,17 @@
 namespace bppp {
 
 BPPP_HD uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+// three-input bit operations: one v_bitop3_b32 each on gfx950 (truth table from src0 = 0xF0, src1 = 0xCC, src2 = 0xAA); the
+// compiler keeps two-input xors otherwise, and the XOR chains are a quarter of a compression's instructions
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SHA_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#define SHA_CH(e, f, g) __builtin_amdgcn_bitop3_b32((e), (f), (g), 0xCA)
+#define SHA_MAJ(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xE8)
+#else
+#define SHA_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#define SHA_CH(e, f, g) (((e) & (f)) ^ (~(e) & (g)))
+#define SHA_MAJ(a, b, c) (((a) & (b)) ^ ((a) & (c)) ^ ((b) & (c)))
+#endif
 
 BPPP_HD void sha256_init(uint32_t h[8]) {
   h[0] = 0x6a09e667u; h[1] = 0xbb67ae85u; h[2] = 0x3c6ef372u; h[3] = 0xa54ff53au;
@@ -37,12 +48,12 @@ BPPP_HD void sha256_compress(uint32_t h[8], uint32_t w[16]) {
     if ((i) < 16) wi = w[(i)];                                                                                   \
     else {                                                                                                       \
       const uint32_t w15 = w[((i) + 1) & 15], w2 = w[((i) + 14) & 15];                                           \
-      const uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);                                     \
-      const uint32_t s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);                                      \
+      const uint32_t s0 = SHA_XOR3(sha_rotr(w15, 7), sha_rotr(w15, 18), (w15 >> 3));                             \
+      const uint32_t s1 = SHA_XOR3(sha_rotr(w2, 17), sha_rotr(w2, 19), (w2 >> 10));                              \
       wi = w[(i) & 15] = w[(i) & 15] + s0 + w[((i) + 9) & 15] + s1;                                              \
     }                                                                                                            \
-    const uint32_t t1 = hh + (sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + (K) + wi; \
-    const uint32_t t2 = (sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));    \
+    const uint32_t t1 = hh + SHA_XOR3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25)) + SHA_CH(e, f, g) + (K) + wi; \
+    const uint32_t t2 = SHA_XOR3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22)) + SHA_MAJ(a, b, c);          \
     hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;                                          \
   }
   SHA_RND(0, 0x428a2f98u) SHA_RND(1, 0x71374491u) SHA_RND(2, 0xb5c0fbcfu) SHA_RND(3, 0xe9b5dba5u)
