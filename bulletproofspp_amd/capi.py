@@ -29,7 +29,7 @@ SYMBOLS = [
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
     "bppp_basis_create", "bppp_basis_create_device", "bppp_basis_destroy", "bppp_basis_info", "bppp_msm_basis",
-    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_prove_batch",
+    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_shape_of", "bppp_rp_digits", "bppp_hash_to_scalar", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_prove_batch",
 ]
 
 
@@ -119,6 +119,9 @@ def load_library() -> C.CDLL:
     lib.bppp_rp_destroy.argtypes = [vp]
     lib.bppp_rp_destroy.restype = None
     lib.bppp_rp_info.argtypes = [vp, vp]
+    lib.bppp_rp_shape_of.argtypes = [i, i, vp, sz, vp]
+    lib.bppp_rp_digits.argtypes = [vp, vp, vp, sz, C.POINTER(sz), C.POINTER(i)]
+    lib.bppp_hash_to_scalar.argtypes = [vp, sz, vp]
     lib.bppp_rp_verify_batch.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp, vp]
     lib.bppp_rp_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp, vp]
     lib.bppp_rp_prove_batch.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, vp]

@@ -330,6 +330,59 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
   return BPPP_OK;
 }
 
+// host-only: the shape a setup would have (no context, no GPU) — setup's arithmetic of TypedReciprocal.hs:332-359 alone
+int bppp_rp_shape_of(int flavour, int has_types, const bppp_rp_range *ranges, size_t nranges, bppp_rp_shape *out) {
+  if (!ranges || !nranges || !out || flavour != 0 || nranges >= (1u << 20)) return BPPP_ERR_ARG;
+  std::vector<bppp_rps::RangeData> rds(nranges);
+  std::string err;
+  for (size_t i = 0; i < nranges; i++) {
+    const bppp_rp_range &r = ranges[i];
+    if (!bppp_rps::make_range_data(r.base, U256::load(r.min), U256::load(r.max), (r.flags & BPPP_RP_SHARED) != 0, (r.flags & BPPP_RP_OUTPUT) != 0,
+                                   (r.flags & BPPP_RP_ASSUMED) != 0, rds[i], err))
+      return BPPP_ERR_ARG;
+  }
+  bppp_rps::Setup st;
+  if (!bppp_rps::make_setup(has_types != 0, rds, std::vector<bppp_rps::PublicVT>(), st, err)) return BPPP_ERR_ARG;
+  const size_t nr = nranges, k = st.rounds, npp = 4 + 2 * k;
+  out->nranges = nr; out->norm_len = st.nlen; out->lin_len = st.llen; out->rounds = k; out->final_norm = st.fn; out->final_lin = st.fl;
+  out->coms_bytes = (nr + 7) / 8 + 32 * nr;
+  out->proof_bytes = 32 * (st.fn + st.fl) + (npp + 7) / 8 + 32 * npp;
+  out->challenges_per_proof = 7 + k;
+  return BPPP_OK;
+}
+
+// host-only: the digits and multiplicity bookkeeping are integer work; this is `digits` (TypedReciprocal.hs:125-127) for one value of
+// one range: out_digits receives *ndigits entries (capacity `cap`); BPPP_ERR_ARG if the value is outside [min, max)
+int bppp_rp_digits(const bppp_rp_range *range, const uint64_t amount[4], uint32_t *out_digits, size_t cap, size_t *ndigits, int *has_bit) {
+  if (!range || !amount || !out_digits || !ndigits) return BPPP_ERR_ARG;
+  bppp_rps::RangeData rd;
+  std::string err;
+  if (!bppp_rps::make_range_data(range->base, U256::load(range->min), U256::load(range->max), false, false, false, rd, err)) return BPPP_ERR_ARG;
+  const U256 v = U256::load(amount);
+  if (bppp_rps::u_lt(v, rd.lo) || !bppp_rps::u_lt(v, rd.hi)) return BPPP_ERR_ARG;
+  const std::vector<uint32_t> ds = bppp_rps::digits(rd, bppp_rps::u_sub(v, rd.lo));
+  if (ds.size() > cap) return BPPP_ERR_ARG;
+  for (size_t i = 0; i < ds.size(); i++) out_digits[i] = ds[i];
+  *ndigits = ds.size();
+  if (has_bit) *has_bit = rd.has_bit ? 1 : 0;
+  return BPPP_OK;
+}
+
+// host-only: the CLI's hash (app/Main.hs:64-65) as the prover and the oracle use it: decode (SHA-256 (data)) through Binary (Prime p)
+// into the scalar field; hashToScalar p s = bppp_hash_to_scalar (p <> s) (app/Main.hs:83-84)
+int bppp_hash_to_scalar(const uint8_t *data, size_t len, uint64_t out[4]) {
+  if ((len && !data) || !out) return BPPP_ERR_ARG;
+  Sha256 h;
+  h.update(data, len);
+  uint32_t d[8], v[8];
+  h.finish(d);
+  sha256_digest_to_limbs(d, v);
+  U256 r;
+  for (int i = 0; i < 4; i++) r.w[i] = ((uint64_t)v[2 * i + 1] << 32) | v[2 * i];
+  bppp_rps::u_mod_n(r).store(out);
+  return BPPP_OK;
+}
+
 int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out) {
   if (!rp || !out) return BPPP_ERR_ARG;
   const bppp_rps::Setup &st = rp->st;

@@ -321,6 +321,13 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
                    const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out);
 void bppp_rp_destroy(bppp_rp *rp);
 int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out);
+/* Host-only helpers (no context, no GPU): the shape `setup` gives a schema (nrmLen, linLen, rounds = optimalWitnessSize, file sizes);
+ * `digits` of one value in one range (src/RangeProof/TypedReciprocal.hs:125-127: greedy mixed-radix digits, the first one binary when
+ * the range needs a bit; cap = capacity of out_digits); and the CLI's hash-to-field `hash = decode . SHA.hash` (app/Main.hs:64-65:
+ * SHA-256, digest read through Binary (Prime p)) — hashToScalar p s = bppp_hash_to_scalar (p <> s) (app/Main.hs:83-84). */
+int bppp_rp_shape_of(int flavour, int has_types, const bppp_rp_range *ranges, size_t nranges, bppp_rp_shape *out);
+int bppp_rp_digits(const bppp_rp_range *range, const uint64_t amount[4], uint32_t *out_digits, size_t cap, size_t *ndigits, int *has_bit);
+int bppp_hash_to_scalar(const uint8_t *data, size_t len, uint64_t out[4]);
 
 /* Batch verification, end to end: for `batch` proofs of this setup, given as the reference's FILES — coms_files [batch][coms_bytes],
  * proof_files [batch][proof_bytes] — decodeProof (src/RangeProof.hs:68-85, src/Encoding.hs:97-128: x-only points, square roots and

@@ -197,3 +197,51 @@ def test_config4_typed_conserved_128by64(gpu):
     ok, status, _ = nat.verify_batch([c for c, _ in bad], [p for _, p in bad], seed, want_status=True)
     assert not ok and [i for i, s_ in enumerate(status) if s_] == [200]
     nat.close()
+
+
+def test_native_layer_on_a_mixed_schema(gpu):
+    """A schema that exercises every Phase1 constructor at once (TypedReciprocal.hs:56-60, :133-169): shared digits with a leading bit
+    (adds the shared base 2), inline digits with and without a bit, an ASSUMED range (typed only: no digits), inputs and outputs of two
+    types balanced by public amounts.  Native prover == host protocol bytes (device-algebra and host-algebra paths), native verifier
+    accepts / identifies a forged member, challenges equal the host's."""
+    pts = O.hash_points(b"mixed schema", 160)
+    rds = [RP.make_range_data(4, 0, 101, True, True, False),        # shared, has_bit
+           RP.make_range_data(4, 0, 256, True, False, False),       # shared, no bit, an INPUT
+           RP.make_range_data(3, 0, 100, False, True, False),       # inline, has_bit
+           RP.make_range_data(16, 0, 2**64, False, True, False),    # inline, no bit
+           RP.make_range_data(5, 0, 1000, False, False, True)]      # assumed input: typing only
+    assert rds[0].has_bit and not rds[1].has_bit and rds[2].has_bit and not rds[3].has_bit
+    # type 3: inputs 200 (range 1) + public 50 = outputs 100 (range 0) + 150 (range 3);  type 9: input 77 (assumed range 4) = output 70 (range 2) + public output 7
+    pub = [(False, 3, 50), (True, 9, 7)]
+    st = RP.setup(RP.GpuBackend(gpu), pts, True, pub, rds, "NL")
+    assert 2 in st.m_bases and 4 in st.m_bases
+    nat = RP.NativeRangeProofs(gpu, st)
+    rnd = random.Random(99)
+    B = 5
+    inputs = [[(100, 3, rnd.randrange(O.N)), (200, 3, rnd.randrange(O.N)), (70, 9, rnd.randrange(O.N)), (150, 3, rnd.randrange(O.N)), (77, 9, rnd.randrange(O.N))]
+              for _ in range(B)]
+    prefixes = [b"mixed %03d" % b for b in range(B)]
+    got = nat.prove_batch(inputs, prefixes)
+    for b in range(B):
+        proof = RP.prove(st, RP.witness(st, inputs[b]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[b]))
+        assert got[b] == E.encode_proof(4, proof), b
+        assert RP.verify(st, proof, RP.sha256_oracle())
+    os.environ["BPPP_RP_HOST_ALGEBRA"] = "1"
+    try:
+        assert nat.prove_batch(inputs, prefixes) == got
+    finally:
+        del os.environ["BPPP_RP_HOST_ALGEBRA"]
+    seed = bytes(range(1, 33))
+    ok, status, chs = nat.verify_batch([c for c, _ in got], [p for _, p in got], seed, want_status=True, want_challenges=True)
+    assert ok and status == [0] * B
+    proof0 = E.decode_proof(4, st.rounds, st.final_lens, E.decode_commitments(5, got[0][0], E.gpu_lift_x(gpu))[0], got[0][1], E.gpu_lift_x(gpu))
+    assert chs[0] == tuple(RP.verifier_challenges(st, proof0, RP.sha256_oracle()))
+    forged = list(got)
+    forged[3] = (got[2][0], got[3][1])                              # another proof's input commitments
+    ok, status, _ = nat.verify_batch([c for c, _ in forged], [p for _, p in forged], seed, want_status=True)
+    assert not ok and status == [0, 0, 0, 1, 0]
+    # the IP argument flavour has no batch path: refused at creation
+    st_ip = RP.setup(RP.GpuBackend(gpu), pts, True, pub, rds, "IP")
+    with pytest.raises(ValueError):
+        RP.NativeRangeProofs(gpu, st_ip)
+    nat.close()
