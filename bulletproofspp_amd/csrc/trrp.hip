@@ -7,8 +7,9 @@
 // bppp_nl_verify_batch_device consumes (q, sp, pub_norm, pub_lin_c, initCom scalars), written where it will read them, so a
 // batch of fresh proofs goes from challenges to the combined MSM without its O(nrmLen + linLen) scalars crossing PCIe.
 //
-// One wavefront per proof.  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
+// A group of lanes per proof (16: four proofs per wavefront).  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
 // inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 8x32 limbs (fe.hip.h).
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
@@ -33,10 +34,16 @@ BPPP_DI fe lds_get(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8;
 BPPP_DI void lds_put(uint32_t *p, uint32_t i, const fe &a) { for (int k = 0; k < 8; k++) p[i * 8 + k] = a.v[k]; }
 
 
-// One WAVEFRONT per proof (64 lanes): lane t owns the contiguous chunks [t*C, (t+1)*C) of every list, so the running powers of
-// q0 advance by one multiplication per position.  ~9 k Fr multiplications per 64by64-shaped proof, half of them start-up
-// (per-lane first powers, the inversion scan); a 256-lane workgroup per proof spent three times that on start-up alone.
-__global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *__restrict__ pos_kind, const uint32_t *__restrict__ pos_range,
+// G lanes per proof (G | 64), 64 / G proofs per wavefront: lane t of a group owns the contiguous chunks [t*C, (t+1)*C) of every list, so
+// the running powers of q0 advance by one multiplication per position.  The per-LANE start-up (first powers of q0 and q0^-1, the
+// prefix / suffix product scans of the inversion, the slot tables: ~100 multiplications) does not shrink with the chunk, and the one
+// safegcd inversion (~14 k instructions on a single lane) is paid per wavefront whatever it serves: with a whole wavefront per proof
+// (round 1) start-up was two thirds of the ~11 k multiplications per 64by64 proof.  G = 16: the chunks are four times longer, the
+// scans two steps shorter and one inversion pass serves four proofs.  (A 256-lane workgroup per proof spent three times the
+// single-wavefront figure on start-up alone.)
+template <int G>
+__global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, uint32_t batch, uint32_t lds_words_per_proof, const uint32_t *__restrict__ pos_kind,
+                                                    const uint32_t *__restrict__ pos_range,
                                                     const uint32_t *__restrict__ pos_slot, const uint32_t *__restrict__ pos_sym,
                                                     const uint32_t *__restrict__ pos_coeff, const uint32_t *__restrict__ range_min,
                                                     const uint32_t *__restrict__ range_assumed, const uint32_t *__restrict__ syms,
@@ -45,12 +52,16 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
                                                     const uint32_t *__restrict__ pub_sym, const uint32_t *__restrict__ ch,
                                                     uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp, uint32_t *__restrict__ out_norm,
                                                     uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
-  extern __shared__ uint32_t lds[];
-  const uint32_t t = threadIdx.x, b = blockIdx.x, m = 2 + D.nsyms;
+  extern __shared__ uint32_t lds_all[];
+  const uint32_t t = threadIdx.x % G, grp = threadIdx.x / G, m = 2 + D.nsyms;
+  const uint32_t b_raw = blockIdx.x * (64 / G) + grp;
+  const bool live = b_raw < batch;                 // a group past the end recomputes the last proof and stores nothing (it must keep up with the barriers)
+  const uint32_t b = live ? b_raw : batch - 1;
+  uint32_t *lds = lds_all + (size_t)grp * lds_words_per_proof;
   uint32_t *inv = lds;                         // [m] the inverted list: e, q0, e + sym_k (holds the lanes' running products first)
-  uint32_t *sa = inv + (size_t)m * 8;          // [64] scan scratch A
-  uint32_t *sb = sa + 64 * 8;                  // [64] scan scratch B
-  uint32_t *x2 = sb + 64 * 8;                  // [nr]  x^(2(j+1))
+  uint32_t *sa = inv + (size_t)m * 8;          // [G] scan scratch A
+  uint32_t *sb = sa + G * 8;                   // [G] scan scratch B
+  uint32_t *x2 = sb + G * 8;                   // [nr]  x^(2(j+1))
   uint32_t *sl = x2 + (size_t)D.nr * 8;        // [3][TRRP_MAX_SLOTS] per base slot: t^2 v, 2 t^5 v / e, 2 t^3 v   (v = x^(3+2 slot))
   const uint32_t *c = ch + (size_t)b * 56;
   const fe e = fe_load(c), x = fe_load(c + 8), r0 = fe_load(c + 16), q = fe_load(c + 24), xp = fe_load(c + 32), r1 = fe_load(c + 40), tt = fe_load(c + 48);
@@ -58,7 +69,7 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   if (D.flavour) q0 = fe_neg<1>(q0);
 
   // ---- one inversion for the whole proof (batchInverse semantics: 0 -> 0)
-  const uint32_t K = (m + 63) / 64, lo = min(m, t * K), hi = min(m, lo + K);
+  const uint32_t K = (m + G - 1) / G, lo = min(m, t * K), hi = min(m, lo + K);
   fe local = fe_one();
   for (uint32_t i = lo; i < hi; i++) {
     fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));
@@ -67,18 +78,18 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   }
   lds_put(sa, t, local); lds_put(sb, t, local);
   __syncthreads();
-  for (int d = 1; d < 64; d <<= 1) {           // inclusive prefix (sa) and suffix (sb) products over the lanes
+  for (int d = 1; d < G; d <<= 1) {            // inclusive prefix (sa) and suffix (sb) products over the lanes of the group
     fe pa = lds_get(sa, t), pb = lds_get(sb, t);
     fe oa = (int)t - d >= 0 ? lds_get(sa, t - d) : fe_one();
-    fe ob = t + d < 64 ? lds_get(sb, t + d) : fe_one();
+    fe ob = t + d < (uint32_t)G ? lds_get(sb, t + d) : fe_one();
     __syncthreads();
     lds_put(sa, t, frm(pa, oa)); lds_put(sb, t, frm(pb, ob));
     __syncthreads();
   }
-  fe others = frm(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < 64 ? lds_get(sb, t + 1) : fe_one());
-  fe total = lds_get(sa, 63);
+  fe others = frm(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < (uint32_t)G ? lds_get(sb, t + 1) : fe_one());
+  fe total = lds_get(sa, G - 1);
   __syncthreads();
-  if (t == 0) lds_put(sa, 0, fe_modinv<1>(total));        // one active lane: division steps (~14 k instructions)
+  if (t == 0) lds_put(sa, 0, fe_modinv<1>(total));        // one active lane per group: division steps (~14 k instructions), all groups in one pass
   __syncthreads();
   {
     fe suf = frm(lds_get(sa, 0), others);  // 1 / (product of this lane's own elements), then times the ones already passed
@@ -93,14 +104,18 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   const fe xx = frs(x), x3 = frm(xx, x);
   const fe t2 = frs(tt), t3 = frm(t2, tt), t4 = frs(t2), t5 = frm(t4, tt), t6 = frs(t3);
   const fe two_t5 = fe_dbl<1>(t5), two_t3 = fe_dbl<1>(t3);
-  for (uint32_t j = t; j < D.nr; j += 64) lds_put(x2, j, fr_pow_u32(xx, j + 1));
+  {                                                           // x^(2(j+1)) for this lane's ranges j = t, t + G, ...: one power, then steps of x^(2G)
+    fe xj = fr_pow_u32(xx, t + 1);
+    const fe xg = fr_pow_u32(xx, G);
+    for (uint32_t j = t; j < D.nr; j += G) { lds_put(x2, j, xj); xj = frm(xj, xg); }
+  }
   __syncthreads();
   const fe e_inv = lds_get(inv, 0), q0_inv = lds_get(inv, 1);
-  if (t < TRRP_MAX_SLOTS) {
-    fe v = frm(x3, fr_pow_u32(xx, t));                       // makeBaseMap: x^3, x^5, ... (:349)
-    lds_put(sl, t, frm(t2, v));
-    lds_put(sl, TRRP_MAX_SLOTS + t, frm(frm(two_t5, e_inv), v));
-    lds_put(sl, 2 * TRRP_MAX_SLOTS + t, frm(two_t3, v));
+  for (uint32_t s_ = t; s_ < (uint32_t)TRRP_MAX_SLOTS; s_ += G) {
+    fe v = frm(x3, fr_pow_u32(xx, s_));                      // makeBaseMap: x^3, x^5, ... (:349)
+    lds_put(sl, s_, frm(t2, v));
+    lds_put(sl, TRRP_MAX_SLOTS + s_, frm(frm(two_t5, e_inv), v));
+    lds_put(sl, 2 * TRRP_MAX_SLOTS + s_, frm(two_t3, v));
   }
   __syncthreads();
 
@@ -109,7 +124,7 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
   //   type:   p = t^2 e + t^3 x' + q^-2i (t^2 v + t^3 x' u),     ts0 = q^2i p^2
   fe acc = fe_zero();
   {
-    const uint32_t C = (D.nlen + 63) / 64, plo = min(D.nlen, t * C), phi = min(D.nlen, plo + C);
+    const uint32_t C = (D.nlen + G - 1) / G, plo = min(D.nlen, t * C), phi = min(D.nlen, plo + C);
     fe q2 = fr_pow_u32(q0, plo + 1), qi2 = fr_pow_u32(q0_inv, plo + 1);
     const fe t2e = frm(t2, e), t3xp = frm(t3, xp), t2e_t = fe_add<1>(t2e, t3xp);
     for (uint32_t i = plo; i < phi; i++) {
@@ -131,51 +146,54 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, const uint32_t *
         p = fe_add<1>(t2e, frm(qi2, A));
         ts0 = fe_add<1>(frm(q2, fe_add<1>(frs(p), two_t5)), lds_get(sl, TRRP_MAX_SLOTS + slot));
       }
-      fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
+      if (live) fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
       acc = fe_add<1>(acc, ts0);
       q2 = frm(q2, q0); qi2 = frm(qi2, q0_inv);
     }
   }
   // z (:254): -2 t^5 sum_j min_j x^(2(j+1))  -  [typed] 2 t^5 x pubSum
-  for (uint32_t j = t; j < D.nr; j += 64)
+  for (uint32_t j = t; j < D.nr; j += G)
     if (!range_assumed[j]) acc = fe_sub<1>(acc, frm(two_t5, frm(fe_load(range_min + (size_t)j * 8), lds_get(x2, j))));
   if (D.has_types)
-    for (uint32_t j = t; j < D.npub; j += 64) {
+    for (uint32_t j = t; j < D.npub; j += G) {
       fe term = frm(frm(two_t5, x), frm(fe_load(pub_amount + (size_t)j * 8), lds_get(inv, 2 + pub_sym[j])));
       acc = pub_is_out[j] ? fe_add<1>(acc, term) : fe_sub<1>(acc, term);
     }
   __syncthreads();
   lds_put(sa, t, acc);
   __syncthreads();
-  for (int d = 32; d >= 1; d >>= 1) {
+  for (int d = G / 2; d >= 1; d >>= 1) {
     if ((int)t < d) lds_put(sa, t, fe_add<1>(lds_get(sa, t), lds_get(sa, t + d)));
     __syncthreads();
   }
-  if (t == 0) { fe_store(out_sp + (size_t)b * 8, lds_get(sa, 0)); fe_store(out_q + (size_t)b * 8, q); }
+  if (t == 0 && live) { fe_store(out_sp + (size_t)b * 8, lds_get(sa, 0)); fe_store(out_q + (size_t)b * 8, q); }
 
   // ---- linear weights: makeBpCoeffs (:391-396) over makeSharedCoeffs (:213-216)
   const fe rs = frm(r0, r1);
-  for (uint32_t j = t; j < D.llen; j += 64) {
-    fe v;
-    if (j == 0) v = D.has_types ? fe_neg<1>(xp) : fe_zero();
-    else if (j == 1) v = frm(rs, tt);
-    else if (j == 2) v = frm(rs, t2);
-    else if (j == 3) v = frm(rs, t3);
-    else if (j == 4) v = frm(r0, t4);
-    else if (j == 5) v = frm(rs, t6);
-    else v = frm(lds_get(sl, 2 * TRRP_MAX_SLOTS + cs_slot[j - 6]), fe_sub<1>(e_inv, lds_get(inv, 2 + cs_sym[j - 6])));
-    fe_store(out_cs + ((size_t)b * D.llen + j) * 8, v);
-  }
+  if (live)
+    for (uint32_t j = t; j < D.llen; j += G) {
+      fe v;
+      if (j == 0) v = D.has_types ? fe_neg<1>(xp) : fe_zero();
+      else if (j == 1) v = frm(rs, tt);
+      else if (j == 2) v = frm(rs, t2);
+      else if (j == 3) v = frm(rs, t3);
+      else if (j == 4) v = frm(r0, t4);
+      else if (j == 5) v = frm(rs, t6);
+      else v = frm(lds_get(sl, 2 * TRRP_MAX_SLOTS + cs_slot[j - 6]), fe_sub<1>(e_inv, lds_get(inv, 2 + cs_sym[j - 6])));
+      fe_store(out_cs + ((size_t)b * D.llen + j) * 8, v);
+    }
   // ---- initCom scalars in commitment order blCom : rCom : dmCom : mCom : nComs  (openWith of TranscriptTRRP, :293-297)
   const uint32_t ninit = 4 + D.nr;
   fe qr = D.has_types ? fr_pow_u32(q0, t + 1) : fe_zero();
-  const fe q64 = D.has_types ? fr_pow_u32(q0, 64) : fe_zero();
-  for (uint32_t r = t; r < D.nr; r += 64) {
-    fe ic = range_assumed[r] ? fe_zero() : lds_get(x2, r);                     // inputCoeffs (:325-328)
-    if (D.has_types) { ic = fe_add<1>(ic, qr); qr = frm(qr, q64); }
-    fe_store(out_init + ((size_t)b * ninit + 4 + r) * 8, frm(two_t5, ic));
+  const fe qG = D.has_types ? fr_pow_u32(q0, G) : fe_zero();
+  if (live) {
+    for (uint32_t r = t; r < D.nr; r += G) {
+      fe ic = range_assumed[r] ? fe_zero() : lds_get(x2, r);                     // inputCoeffs (:325-328)
+      if (D.has_types) { ic = fe_add<1>(ic, qr); qr = frm(qr, qG); }
+      fe_store(out_init + ((size_t)b * ninit + 4 + r) * 8, frm(two_t5, ic));
+    }
+    if (t < 4) fe_store(out_init + ((size_t)b * ninit + t) * 8, t == 0 ? fe_one() : t == 1 ? t3 : t == 2 ? t2 : tt);
   }
-  if (t < 4) fe_store(out_init + ((size_t)b * ninit + t) * 8, t == 0 ? fe_one() : t == 1 ? t3 : t == 2 ? t2 : tt);
 }
 
 }  // namespace bppp
@@ -241,13 +259,25 @@ int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges
   if (!batch) return BPPP_OK;
   if (!d_challenges || !d_q || !d_sp || !d_pub_norm || !d_pub_lin_c || !d_init_scalars || batch >= (1u << 24)) return fail(ctx, BPPP_ERR_ARG, "trrp_public: bad arguments");
   hipSetDevice(ctx->device);
-  const size_t lds = ((size_t)(2 + o->D.nsyms) + 128 + o->D.nr + 3 * TRRP_MAX_SLOTS) * 32;
+  // lanes per proof: 32 (two proofs per wavefront) unless the LDS of the proofs of a wavefront would not fit a workgroup
+  int G = 32;
+  if (const char *e = getenv("BPPP_TRRP_G")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) G = v; }
+  auto words = [&](int g) { return ((size_t)(2 + o->D.nsyms) + 2 * (size_t)g + o->D.nr + 3 * TRRP_MAX_SLOTS) * 8; };
+  while (G < 64 && words(G) * 4 * (64 / G) > 64 * 1024) G <<= 1;
+  const size_t wpp = words(G), lds = wpp * 4 * (64 / G);
   if (lds > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "trrp_public: too many ranges for one workgroup's LDS");
-  if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_trrp_public, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_trrp_public<<<dim3((unsigned)batch), dim3(64), lds, ctx->stream>>>(o->D, o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, o->range_min,
-                                                                        o->range_assumed, o->syms, o->cs_slot, o->cs_sym, o->pub_is_out, o->pub_amount, o->pub_sym,
-                                                                        (const uint32_t *)d_challenges, (uint32_t *)d_q, (uint32_t *)d_sp, (uint32_t *)d_pub_norm,
-                                                                        (uint32_t *)d_pub_lin_c, (uint32_t *)d_init_scalars);
+  const unsigned grid = (unsigned)((batch + 64 / G - 1) / (64 / G));
+#define TRRP_LAUNCH(GG)                                                                                                                        \
+  k_trrp_public<GG><<<dim3(grid), dim3(64), lds, ctx->stream>>>(o->D, (uint32_t)batch, (uint32_t)wpp, o->pos_kind, o->pos_range, o->pos_slot, o->pos_sym, o->pos_coeff, \
+                                                               o->range_min, o->range_assumed, o->syms, o->cs_slot, o->cs_sym, o->pub_is_out, o->pub_amount, o->pub_sym, \
+                                                               (const uint32_t *)d_challenges, (uint32_t *)d_q, (uint32_t *)d_sp, (uint32_t *)d_pub_norm,          \
+                                                               (uint32_t *)d_pub_lin_c, (uint32_t *)d_init_scalars)
+  if (G == 64) {
+    if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_trrp_public<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TRRP_LAUNCH(64);
+  } else if (G == 32) TRRP_LAUNCH(32);
+  else TRRP_LAUNCH(16);
+#undef TRRP_LAUNCH
   BPPP_HIP(ctx, hipGetLastError());
   return BPPP_OK;
 }
