@@ -533,6 +533,10 @@ static int choose_window(size_t n, size_t batch) {
   //               bucket for a large batch of small MSMs, which goes through k_reduce_groups (throughput-bound);
   //   heavy top:  when the top window has few real bits its buckets hold n / 2^r entries each and go through the
   //               wave-cooperative merge tree: a flat ~1.5e6 (0.1 ms) once they span many lanes.
+  // One large MSM: the reduction is latency-bound and nearly flat in the bucket count (0.12 ms at c = 11 .. 0.26 ms at c = 16),
+  // so the model above overprices wide windows; thresholds read off the (n, c, L) table of benchmarks/sweep_window.py
+  // (profiles/r02_window_sweep.txt): c = 16 has 17 windows against 20 at c = 13 and no heavy top window.
+  if (batch == 1 && n >= 4096) return n < 12288 ? 8 : n < 46000 ? 10 : n < 200000 ? 13 : 16;
   double best = 1e300; int bc = 8;
   for (int c = 4; c <= 16; c++) {
     int W = 256 / c + 1, full = 254 / c, r = 255 - c * full;       // r = real bits in the top window (1..c)
@@ -593,9 +597,16 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
     while (g.PC > 64) { g.PC >>= 1; g.SC <<= 1; }
     g.row_tiles = (uint32_t)(((size_t)g.HI * g.PR + 63) / 64); g.col_tiles = (uint32_t)(((size_t)g.LO * g.PC + 63) / 64);
   }
-  // slice length: long enough that few buckets straddle lanes, short enough to keep >= ~64K lanes
-  p.L = 4;
-  while (p.L < 64 && p.total_max / (uint64_t)(2 * p.L) >= 65536) p.L <<= 1;
+  // slice length: short enough to keep >= ~150K lanes (two to four wavefronts per SIMD), but at least a quarter of a bucket's
+  // expected entries, so that a bucket straddles few lanes and stays on the serial merge path (sweep_window.py table)
+  if (batch == 1 && !flat) {
+    const uint64_t occ = n / (uint64_t)p.M;
+    int lo = 8; while (lo < 64 && (uint64_t)(4 * lo) < occ) lo <<= 1;
+    p.L = 64; while (p.L > lo && p.total_max / (uint64_t)p.L < 150000) p.L >>= 1;
+  } else {
+    p.L = 4;
+    while (p.L < 64 && p.total_max / (uint64_t)(2 * p.L) >= 65536) p.L <<= 1;
+  }
   // one bucket set for all windows: buckets hold W times more entries; a longer slice keeps a bucket within a few lanes (the
   // serial merge path) while the launch still has two wavefronts per SIMD
   // (L = 256 leaves one wavefront per SIMD and the gathers are no longer hidden: 1.39 ms against 1.15 ms at 2^20)
