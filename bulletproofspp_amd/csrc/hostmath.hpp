@@ -366,7 +366,8 @@ inline U256 extract_scalar(const SInt &s) {
 }
 // rationalReduceScalar (Commitment.hs:242-255): the egcd list starts at its second argument
 // (:252); the first (r, s) with r^2 <= 2n is returned (:247).
-inline std::pair<SInt, SInt> rational_reduce_scalar(const U256 &x) {
+// The plain multi-limb restatement; rational_reduce_scalar below takes the same steps with word-sized quotient estimates.
+inline std::pair<SInt, SInt> rational_reduce_scalar_plain(const U256 &x) {
   SInt pr = SInt::zero(), ps = SInt::zero(), cr = reduce_scalar(x), cs = SInt::zero();
   memcpy(pr.m, FR().m.w, 32);
   cs.m[0] = 1;
@@ -381,6 +382,69 @@ inline std::pair<SInt, SInt> rational_reduce_scalar(const U256 &x) {
     pr = cr; ps = cs; cr = nr; cs = ns;
   }
   return {cr, cs};
+}
+
+// The same (r, s), step for step, on magnitudes.  With r_0 = n, r_1 = x' = reduceScalar x, s_0 = 0, s_1 = 1 and truncating
+// quotients q_i = quot r_(i-1) r_i:  |r_(i+1)| = |r_(i-1)| mod |r_i|,  |s_(i+1)| = |s_(i-1)| + |q_i| |s_i|;  r_i is positive for
+// even i and has the sign of x' for odd i;  every q_i has the sign of x', so s_i alternates (+ for odd i, - for even i) when
+// x' > 0 and stays positive when x' < 0.  A quotient is read off the leading 64 bits of both remainders when the two bounds
+// h0 / (h1 + 1) <= q <= (h0 + 1) / h1 agree (Euclid's quotients are a few bits long, so they nearly always do); otherwise that
+// one step goes through the shift-subtract division.  A batch prover calls this twice per proof and round on the host.
+inline std::pair<SInt, SInt> rational_reduce_scalar(const U256 &x) {
+  const SInt x1 = reduce_scalar(x);
+  uint64_t R0[SInt::L], R1[SInt::L], S0[SInt::L] = {0}, S1[SInt::L] = {1, 0, 0, 0, 0};
+  memset(R0, 0, sizeof R0); memcpy(R0, FR().m.w, 32);
+  memcpy(R1, x1.m, sizeof R1);
+  uint64_t two_n[SInt::L] = {0}; memcpy(two_n, FR().m.w, 32); madd_mag(two_n, two_n, two_n);
+  auto bits = [](const uint64_t *m) { for (int i = SInt::L - 1; i >= 0; i--) if (m[i]) return 64 * i + 64 - __builtin_clzll(m[i]); return 0; };
+  auto top64 = [](const uint64_t *m, int k) {          // bits k .. k+63
+    const int w = k >> 6, o = k & 63;
+    uint64_t v = m[w] >> o;
+    if (o && w + 1 < SInt::L) v |= m[w + 1] << (64 - o);
+    return v;
+  };
+  int idx = 1;                                        // (R1, S1) = (|r_idx|, |s_idx|)
+  for (;;) {
+    const int b1 = bits(R1);
+    bool big = b1 > 130;
+    if (!big) { SInt a = SInt::zero(); memcpy(a.m, R1, sizeof R1); SInt sq = smul(a, a); big = mcmp(sq.m, two_n) > 0; }
+    if (!big) break;
+    const int b0 = bits(R0), k = b0 > 64 ? b0 - 64 : 0;
+    const uint64_t h0 = top64(R0, k), h1 = top64(R1, k);
+    uint64_t R2[SInt::L], S2[SInt::L];
+    bool done = false;
+    if (h1) {
+      const u128 ql = (u128)h0 / ((u128)h1 + 1), qh = ((u128)h0 + 1) / h1;
+      if (ql == qh && (ql >> 62) == 0) {
+        const uint64_t q = (uint64_t)ql;
+        u128 c = 0; uint64_t br = 0;
+        for (int i = 0; i < SInt::L; i++) {             // R2 = R0 - q R1
+          c += (u128)q * R1[i];
+          const u128 d = (u128)R0[i] - (uint64_t)c - br;
+          R2[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; c >>= 64;
+        }
+        c = 0;
+        for (int i = 0; i < SInt::L; i++) { c += (u128)q * S1[i] + S0[i]; S2[i] = (uint64_t)c; c >>= 64; }   // S2 = S0 + q S1
+        done = true;
+      }
+    }
+    if (!done) {
+      SInt a = SInt::zero(), b = SInt::zero(), sa = SInt::zero(), sb = SInt::zero();
+      memcpy(a.m, R0, sizeof R0); memcpy(b.m, R1, sizeof R1); memcpy(sa.m, S0, sizeof S0); memcpy(sb.m, S1, sizeof S1);
+      const SInt q = squot(a, b);
+      const SInt nr = sadd(a, sneg(smul(q, b))), ns = sadd(sa, smul(q, sb));
+      memcpy(R2, nr.m, sizeof R2); memcpy(S2, ns.m, sizeof S2);
+    }
+    memcpy(R0, R1, sizeof R0); memcpy(R1, R2, sizeof R1); memcpy(S0, S1, sizeof S0); memcpy(S1, S2, sizeof S1);
+    idx++;
+  }
+  SInt r = SInt::zero(), sc = SInt::zero();
+  memcpy(r.m, R1, sizeof R1); memcpy(sc.m, S1, sizeof S1);
+  r.neg = (idx & 1) ? x1.neg : false;
+  sc.neg = x1.neg ? false : !(idx & 1);
+  if (r.is_zero()) r.neg = false;
+  if (sc.is_zero()) sc.neg = false;
+  return {r, sc};
 }
 
 }  // namespace bppp_host

@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(64) k_reduce_groups(const uint32_t *__restrict
     if ((int)gl + d < G) xyzz_add(suf, o);
   }
   xyzz v = (gl >= 1) ? suf : xyzz_inf();         // sum_g g * S_g = sum_{g>=1} suf_g, times Lw
-  for (int k = Lw; k > 1; k >>= 1) v = xyzz_dbl(v);
+  if (G > 1) for (int k = Lw; k > 1; k >>= 1) v = xyzz_dbl(v);
   xyzz_add(v, acc);
   for (int d = G >> 1; d >= 1; d >>= 1) {
     xyzz o = xyzz_shfl_down(v, d);
@@ -529,7 +529,7 @@ static int choose_window(size_t n, size_t batch) {
   // Cost model in units of one mixed addition (~68 ps chip-wide, measured at 2^20; profiles/):
   //   accumulate: one addition per (scalar, window that holds real bits): ceil(255/c) windows (+ half a window when
   //               c divides 255: the top digit then wraps for half the scalars and a carry window appears);
-  //   reduce:     ~10 per bucket (the wave-prefix bucket reduction is latency-bound; fitted at c = 13..16); ~4.5 per
+  //   reduce:     ~10 per bucket (the wave-prefix bucket reduction is latency-bound; fitted at c = 13..16); ~3.5 per
   //               bucket for a large batch of small MSMs, which goes through k_reduce_groups (throughput-bound);
   //   heavy top:  when the top window has few real bits its buckets hold n / 2^r entries each and go through the
   //               wave-cooperative merge tree: a flat ~1.5e6 (0.1 ms) once they span many lanes.
@@ -537,12 +537,15 @@ static int choose_window(size_t n, size_t batch) {
   // so the model above overprices wide windows; thresholds read off the (n, c, L) table of benchmarks/sweep_window.py
   // (profiles/r02_window_sweep.txt): c = 16 has 17 windows against 20 at c = 13 and no heavy top window.
   if (batch == 1 && n >= 4096) return n < 12288 ? 8 : n < 46000 ? 10 : n < 200000 ? 13 : 16;
+  double gcost = 3.5; int cmin = 4;
+  if (const char *e = getenv("BPPP_GCOST")) gcost = atof(e);            // tuning sweeps
+  if (const char *e = getenv("BPPP_CMIN")) cmin = std::max(2, atoi(e));
   double best = 1e300; int bc = 8;
-  for (int c = 4; c <= 16; c++) {
+  for (int c = cmin; c <= 16; c++) {
     int W = 256 / c + 1, full = 254 / c, r = 255 - c * full;       // r = real bits in the top window (1..c)
     double weff = full + 1 + (r == c ? 0.5 : 0.0);
     const bool groups = c <= 9 && (double)batch * W >= 4096.0;
-    double cost = weff * (double)n + (groups ? 4.5 : 10.0) * W * (double)(1u << (c - 1));
+    double cost = weff * (double)n + (groups ? gcost : 10.0) * W * (double)(1u << (c - 1));
     double top_bucket = r == c ? n / 2.0 : (double)n / (double)(1u << (r < 20 ? r : 20));
     if ((r == c || r < c - 1) && top_bucket > 1024.0) cost += 1.5e6;
     if (cost < best) { best = cost; bc = c; }
@@ -581,7 +584,15 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
     if (p.WPW < 1) p.WPW = 1;
   }
   p.RG = 0;
-  if (p.M <= 256 && p.NS >= 4096) p.RG = std::min(8, p.M);   // M is a power of two >= 2
+  if (p.M <= 256 && p.NS >= 4096) {                            // M is a power of two >= 2
+    // lanes per window: the serial part costs 2 additions per bucket, the in-group scan and tree ~3 log2(RG) more per lane, so
+    // keep >= 16 buckets per lane (RG = 8 on 8 buckets is 11 additions per bucket, RG = 1 is 2) unless the launch would
+    // then be under ~2 wavefronts per SIMD
+    const int cap = std::min(8, p.M);
+    p.RG = std::max(1, std::min(cap, p.M / 16));
+    while (p.RG < cap && p.NS * (uint64_t)p.RG < 131072) p.RG <<= 1;
+    if (const char *e = getenv("BPPP_RG")) { int v = atoi(e); if (v >= 1 && v <= cap && (v & (v - 1)) == 0) p.RG = v; }
+  }
   p.marg = !p.RG && p.M >= 256 && p.NS <= 65535 && !getenv("BPPP_REDUCE_OLD");
   memset(&p.mg, 0, sizeof p.mg);
   if (p.marg) {

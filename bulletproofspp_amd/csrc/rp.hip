@@ -274,6 +274,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
+  if (rp->nlb_shared) bppp::nlb_shared_destroy(rp->nlb_shared);
   delete rp;
   ctx_release(ctx);
 }

@@ -54,6 +54,7 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
 }
 
 
+namespace bppp { struct NlbShared; void nlb_shared_destroy(NlbShared *); }
 struct bppp_rp {
   bppp_ctx *ctx = nullptr;
   bppp_rps::Setup st;
@@ -73,6 +74,7 @@ struct bppp_rp {
   uint32_t *d_fixed = nullptr;
   bppp_basis *commit_basis = nullptr;           // [g | H | G] registered with its fixed-base table: the range-proof commitments
   void *pwork = nullptr; size_t pwork_bytes = 0;
+  bppp::NlbShared *nlb_shared = nullptr; size_t nlb_shared_batch = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
   void *work = nullptr; size_t work_bytes = 0;
   void *stage = nullptr; size_t stage_bytes = 0;

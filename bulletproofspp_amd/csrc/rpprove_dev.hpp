@@ -33,6 +33,11 @@ int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t 
 int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t *g_xy, const uint64_t *q, const uint64_t *norm_x, const uint64_t *norm_g_xy,
                     size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out, bool on_device);
 
+struct NlbShared;
+int nlb_shared_create(bppp_nlb *o, size_t batch_hint, NlbShared **out);
+void nlb_shared_destroy(NlbShared *sh);
+void nlb_set_shared(bppp_nlb *o, const NlbShared *sh);
+
 }  // namespace bppp
 
 extern "C" {

@@ -121,6 +121,14 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
         assert nat.prove_batch(inputs, prefixes) == got
     finally:
         del os.environ["BPPP_RP_HOST_ALGEBRA"]
+    # the fixed-base route of the argument's first round (round-1 commitments over the registered basis, round-1 fold out of the
+    # multiples table, csrc/nlb.hip: large batches take it by default) writes the same bytes as well
+    os.environ["BPPP_NLB_SHARED_MIN"] = "1"
+    try:
+        assert nat.prove_batch(inputs, prefixes) == got
+        assert nat.prove_batch(inputs[:3], prefixes[:3]) == got[:3]      # the tables are kept by the handle across batches
+    finally:
+        del os.environ["BPPP_NLB_SHARED_MIN"]
     # a value outside its range is refused
     bad = [list(r) for r in inputs]
     bad[2][3] = (100 if not typed else 1000, bad[2][3][1], bad[2][3][2])
