@@ -132,6 +132,7 @@ struct PState {
   size_t npoints = 0;
   Rnd rnd;
   std::string err;
+  std::vector<uint32_t> tmp_ds, tmp_cnt, tmp_ms;   // make_witness scratch
 };
 
 // shaOracle (app/Main.hs:75-80) over ZKPT's transcript (src/ZKP.hs:96-101): the new commitments go IN FRONT; output n hashes
@@ -185,12 +186,13 @@ bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const ui
     const RangeData &rd = st.rds[i];
     if (rd.assumed) continue;
     if (bppp_rps::u_lt(amt[i], rd.lo) || !bppp_rps::u_lt(amt[i], rd.hi)) { ps.err = "value outside its range"; return false; }
-    const std::vector<uint32_t> ds = bppp_rps::digits(rd, bppp_rps::u_sub(amt[i], rd.lo));
+    std::vector<uint32_t> &ds = ps.tmp_ds, &cnt = ps.tmp_cnt, &ms = ps.tmp_ms;       // reused across ranges and proofs
+    bppp_rps::digits_into(rd, bppp_rps::u_sub(amt[i], rd.lo), ds);
     const uint32_t b = rd.base;
     // ms aligned with ns = [1 | hasBit] ++ [1 .. b-1]: the bit itself, then how often each non-zero digit value occurs (:141-145)
-    std::vector<uint32_t> cnt(b, 0);
+    cnt.assign(b, 0);
     for (size_t j = rd.has_bit ? 1 : 0; j < ds.size(); j++) cnt[ds[j]]++;
-    std::vector<uint32_t> ms;
+    ms.clear();
     if (rd.has_bit) ms.push_back(ds[0]);
     for (uint32_t s = 1; s < b; s++) ms.push_back(cnt[s]);
     const size_t p0 = st.first_pos[i];

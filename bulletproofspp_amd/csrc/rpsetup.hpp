@@ -89,20 +89,36 @@ inline bool make_range_data(uint32_t base, const U256 &lo, const U256 &hi, bool 
 
 // digits (TypedReciprocal.hs:125-127): greedy mixed-radix digits of n (already shifted by the range minimum); the first digit
 // is binary when has_bit.  d = min (radix - 1) (n div coeff): the largest d <= radix - 1 with d * coeff <= n, by bisection.
-inline std::vector<uint32_t> digits(const RangeData &rd, U256 n) {
-  std::vector<uint32_t> out;
+// Each digit is the largest d <= radix - 1 with d * coeff <= n (the reference subtracts repeatedly; same digits).  Amounts are
+// nearly always below 2^64, where that is one machine division; wider remainders bisect with a 256 x 64-bit product.
+inline void digits_into(const RangeData &rd, U256 n, std::vector<uint32_t> &out) {
+  out.clear();
   for (size_t i = 0; i < rd.coeffs.size(); i++) {
     const uint32_t radix = (rd.has_bit && i == 0) ? 2u : rd.base;
+    const U256 &cf = rd.coeffs[i];
+    if (!(n.w[1] | n.w[2] | n.w[3])) {
+      uint32_t d;
+      if (cf.w[1] | cf.w[2] | cf.w[3]) d = 0;
+      else if (cf.w[0] == 0) d = radix - 1;
+      else { const uint64_t q = n.w[0] / cf.w[0]; d = q < radix - 1 ? (uint32_t)q : radix - 1; }
+      n.w[0] -= (uint64_t)d * cf.w[0];
+      out.push_back(d);
+      continue;
+    }
     uint32_t lo = 0, hi = radix - 1;
     while (lo < hi) {
       const uint32_t mid = lo + (hi - lo + 1) / 2;
       bool ovf = false;
-      const U256 prod = u_mul64(rd.coeffs[i], mid, &ovf);
+      const U256 prod = u_mul64(cf, mid, &ovf);
       if (!ovf && !u_lt(n, prod)) lo = mid; else hi = mid - 1;
     }
-    if (lo) n = u_sub(n, u_mul64(rd.coeffs[i], lo));
+    if (lo) n = u_sub(n, u_mul64(cf, lo));
     out.push_back(lo);
   }
+}
+inline std::vector<uint32_t> digits(const RangeData &rd, const U256 &n) {
+  std::vector<uint32_t> out;
+  digits_into(rd, n, out);
   return out;
 }
 
