@@ -275,6 +275,8 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
   if (rp->nlb_shared) bppp::nlb_shared_destroy(rp->nlb_shared);
+  if (rp->twin) bppp_rp_destroy(rp->twin);
+  if (rp->twin_ctx) bppp_ctx_destroy(rp->twin_ctx);
   delete rp;
   ctx_release(ctx);
 }
@@ -312,6 +314,8 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
     rp->h_H.assign(points_xy + 16, points_xy + 16 + 8 * st.llen);
     rp->h_G.assign(points_xy + 16 + 8 * st.llen, points_xy + 16 + 8 * (st.llen + st.nlen));
     rp->tag = oracle_tag ? oracle_tag : "";
+    rp->c_ranges.assign(ranges, ranges + nranges); if (npub) rp->c_pubs.assign(pubs, pubs + npub);
+    rp->c_points.assign(points_xy, points_xy + 8 * (2 + st.llen + st.nlen)); rp->c_has_types = has_types;
     hipSetDevice(ctx->device);
     BPPP_HIP(ctx, hipMalloc(&rp->d_basis, (1 + st.nlen + st.llen) * 64));
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis, rp->h_g.data(), 64, hipMemcpyHostToDevice));

@@ -74,6 +74,10 @@ struct bppp_rp {
   uint32_t *d_fixed = nullptr;
   bppp_basis *commit_basis = nullptr;           // [g | H | G] registered with its fixed-base table: the range-proof commitments
   void *pwork = nullptr; size_t pwork_bytes = 0;
+  // the creation arguments, kept so that a second handle on its OWN context (stream, workspaces) can be made: a large prove batch
+  // runs as two half-batches in flight, the host shares of one under the kernels of the other (csrc/rpprove.hip)
+  std::vector<bppp_rp_range> c_ranges; std::vector<bppp_rp_public> c_pubs; std::vector<uint64_t> c_points; int c_has_types = 0;
+  bppp_rp *twin = nullptr; bppp_ctx *twin_ctx = nullptr; bool is_twin = false;
   bppp::NlbShared *nlb_shared = nullptr; size_t nlb_shared_batch = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
   void *work = nullptr; size_t work_bytes = 0;

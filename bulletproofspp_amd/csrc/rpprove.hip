@@ -500,7 +500,7 @@ int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t 
 }  // namespace bppp
 
 static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
-                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files);
+                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base);
 
 // encodeProof' (src/RangeProof.hs:60-66): commitments file = the input commitments; proof file = final witness scalars (norm, linear),
 // then blCom, rCom, dmCom, mCom and the responses
@@ -525,6 +525,9 @@ static void encode_batch(const bppp_rp *rp, size_t B, const RppOutputs &o, uint8
   });
 }
 
+static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
+                           size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base);
+
 extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
                                    size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files) {
   if (!rp) return BPPP_ERR_ARG;
@@ -533,12 +536,43 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   if (!batch) return BPPP_OK;
   if (!amounts || !types || !blinds || (prefix_len && !rand_prefix) || !coms_files || !proof_files || batch >= (1u << 20) || prefix_len > 4096)
     return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: bad arguments");
+  // A large batch runs as TWO half-batches in flight, the second on a twin handle with its own context (stream, workspaces, host
+  // thread): the proofs are independent, and the host shares of a half (digits, the argument's half-GCDs and round bookkeeping,
+  // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).
+  size_t split_min = 2048;
+  if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
+  if (batch < split_min || batch < 2 || rp->is_twin || getenv("BPPP_RP_NO_SPLIT"))
+    return prove_batch_one(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
+  if (!rp->twin) {
+    int rc = bppp_ctx_create(ctx->device, &rp->twin_ctx);
+    if (rc) { rp->twin_ctx = nullptr; return fail(ctx, rc, "rp_prove_batch: creating the second context failed"); }
+    rc = bppp_rp_create(rp->twin_ctx, 0, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
+                        rp->c_points.data(), rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
+    if (rc) { std::string m = bppp_last_error(rp->twin_ctx); bppp_ctx_destroy(rp->twin_ctx); rp->twin_ctx = nullptr; rp->twin = nullptr; return fail(ctx, rc, "rp_prove_batch: second handle: " + m); }
+    rp->twin->is_twin = true;
+  }
+  const size_t nr = rp->st.rds.size(), B0 = (batch + 1) / 2, B1 = batch - B0;
+  int rc1 = BPPP_OK;
+  std::thread second([&] {
+    rc1 = prove_batch_one(rp->twin, B1, amounts + 4 * nr * B0, types + 4 * nr * B0, blinds + 4 * nr * B0, rand_prefix ? rand_prefix + prefix_len * B0 : nullptr, prefix_len,
+                          coms_files + (size_t)rp->D.coms_bytes * B0, proof_files + (size_t)rp->D.proof_bytes * B0, B0);
+  });
+  const int rc0 = prove_batch_one(rp, B0, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
+  second.join();
+  if (rc0) return rc0;
+  if (rc1) return fail(ctx, rc1, bppp_last_error(rp->twin_ctx));
+  return BPPP_OK;
+}
+
+static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
+                           size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base) {
+  bppp_ctx *ctx = rp->ctx;
   const Setup &st = rp->st;
   uint32_t max_base = 0;
   for (const RangeData &rd : st.rds) max_base = std::max(max_base, rd.base);
   // the device algebra looks digits up in a 256-entry table of reciprocals; wider bases (and BPPP_RP_HOST_ALGEBRA=1, kept for
   // comparison) take the host-algebra path: same bytes out
-  if (max_base > 256 || getenv("BPPP_RP_HOST_ALGEBRA")) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files);
+  if (max_base > 256 || getenv("BPPP_RP_HOST_ALGEBRA")) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
   hipSetDevice(ctx->device);
   const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
   if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");
@@ -566,7 +600,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
       for (size_t j = 0; j + 6 < llen; j++) mss[b * (llen - 6) + j] = (uint32_t)p.ms_shared[j].w[0];
     }
   });
-  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((int)failed) + ": " + errs[failed]);
+  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed + index_base) + ": " + errs[failed]);
   lap("witness digits (host)");
   std::vector<uint64_t> in_pt(B * nr * 8), c_dm(B * 8), c_m(B * 8), c_r(B * 8), c_bl(B * 8), resp(B * k * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
   RppHostInputs in{B, h_in_sc.data(), dig.data(), mul.data(), mss.data(), rand_prefix, prefix_len};
@@ -579,7 +613,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
 }
 
 static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
-                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files) {
+                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base) {
   if (!rp) return BPPP_ERR_ARG;
   bppp_ctx *ctx = rp->ctx;
   if (!batch) return BPPP_OK;
@@ -628,7 +662,7 @@ static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, 
       put_row(2 * b, p.dm); put_row(2 * b + 1, p.m);
     }
   });
-  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((int)failed) + ": " + ps[failed].err);
+  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed + index_base) + ": " + ps[failed].err);
   lap("phase 1 host");
   BPPP_HIP(ctx, hipMemcpyAsync(d_in_sc, h_in_sc.data(), in_sc, hipMemcpyHostToDevice, stream));
   {

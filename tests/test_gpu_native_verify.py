@@ -129,6 +129,18 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
         assert nat.prove_batch(inputs[:3], prefixes[:3]) == got[:3]      # the tables are kept by the handle across batches
     finally:
         del os.environ["BPPP_NLB_SHARED_MIN"]
+    # two half-batches in flight on two contexts (the default for large batches, csrc/rpprove.hip): the same bytes, and a refused
+    # input in the second half is reported under its index in the whole batch
+    os.environ["BPPP_RP_SPLIT_MIN"] = "2"
+    try:
+        assert nat.prove_batch(inputs, prefixes) == got
+        assert nat.prove_batch(inputs[:5], prefixes[:5]) == got[:5]
+        worse = [list(r) for r in inputs]
+        worse[4][3] = (100 if not typed else 1000, worse[4][3][1], worse[4][3][2])
+        with pytest.raises(Exception, match="proof 4"):
+            nat.prove_batch(worse, prefixes)
+    finally:
+        del os.environ["BPPP_RP_SPLIT_MIN"]
     # a value outside its range is refused
     bad = [list(r) for r in inputs]
     bad[2][3] = (100 if not typed else 1000, bad[2][3][1], bad[2][3][2])
