@@ -414,6 +414,25 @@ int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t
                                 const void *d_pub_lin_c, const void *d_pub_lin_x, const void *d_es, const void *d_wit_norm, const void *d_wit_lin,
                                 const void *d_init_scalars, const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
 
+}  // extern "C"
+// a second handle of the same setup on its own context (stream, workspaces): the two halves of a large batch run side by side
+int rp_ensure_twin(bppp_rp *rp) {
+  if (rp->twin) return BPPP_OK;
+  bppp_ctx *ctx = rp->ctx;
+  int rc = bppp_ctx_create(ctx->device, &rp->twin_ctx);
+  if (rc) { rp->twin_ctx = nullptr; return fail(ctx, rc, "rp: creating the second context failed"); }
+  rc = bppp_rp_create(rp->twin_ctx, 0, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
+                      rp->c_points.data(), rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
+  if (rc) {
+    const std::string m = bppp_last_error(rp->twin_ctx);
+    bppp_ctx_destroy(rp->twin_ctx); rp->twin_ctx = nullptr; rp->twin = nullptr;
+    return fail(ctx, rc, "rp: second handle: " + m);
+  }
+  rp->twin->is_twin = true;
+  return BPPP_OK;
+}
+extern "C" {
+
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
                                 uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
   if (!rp || !accept) return BPPP_ERR_ARG;

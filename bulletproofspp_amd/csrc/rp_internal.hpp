@@ -84,3 +84,4 @@ struct bppp_rp {
   void *stage = nullptr; size_t stage_bytes = 0;
 };
 
+int rp_ensure_twin(bppp_rp *rp);      // csrc/rp.hip

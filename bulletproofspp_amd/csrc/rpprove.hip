@@ -543,14 +543,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
   if (batch < split_min || batch < 2 || rp->is_twin || getenv("BPPP_RP_NO_SPLIT"))
     return prove_batch_one(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
-  if (!rp->twin) {
-    int rc = bppp_ctx_create(ctx->device, &rp->twin_ctx);
-    if (rc) { rp->twin_ctx = nullptr; return fail(ctx, rc, "rp_prove_batch: creating the second context failed"); }
-    rc = bppp_rp_create(rp->twin_ctx, 0, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
-                        rp->c_points.data(), rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
-    if (rc) { std::string m = bppp_last_error(rp->twin_ctx); bppp_ctx_destroy(rp->twin_ctx); rp->twin_ctx = nullptr; rp->twin = nullptr; return fail(ctx, rc, "rp_prove_batch: second handle: " + m); }
-    rp->twin->is_twin = true;
-  }
+  { int rc = rp_ensure_twin(rp); if (rc) return rc; }
   const size_t nr = rp->st.rds.size(), B0 = (batch + 1) / 2, B1 = batch - B0;
   int rc1 = BPPP_OK;
   std::thread second([&] {
