@@ -179,40 +179,29 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         pdt = float(t.item())
     assert len({pf[b * shp["proof_bytes"]:(b + 1) * shp["proof_bytes"]].tobytes() for b in range(min(batch, 512))}) == min(batch, 512), "proofs are not distinct"
-    # two prover handles on two contexts, half of the batch each, one host thread each: the host shares of one half (digits, half-GCDs of
-    # the argument's rounds, file encoding) and its latency-bound launches overlap the kernels of the other.  Reported beside `value`.
-    pipelined = None
-    if world == 1 and batch >= 128:
-        import threading
-        from bulletproofspp_amd.capi import Bppp
-        from bulletproofspp_amd import rangeproof as RP
-        ctx2 = Bppp(gpu_device(dev))
-        nat2 = RP.NativeRangeProofs(ctx2, st, h=st.g)
-        half = batch // 2
-        cb, pb = shp["coms_bytes"], shp["proof_bytes"]
+    # the library runs a batch of this size as two half-batches in flight (twin handle on its own context, csrc/rpprove.hip): the host
+    # shares of one half (digits, half-GCDs of the argument's rounds, challenge round trips) fall under the kernels of the other.  The
+    # one-context figure is reported beside `value`; both write the same bytes.
+    single_context = None
+    if world == 1 and batch >= 2048:
         cf2, pf2 = np.zeros_like(cf), np.zeros_like(pf)
-
-        def part(handle, ctx_, lo, hi):
-            ctx_._check(ctx_.lib.bppp_rp_prove_batch(handle.h, hi - lo, vp(amt[lo:hi]), vp(typ[lo:hi]), vp(bld[lo:hi]), vp(pre[lo * plen:hi * plen]), plen,
-                                                       vp(cf2[lo * cb:hi * cb]), vp(pf2[lo * pb:hi * pb])), "bppp_rp_prove_batch")
-
-        def both():
-            th = threading.Thread(target=part, args=(nat2, ctx2, half, batch))
-            th.start()
-            part(nat, gpu, 0, half)
-            th.join()
-        both()                                           # warm-up of the second handle
-        torch.cuda.synchronize()
-        tq0 = time.perf_counter()
-        for _ in range(prove_steps):
-            both()
-        torch.cuda.synchronize()
-        qdt = time.perf_counter() - tq0
-        assert np.array_equal(cf2, cf) and np.array_equal(pf2, pf), "pipelined prover output differs"
-        pipelined = {"handles": 2, "value": batch * prove_steps / qdt, "unit": "proofs/s", "ms_per_batch": qdt / prove_steps * 1e3}
-        nat2.close(); ctx2.close()
+        os.environ["BPPP_RP_NO_SPLIT"] = "1"
+        try:
+            def one():
+                gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bld), vp(pre), plen, vp(cf2), vp(pf2)), "bppp_rp_prove_batch")
+            one()
+            torch.cuda.synchronize()
+            tq0 = time.perf_counter()
+            for _ in range(prove_steps):
+                one()
+            torch.cuda.synchronize()
+            qdt = time.perf_counter() - tq0
+        finally:
+            del os.environ["BPPP_RP_NO_SPLIT"]
+        assert np.array_equal(cf2, cf) and np.array_equal(pf2, pf), "one-context prover output differs"
+        single_context = {"value": batch * prove_steps / qdt, "unit": "proofs/s", "ms_per_batch": qdt / prove_steps * 1e3}
     prove = {"metric": "range_proofs_proved_per_sec", "value": world * batch * prove_steps / pdt, "unit": "proofs/s", "ms_per_batch": pdt / prove_steps * 1e3,
-             "pipelined": pipelined,
+             "half_batches_in_flight": 2 if batch >= 2048 else 1, "single_context": single_context,
              "batch_per_gpu": batch, "replicas": world, "shape": f"{shape}: {count} x 64-bit values per proof, nrmLen {nlen}, linLen {llen}, {k} rounds",
              "scope": "proveM of RangeProof (src/RangeProof.hs:93-97) end to end: host inputs in, the reference's commitments / proof files out; "
                       "commitments, per-proof field algebra, randomness and SHA-256 transcripts on the GPU, digit extraction and the argument's "

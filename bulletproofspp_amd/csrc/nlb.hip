@@ -26,7 +26,7 @@ BPPP_DI void block_sum4(fe v[4], uint32_t *lds) {
   const int t = threadIdx.x;
   for (int k = 0; k < 4; k++) for (int i = 0; i < 8; i++) lds[(t * 4 + k) * 8 + i] = v[k].v[i];
   __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
+  for (int d = (int)blockDim.x >> 1; d >= 1; d >>= 1) {      // blockDim.x is a power of two (64 .. 256)
     if (t < d) {
       for (int k = 0; k < 4; k++) {
         fe x, y;
@@ -50,11 +50,12 @@ __global__ void __launch_bounds__(256) k_nlb_round(const uint32_t *__restrict__ 
   const uint32_t ne = n + (n & 1), np = (n + 1) / 2, lp = (l + 1) / 2;
   const fe q = fe_load(qs + (size_t)b * 16), qinv = fe_load(qs + (size_t)b * 16 + 8);
   fe q2 = fe_sqr<1>(q), q4 = fe_sqr<1>(q2);
-  fe w = frb_pow(q4, t), step = frb_pow(q4, 256);
+  const uint32_t bs = blockDim.x;                  // 64 .. 256: late rounds have a handful of pairs per proof
+  fe w = frb_pow(q4, t), step = frb_pow(q4, bs);
   uint32_t *scX = sc + (size_t)(2 * b) * T * 8, *scR = sc + (size_t)(2 * b + 1) * T * 8;
   const uint32_t *xb = x + (size_t)b * xstride * 8, *lcb = lc + (size_t)b * lstride * 8, *lxb = lx + (size_t)b * lstride * 8;
   fe s[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
-  for (uint32_t j = t; j < np; j += 256) {
+  for (uint32_t j = t; j < np; j += bs) {
     fe xl = fe_load(xb + (size_t)(2 * j) * 8);
     fe xr = (2 * j + 1 < n) ? fe_load(xb + (size_t)(2 * j + 1) * 8) : fe_zero();
     fe wxr = fe_mul<1>(w, xr);
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) k_nlb_round(const uint32_t *__restrict__ 
     fe_store(scR + (size_t)(2 * j + 1) * 8, xr);
     w = fe_mul<1>(w, step);
   }
-  for (uint32_t j = t; j < lp; j += 256) {
+  for (uint32_t j = t; j < lp; j += bs) {
     bool has = 2 * j + 1 < l;
     fe cl = fe_load(lcb + (size_t)(2 * j) * 8), xl = fe_load(lxb + (size_t)(2 * j) * 8);
     fe cr = has ? fe_load(lcb + (size_t)(2 * j + 1) * 8) : fe_zero();
@@ -408,7 +409,9 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
   for (size_t b = 0; b < B; b++) { o->q[b].store(&h[8 * b]); o->qinv[b].store(&h[8 * b + 4]); }
   NLB_HIP(o, hipMemcpyAsync(o->qs, h.data(), B * 64, hipMemcpyHostToDevice, st));
   NLB_HIP(o, hipMemsetAsync(o->sc, 0, 2 * B * T * 32, st));
-  k_nlb_round<<<dim3((unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride, (uint32_t)o->lstride,
+  unsigned round_threads = 64;
+  while (round_threads < 256 && round_threads < std::max((o->n + 1) / 2, (o->l + 1) / 2)) round_threads <<= 1;
+  k_nlb_round<<<dim3((unsigned)B), dim3(round_threads), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride, (uint32_t)o->lstride,
                                                       o->qs, (uint32_t)T, o->sc, o->sums);
   std::vector<uint64_t> sums(B * 16);
   NLB_HIP(o, hipMemcpyAsync(sums.data(), o->sums, B * 128, hipMemcpyDeviceToHost, st));
