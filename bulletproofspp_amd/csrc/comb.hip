@@ -1,0 +1,176 @@
+// comb.hip — fixed-base comb for THOUSANDS of MSMs over ONE short basis (the prover: range-proof commitments and every round of the
+// lockstep argument, 2 x batch instances of ~775 terms each over the setup's [g | H | G]).
+//
+// The reference commits with `innerProduct` over the setup's fixed points (commitRPW, src/RangeProof/Internal.hs:45-50; the argument's
+// round commitments, src/NormArgument.hs:100-128, over a basis that is a known linear image of the setup's).  With the basis fixed
+// per setup and 288 GB of HBM, every multiple a signed c-bit digit can ask for is stored once:
+//     tab[w][i][d - 1] = d * 2^(c w) * P_i          w < W = ceil(257 / c),   d = 1 .. 2^(c-1)
+// (c = 13: 20 x 775 x 4096 entries of 64 B = 4.1 GB), and an MSM is then nothing but one mixed addition per non-zero digit into ONE
+// accumulator: no digit sort, no buckets, no bucket reduction, no window combine, no doubling — 20 additions per term against
+// 29 + sort + reduction on the bucket route at its best window for this shape (csrc/msm.hip, c = 9).
+//
+// k_comb_msm: one wavefront per instance, lane l takes one term of every 64; the table entry of the NEXT digit is requested
+// before the addition of the current one is issued, so the 64-B gathers (random over the table: HBM, not cache) hide under ~2.8 k
+// VALU instructions each.  The 64 lane sums meet in a shuffle tree; lane 0 normalises.  VALU-bound like k_acc_points.
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include "comb.hpp"
+#include "ec.hip.h"
+
+namespace bppp {
+
+struct CombK { uint32_t k[9]; };       // sum_w 2^(c-1) 2^(c w): adding it turns signed digits into unsigned c-bit fields (as k_digits)
+
+// bases[w][i] = 2^(c w) P_i: one lane per point walks the chain (c doublings and one normalisation per window)
+__global__ void __launch_bounds__(64) k_comb_bases(const uint32_t *__restrict__ pts, uint32_t T, int c, int W, uint32_t *__restrict__ bases) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  aff P = aff_load(pts + (size_t)i * 16);
+  aff_store(bases + (size_t)i * 16, P);
+  for (int w = 1; w < W; w++) {
+    xyzz a = xyzz_dbl_aff(P);
+    for (int k = 1; k < c; k++) a = xyzz_dbl(a);
+    P = xyzz_to_aff(a);
+    aff_store(bases + ((size_t)w * T + i) * 16, P);
+  }
+}
+// one lane per (w, i, chunk): the multiples chunk * CH + 1 .. chunk * CH + CH of bases[w][i], each normalised (canonical affine rows)
+__global__ void __launch_bounds__(64) k_comb_multiples(const uint32_t *__restrict__ bases, uint32_t T, int W, uint32_t D, uint32_t CH, uint32_t *__restrict__ tab) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunks = D / CH;
+  if (g >= (uint64_t)W * T * chunks) return;
+  const uint32_t chunk = (uint32_t)(g % chunks);
+  const uint64_t wi = g / chunks;                       // w * T + i
+  const aff B = aff_load(bases + wi * 16);
+  const uint32_t m0 = chunk * CH;
+  xyzz acc = xyzz_inf();
+  for (int b = 31 - __builtin_clz(m0 | 1u); b >= 0 && m0; b--) {      // m0 * B, double and add
+    acc = xyzz_dbl(acc);
+    if ((m0 >> b) & 1u) xyzz_madd(acc, B);
+  }
+  uint32_t *row = tab + (wi * D + m0) * 16;
+  for (uint32_t d = 0; d < CH; d++) { xyzz_madd(acc, B); aff_store(row + (size_t)d * 16, xyzz_to_aff(acc)); }
+}
+
+struct CombRaw { uint4 a, b, c, d; };                  // one 64-B table entry as loaded
+BPPP_DI aff comb_aff(const CombRaw &r, bool neg) {
+  fe x, y;
+  x.v[0] = r.a.x; x.v[1] = r.a.y; x.v[2] = r.a.z; x.v[3] = r.a.w; x.v[4] = r.b.x; x.v[5] = r.b.y; x.v[6] = r.b.z; x.v[7] = r.b.w;
+  y.v[0] = r.c.x; y.v[1] = r.c.y; y.v[2] = r.c.z; y.v[3] = r.c.w; y.v[4] = r.d.x; y.v[5] = r.d.y; y.v[6] = r.d.z; y.v[7] = r.d.w;
+  aff p; p.x = fq_from_fe(x); p.y = fq_from_fe(y);
+  return aff_cneg(p, neg);
+}
+
+// heavy_first: the instances come as (heavy, light) pairs — the prover's X (every scalar non-zero) and R (half of them) — and the
+// launch dispatches all heavy ones first, so the light ones fill the slots that free up instead of leaving a tail of heavy ones
+__global__ void __launch_bounds__(64) k_comb_msm(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
+                                                 const uint32_t *__restrict__ scalars, uint32_t ninst, int heavy_first, uint32_t *__restrict__ out) {
+  const uint32_t lane = threadIdx.x, half = ninst >> 1;
+  const uint32_t inst = !heavy_first ? blockIdx.x : blockIdx.x < half ? 2 * blockIdx.x : 2 * (blockIdx.x - half) + 1;
+  const uint32_t mask = (1u << c) - 1u;
+  const uint32_t *sc = scalars + (size_t)inst * T * 8;
+  xyzz acc = xyzz_inf();
+  CombRaw pend; pend.a = pend.b = pend.c = pend.d = make_uint4(0, 0, 0, 0);
+  bool pend_ok = false, pend_neg = false;
+  // Lane l takes one term of every group of 64, rotated by 21 per group, and walks ITS terms at its own pace: a lane whose term is
+  // zero moves straight on to its next non-zero one instead of idling through the other lanes' 20 digit steps.  With vectors whose
+  // zeros follow a power-of-two pattern in the index (the argument's R scalars vanish on every left half) every lane then has the
+  // same share, and the wavefront of such an instance takes half the steps.
+  uint32_t k0 = 0, k = 0, sp[9];
+  int w = W;                                                   // w == W: this lane needs its next term
+  bool neg = false, live = true;
+  const uint32_t *ti = tab;
+  while (__any(live)) {
+    if (live && w == W) {
+      live = false;
+      while (k0 < T) {
+        const uint32_t i = k0 + ((lane + 21u * k) & 63u);
+        k0 += 64; k++;
+        if (i >= T) continue;
+        const fe s = fe_load(sc + (size_t)i * 8);
+        if (fe_is_zero(s)) continue;
+        fe t, tmp;
+        raw_sub(t, fr_modulus(), s);                           // n - s
+        neg = raw_sub(tmp, t, s) != 0;                         // s > n - s: take n - s and the negated point (reduceScalar, Commitment.hs:276-279)
+        uint64_t cy = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
+        sp[8] = (uint32_t)cy + K.k[8];
+        ti = tab + (size_t)i * D * 16;
+        w = 0; live = true;
+        break;
+      }
+    }
+    CombRaw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_uint4(0, 0, 0, 0);
+    bool ok = false, nneg = false;
+    if (live) {
+      const int d = (int)(sp[0] & mask) - (int)D;              // signed digit in [-D, D - 1]
+#pragma unroll
+      for (int q = 0; q < 8; q++) sp[q] = (sp[q] >> c) | (sp[q + 1] << (32 - c));
+      sp[8] >>= c;
+      ok = d != 0; nneg = (d < 0) != neg;
+      if (ok) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint4 *e = (const uint4 *)(ti + ((size_t)w * T * D + (mag - 1)) * 16);
+        nxt.a = e[0]; nxt.b = e[1]; nxt.c = e[2]; nxt.d = e[3];
+      }
+      w++;
+    }
+    if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));     // the previous digit's entry: its load was issued one step ago
+    pend = nxt; pend_ok = ok; pend_neg = nneg;
+  }
+  if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+  for (int dd = 32; dd >= 1; dd >>= 1) {
+    xyzz o = xyzz_shfl_down(acc, dd);
+    if ((int)lane + dd < 64) xyzz_add(acc, o);
+  }
+  if (lane == 0) aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
+}
+
+void comb_destroy(CombTable *t) {
+  if (!t) return;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  if (t->tab) hipFree(t->tab);
+  ctx_release(t->ctx);
+  delete t;
+}
+
+int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bits, size_t budget_bytes, CombTable **out) {
+  if (!ctx || !d_points || !T || !out || T >= (1u << 24)) return BPPP_ERR_ARG;
+  hipSetDevice(ctx->device);
+  int c = window_bits;
+  auto size_of = [&](int cc) { return (size_t)((257 + cc - 1) / cc) * T * ((size_t)1 << (cc - 1)) * 64; };
+  if (!c) { c = 14; while (c > 4 && size_of(c) > budget_bytes) c--; }
+  if (c < 4 || c > 16) return fail(ctx, BPPP_ERR_ARG, "comb_create: window_bits must be in [4,16]");
+  CombTable *t = new CombTable();
+  t->ctx = ctx; ctx_retain(ctx); t->T = T; t->c = c; t->W = (257 + c - 1) / c; t->D = 1 << (c - 1); t->tab = nullptr; t->bytes = size_of(c);
+  uint32_t *bases = nullptr;
+  hipStream_t st = ctx->stream;
+  auto bail = [&](const std::string &m) { if (bases) hipFree(bases); comb_destroy(t); return fail(ctx, BPPP_ERR_HIP, m); };
+  if (hipMalloc(&t->tab, t->bytes) != hipSuccess) return bail("comb_create: hipMalloc of the table failed (" + std::to_string(t->bytes >> 20) + " MiB)");
+  if (hipMalloc(&bases, (size_t)t->W * T * 64) != hipSuccess) return bail("comb_create: hipMalloc failed");
+  k_comb_bases<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, st>>>(d_points, (uint32_t)T, c, t->W, bases);
+  const uint32_t CH = std::min<uint32_t>(256u, (uint32_t)t->D);
+  const uint64_t lanes = (uint64_t)t->W * T * (t->D / CH);
+  k_comb_multiples<<<dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st>>>(bases, (uint32_t)T, t->W, (uint32_t)t->D, CH, t->tab);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return bail("comb_create: table kernels failed");
+  hipFree(bases);
+  *out = t;
+  return BPPP_OK;
+}
+
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first) {
+  if (!t || !d_scalars || !d_out_aff || ninst >= (1u << 31)) return BPPP_ERR_ARG;
+  if (!ninst) return BPPP_OK;
+  CombK K; memset(&K, 0, sizeof K);
+  for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
+  k_comb_msm<<<dim3((unsigned)ninst), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)ninst,
+                                                         (heavy_first && !(ninst & 1)) ? 1 : 0, d_out_aff);
+  if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_msm: launch failed");
+  return BPPP_OK;
+}
+
+}  // namespace bppp

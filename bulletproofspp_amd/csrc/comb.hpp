@@ -1,0 +1,26 @@
+// comb.hpp — fixed-base comb over a setup's basis: every signed c-bit digit of a scalar is ONE table addition (csrc/comb.hip).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "ctx.hpp"
+
+namespace bppp {
+
+struct CombTable {
+  bppp_ctx *ctx;
+  size_t T;            // registered points
+  int c, W, D;         // window bits, windows (c * W >= 257), multiples per window D = 2^(c-1)
+  uint32_t *tab;       // [W][T][D] affine (16 u32 each): tab[w][i][d - 1] = d * 2^(c w) * P_i
+  size_t bytes;
+};
+
+// d_points: T affine points in HBM (copied into the table; the caller keeps ownership of the array).  window_bits = 0: chosen so
+// that the table stays under `budget_bytes`.
+int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bits, size_t budget_bytes, CombTable **out);
+void comb_destroy(CombTable *t);
+// out[inst] = sum_i scalars[inst][i] * P_i for inst < ninst (canonical affine, infinity = zeros); scalars are canonical (< n),
+// [ninst][T] in HBM.  Asynchronous on `st`.  heavy_first: instances 2b / 2b + 1 are a heavy / light pair (dispatch order only).
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first = false);
+
+}  // namespace bppp

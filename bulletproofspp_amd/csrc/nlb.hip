@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
+#include "comb.hpp"
 #include "foldcore.hip.h"
 #include "hostmath.hpp"
 
@@ -91,11 +92,6 @@ struct CollapseK {
   uint32_t cu[8], cv[8];                 // linear c' = cu cL + cv cR
   uint32_t lu[8], lv[8];                 // linear x' = lu xL + lv xR
 };
-struct NlbShared;
-void nlb_shared_destroy(NlbShared *);
-#define NLB_FW 17          // signed 8-bit windows of a reduced fold coefficient (<= 130 bits)
-#define NLB_FD 128         // table multiples per window
-struct FoldDigits { int16_t nb[NLB_FW], na[NLB_FW], lb[NLB_FW], la[NLB_FW]; };
 BPPP_DI fe fe_of8(const uint32_t *p) { fe r; for (int i = 0; i < 8; i++) r.v[i] = p[i]; return r; }
 
 __global__ void __launch_bounds__(256) k_nlb_fold_scalars(const uint32_t *__restrict__ x, const uint32_t *__restrict__ lc, const uint32_t *__restrict__ lx,
@@ -152,63 +148,53 @@ __global__ void k_nlb_move_g(const uint32_t *__restrict__ P, uint32_t cap, uint3
   if (t < 16) Po[((size_t)b * cap_out + dst_off) * 16 + t] = P[((size_t)b * cap + src_off) * 16 + t];
 }
 
-// ---- fixed-base tables over the STARTING basis (round 1 only: every proof still has the setup's points)
-// Fold: after rationalReduceScalar the two coefficients are <= 130 bits, i.e. 17 signed 8-bit digits each; with
-//     tab[w][i][d - 1] = d * 2^(8 w) * P_i       d = 1 .. 128
-// a folded point is at most 34 table additions (no doublings) against 128 doublings + ~64 additions of the joint-sparse-form
-// walk.  One lane per (w, i) builds a row: the chain to 2^(8w) P_i, then 128 running multiples, each normalised.
-__global__ void __launch_bounds__(64) k_nlb_foldtab(const uint32_t *__restrict__ pts, uint32_t cap, uint32_t *__restrict__ tab) {
-  const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= cap * (uint32_t)NLB_FW) return;
-  const uint32_t w = g / cap, i = g % cap;               // w-major: the lanes of a wavefront run the same number of doublings
-  aff P = aff_load(pts + (size_t)i * 16);
-  if (w) {
-    xyzz a = xyzz_dbl_aff(P);
-    for (uint32_t k = 1; k < 8 * w; k++) a = xyzz_dbl(a);
-    P = xyzz_to_aff(a);
+// ---- fixed-basis mode (a comb table over the setup's [g | H | G] is attached, csrc/comb.hip): the points are NEVER folded.
+// After r folds the basis point at level position p is  G^(r)_p = sum_{i >> r == p} coef_i G_i  with coef_i the product of the
+// fold coefficients of the halves index i fell into (left: 1, right: a = e q^-1 for the norm part, a = e for the linear part —
+// the unscaled fold, i.e. (a, b) = (x, 1) where the point-folding route uses the reduced fraction of rationalReduceScalar), so a
+// round commitment  sum_p sc_p G^(r)_p  is the MSM over the ORIGINAL points with scalars sc_(i >> r) coef_i: one comb MSM per
+// round, no point fold, no half-GCD.  The same group elements X, R (hence the same proof bytes) as the folding route.
+// full[inst][0] = g's scalar, [1 .. l0] = linear part, [1 + l0 ..] = norm part (the comb table's order)
+__global__ void __launch_bounds__(256) k_nlb_expand(const uint32_t *__restrict__ sc, uint32_t Tr, uint32_t ne_r, uint32_t r, const uint32_t *__restrict__ coefn,
+                                                    const uint32_t *__restrict__ coefl, uint32_t n0, uint32_t l0, uint32_t *__restrict__ full) {
+  const uint32_t inst = blockIdx.y, b = inst >> 1, pos = blockIdx.x * 256 + threadIdx.x, Tc = 1 + l0 + n0;
+  if (pos >= Tc) return;
+  const uint32_t *row = sc + (size_t)inst * Tr * 8;
+  fe v;
+  if (pos == 0) v = fe_load(row + (size_t)(Tr - 1) * 8);
+  else if (pos <= l0) {
+    const uint32_t i = pos - 1;
+    v = fe_load(row + (size_t)(ne_r + (i >> r)) * 8);
+    if (r && !fe_is_zero(v)) v = fe_mul<1>(v, fe_load(coefl + ((size_t)b * l0 + i) * 8));
+  } else {
+    const uint32_t i = pos - 1 - l0;
+    v = fe_load(row + (size_t)(i >> r) * 8);
+    if (r && !fe_is_zero(v)) v = fe_mul<1>(v, fe_load(coefn + ((size_t)b * n0 + i) * 8));
   }
-  uint32_t *row = tab + ((size_t)w * cap + i) * NLB_FD * 16;
-  xyzz acc = xyzz_inf();
-  for (int d = 1; d <= NLB_FD; d++) { xyzz_madd(acc, P); aff_store(row + (size_t)(d - 1) * 16, xyzz_to_aff(acc)); }
+  fe_store(full + ((size_t)inst * Tc + pos) * 8, v);
 }
-// the round-1 fold through the table; same lane <-> folded point mapping and output layout as k_nlb_fold_points
-__global__ void __launch_bounds__(64) k_nlb_fold_points_tab(const uint32_t *__restrict__ tab, uint32_t n, uint32_t l, uint32_t cap, uint32_t cap_out,
-                                                            const FoldDigits *__restrict__ D, uint32_t batch, uint32_t *__restrict__ Po) {
-  const uint32_t n2 = (n + 1) / 2, l2 = (l + 1) / 2, pp = n2 + l2;
-  const uint64_t g = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (g >= (uint64_t)batch * pp) return;
-  const uint32_t b = (uint32_t)(g / pp), r = (uint32_t)(g % pp);
-  const bool lin = r >= n2;
-  const uint32_t cnt = lin ? l : n, j = lin ? r - n2 : r;
-  const uint32_t ne = n + (n & 1), ne2 = n2 + (n2 & 1);
-  const uint32_t i0 = (lin ? ne : 0) + 2 * j;
-  const bool has = 2 * j + 1 < cnt;
-  const int16_t *db = lin ? D[b].lb : D[b].nb, *da = lin ? D[b].la : D[b].na;
-  xyzz acc = xyzz_inf();
-  for (int w = 0; w < NLB_FW; w++) {
-    const int d0 = db[w], d1 = has ? da[w] : 0;
-    const uint32_t *row = tab + ((size_t)w * cap + i0) * NLB_FD * 16;
-    if (d0) xyzz_madd(acc, aff_cneg(aff_load(row + (size_t)((d0 < 0 ? -d0 : d0) - 1) * 16), d0 < 0));
-    if (d1) xyzz_madd(acc, aff_cneg(aff_load(row + (size_t)(NLB_FD + (d1 < 0 ? -d1 : d1) - 1) * 16), d1 < 0));
+// coef_i *= a for the indices that are RIGHT halves at fold r; A[b] = (a_norm, a_lin)
+__global__ void __launch_bounds__(256) k_nlb_coef_update(uint32_t *__restrict__ coefn, uint32_t *__restrict__ coefl, uint32_t n0, uint32_t l0, uint32_t r,
+                                                         const uint32_t *__restrict__ A) {
+  const uint32_t b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n0 && ((i >> r) & 1u)) {
+    uint32_t *c = coefn + ((size_t)b * n0 + i) * 8;
+    fe_store(c, fe_mul<1>(fe_load(c), fe_load(A + (size_t)b * 16)));
   }
-  aff_store(Po + ((size_t)b * cap_out + (lin ? ne2 : 0) + j) * 16, xyzz_to_aff(acc));
+  if (i < l0 && ((i >> r) & 1u)) {
+    uint32_t *c = coefl + ((size_t)b * l0 + i) * 8;
+    fe_store(c, fe_mul<1>(fe_load(c), fe_load(A + (size_t)b * 16 + 8)));
+  }
+}
+__global__ void __launch_bounds__(256) k_nlb_fill_one(uint32_t *__restrict__ v, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) fe_store(v + i * 8, fe_one());
 }
 }  // namespace bppp
 
 using namespace bppp;
 using namespace bppp_host;
 
-// signed 8-bit digits of a <= 130-bit magnitude, the sign of the coefficient folded in
-static void fold_digits8(const uint64_t m[3], bool neg, int16_t out[NLB_FW]) {
-  int carry = 0;
-  for (int w = 0; w < NLB_FW; w++) {
-    const int bit = 8 * w;
-    int u = (int)((m[bit >> 6] >> (bit & 63)) & 0xFF) + carry;      // 8 | 64: a digit never straddles limbs
-    carry = 0;
-    if (u > NLB_FD) { u -= 256; carry = 1; }
-    out[w] = (int16_t)(neg ? -u : u);
-  }
-}
 
 // per-proof host arithmetic of a round (two half-GCDs and a few Fr products each) spread over the host cores: at B in the
 // thousands it is otherwise as long as the round's GPU work
@@ -227,9 +213,9 @@ struct bppp_nlb {
   uint32_t *x[2], *lx[2], *lc[2], *P[2];
   uint32_t *sc, *sums, *qs;
   CollapseK *dK;
-  FoldDigits *dD;
-  const bppp::NlbShared *sh;   // fixed-base tables over the starting basis (round 1), or null
-  bppp::NlbShared *own;        // ... when this handle built them itself
+  const bppp::CombTable *comb; // fixed-basis mode: comb over [g | lin | norm]; the points are never folded (P[] is not allocated)
+  uint32_t *coefn, *coefl, *full, *dA, *d_out;
+  uint32_t folds;              // completed folds (the level shift of an original index)
   int cur;
   std::vector<U256> q, qinv, nn, ln, s, sX, sR;
 };
@@ -248,8 +234,8 @@ void bppp_nlb_destroy(bppp_nlb *o) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(o->x[k]); hipFree(o->lx[k]); hipFree(o->lc[k]); hipFree(o->P[k]); }
-  hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK); hipFree(o->dD);
-  if (o->own) bppp::nlb_shared_destroy(o->own);
+  hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK);
+  hipFree(o->coefn); hipFree(o->coefl); hipFree(o->full); hipFree(o->dA); hipFree(o->d_out);
   delete o;
   ctx_release(ctx);
 }
@@ -266,60 +252,13 @@ __global__ void __launch_bounds__(256) k_nlb_broadcast(const uint4 *__restrict__
   for (uint32_t b = blockIdx.y; b < batch; b += gridDim.y) dst[(size_t)b * words4 + i] = v;
 }
 }  // namespace bppp
-extern "C" {
-int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, int window_bits, size_t batch_hint, bppp_basis **out);
-void bppp_basis_destroy(bppp_basis *basis);
-int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, size_t batch, uint64_t *out_xy);
-}
-namespace bppp {
-// Fixed-base tables over the starting basis [norm | lin | g] of a setup, shared by every batch proved over it (csrc/rpprove_dev.hip
-// keeps one per range-proof handle): the round-1 commitments X, R become MSMs over a registered basis (one bucket set per instance,
-// csrc/basis.hip) and the round-1 fold reads multiples out of `foldtab`.  Later rounds work on per-proof folded points.
-struct NlbShared {
-  bppp_ctx *ctx;
-  size_t cap, nlen, llen;
-  bppp_basis *flat;
-  uint32_t *foldtab;       // [NLB_FW][cap][NLB_FD] affine, or null when it would not fit the budget below
-};
-void nlb_shared_destroy(NlbShared *sh) {
-  if (!sh) return;
-  hipSetDevice(sh->ctx->device);
-  hipStreamSynchronize(sh->ctx->stream);
-  if (sh->flat) bppp_basis_destroy(sh->flat);
-  if (sh->foldtab) hipFree(sh->foldtab);
-  ctx_release(sh->ctx);
-  delete sh;
-}
-// from a prover that has not run a round yet: the basis copy of its proof 0
-int nlb_shared_create(bppp_nlb *o, size_t batch_hint, NlbShared **out) {
-  if (!o || !out || o->n != o->n0 || o->l != o->l0 || o->cur != 0) return BPPP_ERR_ARG;
-  bppp_ctx *ctx = o->ctx;
-  hipSetDevice(ctx->device);
-  NlbShared *sh = new NlbShared();
-  sh->ctx = ctx; ctx_retain(ctx); sh->cap = o->cap; sh->nlen = o->n0; sh->llen = o->l0; sh->flat = nullptr; sh->foldtab = nullptr;
-  int rc = bppp_basis_create_device(ctx, o->P[0], o->cap, 0, batch_hint ? batch_hint : 2 * o->batch, &sh->flat);
-  if (rc) { nlb_shared_destroy(sh); return rc; }
-  const size_t bytes = (size_t)NLB_FW * o->cap * NLB_FD * 64;
-  if (bytes <= ((size_t)8 << 30) && !getenv("BPPP_NLB_NO_FOLDTAB")) {
-    if (hipMalloc(&sh->foldtab, bytes) != hipSuccess) { nlb_shared_destroy(sh); return fail(ctx, BPPP_ERR_HIP, "nlb: hipMalloc of the fold table failed"); }
-    const uint32_t lanes = (uint32_t)(o->cap * NLB_FW);
-    k_nlb_foldtab<<<dim3((lanes + 63) / 64), dim3(64), 0, ctx->stream>>>(o->P[0], (uint32_t)o->cap, sh->foldtab);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { nlb_shared_destroy(sh); return fail(ctx, BPPP_ERR_HIP, "nlb: fold table kernel failed"); }
-  }
-  *out = sh;
-  return BPPP_OK;
-}
-// `sh` must outlive the prover's first round and match its lengths; a mismatch is ignored (the general route runs)
-void nlb_set_shared(bppp_nlb *o, const NlbShared *sh) {
-  if (o && sh && sh->cap == o->cap && sh->nlen == o->n0 && sh->llen == o->l0 && sh->ctx == o->ctx) o->sh = sh;
-}
-}  // namespace bppp
 namespace bppp {
 // on_device: every array argument (scalars AND basis points) is already resident in HBM (the batch range-proof prover builds the
 // start state of the argument on the device, csrc/rpprove_dev.hip); otherwise they are host arrays (the C ABI entry point)
 int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t *g_xy, const uint64_t *q, const uint64_t *norm_x,
                     const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
-                    bppp_nlb **out, bool on_device) {
+                    bppp_nlb **out, bool on_device, const CombTable *comb) {
+  if (comb && comb->T != 1 + llen + nlen) comb = nullptr;        // not this basis: the general route
   const hipMemcpyKind KIND = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (!ctx || !out || !s || !g_xy || !q || !batch || ctx_closed(ctx)) return BPPP_ERR_ARG;
   if ((nlen && (!norm_x || !norm_g_xy)) || (llen && (!lin_c || !lin_x || !lin_h_xy)) || nlen + llen == 0 || nlen >= (1u << 24) || llen >= (1u << 24) ||
@@ -331,19 +270,24 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   o->ctx = ctx; ctx_retain(ctx); o->batch = batch; o->n = o->n0 = nlen; o->l = o->l0 = llen; o->cur = 0;
   o->cap = evb(nlen) + evb(llen) + 1; o->xstride = evb(nlen) + 2; o->lstride = evb(llen) + 2;
   for (int k = 0; k < 2; k++) { o->x[k] = o->lx[k] = o->lc[k] = o->P[k] = nullptr; }
-  o->sc = o->sums = o->qs = nullptr; o->dK = nullptr; o->dD = nullptr; o->sh = nullptr; o->own = nullptr;
+  o->sc = o->sums = o->qs = nullptr; o->dK = nullptr;
+  o->comb = comb; o->coefn = o->coefl = o->full = o->dA = o->d_out = nullptr; o->folds = 0;
   bool bad = false;
   for (int k = 0; k < 2; k++) {
     bad |= hipMalloc(&o->x[k], batch * o->xstride * 32) != hipSuccess || hipMalloc(&o->lx[k], batch * o->lstride * 32) != hipSuccess;
-    bad |= hipMalloc(&o->lc[k], batch * o->lstride * 32) != hipSuccess || hipMalloc(&o->P[k], batch * o->cap * 64) != hipSuccess;
+    bad |= hipMalloc(&o->lc[k], batch * o->lstride * 32) != hipSuccess || (!comb && hipMalloc(&o->P[k], batch * o->cap * 64) != hipSuccess);
   }
   bad |= hipMalloc(&o->sc, 2 * batch * o->cap * 32) != hipSuccess || hipMalloc(&o->sums, batch * 4 * 32) != hipSuccess;
   bad |= hipMalloc(&o->qs, batch * 64) != hipSuccess || hipMalloc(&o->dK, batch * sizeof(CollapseK)) != hipSuccess;
-  bad |= hipMalloc(&o->dD, batch * sizeof(FoldDigits)) != hipSuccess;
+  if (comb) {
+    const size_t Tc = 1 + llen + nlen;
+    bad |= hipMalloc(&o->coefn, batch * std::max<size_t>(nlen, 1) * 32) != hipSuccess || hipMalloc(&o->coefl, batch * std::max<size_t>(llen, 1) * 32) != hipSuccess;
+    bad |= hipMalloc(&o->full, 2 * batch * Tc * 32) != hipSuccess || hipMalloc(&o->dA, batch * 64) != hipSuccess || hipMalloc(&o->d_out, 2 * batch * 64) != hipSuccess;
+  }
   if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
   hipStream_t st = ctx->stream;
   auto fill = [&]() -> int {                 // any failure below goes through ONE cleanup: the handle is destroyed
-  NLB_HIP(o, hipMemsetAsync(o->P[0], 0, batch * o->cap * 64, st));
+  if (!comb) NLB_HIP(o, hipMemsetAsync(o->P[0], 0, batch * o->cap * 64, st));
   NLB_HIP(o, hipMemsetAsync(o->x[0], 0, batch * o->xstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lx[0], 0, batch * o->lstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lc[0], 0, batch * o->lstride * 32, st));
@@ -352,6 +296,11 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
     NLB_HIP(o, hipMemcpy2DAsync(o->lc[0], o->lstride * 32, lin_c, llen * 32, llen * 32, batch, KIND, st));
     NLB_HIP(o, hipMemcpy2DAsync(o->lx[0], o->lstride * 32, lin_x, llen * 32, llen * 32, batch, KIND, st));
   }
+  if (comb) {
+    const uint64_t cn = (uint64_t)batch * nlen, cl = (uint64_t)batch * llen;
+    if (cn) k_nlb_fill_one<<<dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st>>>(o->coefn, cn);
+    if (cl) k_nlb_fill_one<<<dim3((unsigned)((cl + 255) / 256)), dim3(256), 0, st>>>(o->coefl, cl);
+  } else
   {   // the shared starting basis: uploaded once (staged in the not-yet-used second buffer), then one copy per proof (they diverge after round 1)
     uint32_t *stg = o->P[1];
     NLB_HIP(o, hipMemsetAsync(stg, 0, o->cap * 64, st));
@@ -386,7 +335,7 @@ extern "C" {
 int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x,
                     const uint64_t *norm_g_xy, size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen,
                     bppp_nlb **out) {
-  return nlb_create_impl(ctx, batch, s, g_xy, q, norm_x, norm_g_xy, nlen, lin_c, lin_x, lin_h_xy, llen, out, false);
+  return nlb_create_impl(ctx, batch, s, g_xy, q, norm_x, norm_g_xy, nlen, lin_c, lin_x, lin_h_xy, llen, out, false, nullptr);
 }
 
 int bppp_nlb_lengths(const bppp_nlb *o, size_t *batch, size_t *nlen, size_t *llen) {
@@ -429,9 +378,19 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
   // the scalar on g is the last term of each instance: instance 2b (X) and 2b+1 (R)
   NLB_HIP(o, hipMemcpy2DAsync(o->sc + (T - 1) * 8, T * 32, tails.data(), 32, 32, 2 * B, hipMemcpyHostToDevice, st));
   std::vector<uint64_t> outs(2 * B * 8);
-  const bool first = o->sh && o->cur == 0 && o->n == o->n0 && o->l == o->l0;
-  int rc = first && !getenv("BPPP_NLB_NO_FLAT") ? bppp_msm_basis(o->sh->flat, o->sc, T, 2 * B, outs.data())   // every proof still has the setup's basis
-                 : msm_run(ctx, o->sc, o->P[c], T, 2 * B, 2, 0, outs.data());     // X and R of a proof share that proof's basis
+  if (o->comb) {
+    const uint32_t Tc = (uint32_t)(1 + o->l0 + o->n0);
+    k_nlb_expand<<<dim3((Tc + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds, o->coefn, o->coefl, (uint32_t)o->n0,
+                                                                                  (uint32_t)o->l0, o->full);
+    NLB_HIP(o, hipGetLastError());
+    int rcc = comb_msm(o->comb, o->full, 2 * B, o->d_out, st, true);
+    if (rcc) return fail(ctx, rcc, bppp_last_error(o->comb->ctx));
+    NLB_HIP(o, hipMemcpyAsync(outs.data(), o->d_out, 2 * B * 64, hipMemcpyDeviceToHost, st));
+    NLB_HIP(o, hipStreamSynchronize(st));
+    for (size_t b = 0; b < B; b++) { memcpy(X_xy + 8 * b, &outs[16 * b], 64); memcpy(R_xy + 8 * b, &outs[16 * b + 8], 64); }
+    return BPPP_OK;
+  }
+  int rc = msm_run(ctx, o->sc, o->P[c], T, 2 * B, 2, 0, outs.data());   // X and R of a proof share that proof's basis
   if (rc) return rc;
   for (size_t b = 0; b < B; b++) { memcpy(X_xy + 8 * b, &outs[16 * b], 64); memcpy(R_xy + 8 * b, &outs[16 * b + 8], 64); }
   return BPPP_OK;
@@ -449,8 +408,6 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   const size_t ne = evb(o->n), le = evb(o->l), n2 = (o->n + 1) / 2, l2 = (o->l + 1) / 2, ne2 = evb(n2), le2 = evb(l2);
   hipStream_t st = ctx->stream;
   std::vector<CollapseK> K(B);
-  const bool tabfold = o->sh && o->sh->foldtab && o->cur == 0 && o->n == o->n0 && o->l == o->l0;
-  std::vector<FoldDigits> FD(tabfold ? B : 0);
   auto put8 = [](uint32_t *dst, const U256 &v) { for (int i = 0; i < 8; i++) dst[i] = (uint32_t)(v.w[i / 2] >> (32 * (i & 1))); };
   std::vector<U256> inv(2 * B, U256::zero()), a0l(B), b0n(B), b0l(B);
   // the advanced host state is built beside the current one and committed only after the device work has been issued and has
@@ -458,6 +415,42 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   std::vector<U256> s_new(o->s), nn_new(o->nn), q_new(o->q), qinv_new(o->qinv), ln_new(o->ln);
   for (size_t b = 0; b < B; b++)
     if (cmp(U256::load(es + 4 * b), M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
+  if (o->comb) {
+    // fixed-basis mode: the unscaled fold (a, b) = (x, 1) — no half-GCD, no point fold; the basis coefficients take the factor a
+    std::vector<uint32_t> A(B * 16, 0);
+    parallel_ranges(B, [&](size_t lo, size_t hi) {
+     for (size_t b = lo; b < hi; b++) {
+      const U256 e = U256::load(es + 4 * b);
+      U256 e1 = msub(mmul(e, e, M), U256::one(), M);
+      s_new[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
+      memset(&K[b], 0, sizeof(CollapseK));
+      if (o->n) {
+        put8(K[b].nu, U256::one()); put8(K[b].nv, mmul(e, o->q[b], M));
+        put8(&A[16 * b], mmul(e, o->qinv[b], M));
+        nn_new[b] = mmul(o->nn[b], o->qinv[b], M);
+        q_new[b] = mmul(o->q[b], o->q[b], M); qinv_new[b] = mmul(o->qinv[b], o->qinv[b], M);
+      }
+      if (o->l) {
+        put8(K[b].cu, U256::one()); put8(K[b].cv, e); put8(K[b].lu, U256::one()); put8(K[b].lv, e);
+        put8(&A[16 * b + 8], e);
+      }
+     }
+    });
+    NLB_HIP(o, hipMemcpyAsync(o->dK, K.data(), B * sizeof(CollapseK), hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemcpyAsync(o->dA, A.data(), B * 64, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemsetAsync(o->x[d], 0, B * o->xstride * 32, st));
+    NLB_HIP(o, hipMemsetAsync(o->lx[d], 0, B * o->lstride * 32, st));
+    NLB_HIP(o, hipMemsetAsync(o->lc[d], 0, B * o->lstride * 32, st));
+    const uint32_t maxp = (uint32_t)std::max(n2, l2), maxc = (uint32_t)std::max(o->n0, o->l0);
+    if (maxp) k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l,
+                                                                                             (uint32_t)o->xstride, (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
+    k_nlb_coef_update<<<dim3((maxc + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->coefn, o->coefl, (uint32_t)(o->n ? o->n0 : 0), (uint32_t)(o->l ? o->l0 : 0), o->folds, o->dA);
+    NLB_HIP(o, hipGetLastError());
+    NLB_HIP(o, hipStreamSynchronize(st));
+    o->s.swap(s_new); o->nn.swap(nn_new); o->q.swap(q_new); o->qinv.swap(qinv_new); o->ln.swap(ln_new);
+    o->n = o->n ? n2 : 0; o->l = o->l ? l2 : 0; o->cur = d; o->folds++;
+    return BPPP_OK;
+  }
   std::atomic<int> too_big{0};
   parallel_ranges(B, [&](size_t lo, size_t hi) {
    for (size_t b = lo; b < hi; b++) {
@@ -470,14 +463,12 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
       if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) too_big = 1;
       b0n[b] = extract_scalar(ab.second); inv[2 * b] = b0n[b];
       jsf_recode(ab.second.m, ab.first.m, K[b].dn); K[b].nbneg = ab.second.neg; K[b].naneg = ab.first.neg;
-      if (tabfold) { fold_digits8(ab.second.m, ab.second.neg, FD[b].nb); fold_digits8(ab.first.m, ab.first.neg, FD[b].na); }
     }
     if (o->l) {
       auto ab = rational_reduce_scalar(e);
       if ((ab.first.m[2] >> 1) || (ab.second.m[2] >> 1) || ab.first.m[3] || ab.second.m[3]) too_big = 1;
       a0l[b] = extract_scalar(ab.first); b0l[b] = extract_scalar(ab.second); inv[2 * b + 1] = b0l[b];
       jsf_recode(ab.second.m, ab.first.m, K[b].dl); K[b].lbneg = ab.second.neg; K[b].laneg = ab.first.neg;
-      if (tabfold) { fold_digits8(ab.second.m, ab.second.neg, FD[b].lb); fold_digits8(ab.first.m, ab.first.neg, FD[b].la); }
     }
    }
    batch_minv(inv.data() + 2 * lo, 2 * (hi - lo), M);              // every b0^-1 of the range with ONE field inversion
@@ -505,11 +496,6 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
     k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride,
                                                                                    (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
     const uint64_t pairs = (uint64_t)B * (n2 + l2);
-    if (tabfold) {
-      NLB_HIP(o, hipMemcpyAsync(o->dD, FD.data(), B * sizeof(FoldDigits), hipMemcpyHostToDevice, st));
-      k_nlb_fold_points_tab<<<dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st>>>(o->sh->foldtab, (uint32_t)o->n, (uint32_t)o->l, (uint32_t)(ne + le + 1),
-                                                                                      (uint32_t)(ne2 + le2 + 1), o->dD, (uint32_t)B, o->P[d]);
-    } else
     k_nlb_fold_points<<<dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st>>>(o->P[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)(ne + le + 1),
                                                                                 (uint32_t)(ne2 + le2 + 1), o->dK, (uint32_t)B, o->P[d]);
   }

@@ -54,7 +54,7 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
 }
 
 
-namespace bppp { struct NlbShared; void nlb_shared_destroy(NlbShared *); }
+namespace bppp { struct CombTable; void comb_destroy(CombTable *); }
 struct bppp_rp {
   bppp_ctx *ctx = nullptr;
   bppp_rps::Setup st;
@@ -78,10 +78,14 @@ struct bppp_rp {
   // runs as two half-batches in flight, the host shares of one under the kernels of the other (csrc/rpprove.hip)
   std::vector<bppp_rp_range> c_ranges; std::vector<bppp_rp_public> c_pubs; std::vector<uint64_t> c_points; int c_has_types = 0;
   bppp_rp *twin = nullptr; bppp_ctx *twin_ctx = nullptr; bool is_twin = false;
-  bppp::NlbShared *nlb_shared = nullptr; size_t nlb_shared_batch = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
+  // fixed-base comb over [g | H | G] (csrc/comb.hip): the range-proof commitments and the argument's round commitments of large
+  // batches; the twin handle uses its parent's table
+  bppp::CombTable *comb = nullptr; bool comb_owned = false;
+  uint32_t *d_comb_out = nullptr; size_t comb_out_rows = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
   void *work = nullptr; size_t work_bytes = 0;
   void *stage = nullptr; size_t stage_bytes = 0;
 };
 
 int rp_ensure_twin(bppp_rp *rp);      // csrc/rp.hip
+int rp_ensure_comb(bppp_rp *rp);      // csrc/rpprove.hip

@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 #include "ec.hip.h"
+#include "comb.hpp"
 #include "rp_internal.hpp"
 #include "rpprove_dev.hpp"
 #include "sha256.hip.h"
@@ -495,9 +496,33 @@ int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *
   return BPPP_OK;
 }
 int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t *host_out) {
-  return bppp_msm_basis(rp->commit_basis, d_rows, 1 + rp->st.llen + rp->st.nlen, nrows, host_out);
+  if (!rp->comb) return bppp_msm_basis(rp->commit_basis, d_rows, 1 + rp->st.llen + rp->st.nlen, nrows, host_out);
+  bppp_ctx *ctx = rp->ctx;
+  if (nrows > rp->comb_out_rows) {
+    BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rp->d_comb_out) BPPP_HIP(ctx, hipFree(rp->d_comb_out));
+    rp->d_comb_out = nullptr; rp->comb_out_rows = 0;
+    BPPP_HIP(ctx, hipMalloc(&rp->d_comb_out, nrows * 64));
+    rp->comb_out_rows = nrows;
+  }
+  int rc = comb_msm(rp->comb, d_rows, nrows, rp->d_comb_out, ctx->stream);
+  if (rc) return fail(ctx, rc, bppp_last_error(rp->comb->ctx));
+  BPPP_HIP(ctx, hipMemcpyAsync(host_out, rp->d_comb_out, nrows * 64, hipMemcpyDeviceToHost, ctx->stream));
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BPPP_OK;
 }
 }  // namespace bppp
+
+// the comb table of the setup's basis, built at the first large batch (4 GB at 775 points; BPPP_RP_COMB_BITS / BPPP_RP_NO_COMB)
+int rp_ensure_comb(bppp_rp *rp) {
+  if (rp->comb || getenv("BPPP_RP_NO_COMB")) return BPPP_OK;
+  int c = 0;
+  if (const char *e = getenv("BPPP_RP_COMB_BITS")) c = atoi(e);
+  int rc = bppp::comb_create(rp->ctx, rp->d_basis, 1 + rp->st.llen + rp->st.nlen, c, (size_t)16 << 30, &rp->comb);
+  if (rc) { rp->comb = nullptr; return rc; }
+  rp->comb_owned = true;
+  return BPPP_OK;
+}
 
 static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
                             size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base);
@@ -541,9 +566,13 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).
   size_t split_min = 2048;
   if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
+  size_t comb_min = 256;
+  if (const char *e = getenv("BPPP_RP_COMB_MIN")) comb_min = (size_t)atol(e);
+  if (batch >= comb_min && !rp->is_twin) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
   if (batch < split_min || batch < 2 || rp->is_twin || getenv("BPPP_RP_NO_SPLIT"))
     return prove_batch_one(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
   { int rc = rp_ensure_twin(rp); if (rc) return rc; }
+  if (rp->comb && !rp->twin->comb) rp->twin->comb = rp->comb;      // not owned by the twin
   const size_t nr = rp->st.rds.size(), B0 = (batch + 1) / 2, B1 = batch - B0;
   int rc1 = BPPP_OK;
   std::thread second([&] {

@@ -539,20 +539,8 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   // ---- proveBPM in lockstep (src/Bulletproof.hs:357-359), the start state taken where it lies in HBM
   bppp_nlb *nlb = nullptr;
   rc = nlb_create_impl(ctx, B, (const uint64_t *)a_s, (const uint64_t *)rp->d_g(), (const uint64_t *)a_q, (const uint64_t *)a_nx, (const uint64_t *)rp->d_G(), nlen,
-                       (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true);
+                       (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, getenv("BPPP_NLB_FOLD_POINTS") ? nullptr : rp->comb);
   if (rc) return rc;
-  // the first round runs over the setup's own basis: fixed-base tables, built once per handle (again if the batch size class changes)
-  size_t shared_min = 256;
-  if (const char *e = getenv("BPPP_NLB_SHARED_MIN")) shared_min = (size_t)atol(e);          // tests force the table route on small batches
-  if (B >= shared_min && !getenv("BPPP_NLB_NO_SHARED")) {
-    if (rp->nlb_shared && (B > 4 * rp->nlb_shared_batch || 4 * B < rp->nlb_shared_batch)) { nlb_shared_destroy(rp->nlb_shared); rp->nlb_shared = nullptr; }
-    if (!rp->nlb_shared) {
-      rc = nlb_shared_create(nlb, 2 * B, &rp->nlb_shared);
-      if (rc) { bppp_nlb_destroy(nlb); return rc; }
-      rp->nlb_shared_batch = B;
-    }
-    nlb_set_shared(nlb, rp->nlb_shared);
-  }
   std::vector<uint64_t> sX(B * 4), sR(B * 4), X(B * 8), R(B * 8), eh(B * 4), xr(B * 16);
   for (size_t round = 0; round < k && !rc; round++) {
     rc = bppp_nlb_round_commit(nlb, sX.data(), X.data(), sR.data(), R.data());

@@ -31,12 +31,8 @@ int rpp_ensure_pwork(bppp_rp *rp, size_t bytes);
 int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *d_out);                 // asynchronous on the context's stream
 int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t *host_out);              // synchronises the stream
 int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t *g_xy, const uint64_t *q, const uint64_t *norm_x, const uint64_t *norm_g_xy,
-                    size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out, bool on_device);
-
-struct NlbShared;
-int nlb_shared_create(bppp_nlb *o, size_t batch_hint, NlbShared **out);
-void nlb_shared_destroy(NlbShared *sh);
-void nlb_set_shared(bppp_nlb *o, const NlbShared *sh);
+                    size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out, bool on_device,
+                    const struct CombTable *comb);
 
 }  // namespace bppp
 

@@ -121,14 +121,21 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
         assert nat.prove_batch(inputs, prefixes) == got
     finally:
         del os.environ["BPPP_RP_HOST_ALGEBRA"]
-    # the fixed-base route of the argument's first round (round-1 commitments over the registered basis, round-1 fold out of the
-    # multiples table, csrc/nlb.hip: large batches take it by default) writes the same bytes as well
-    os.environ["BPPP_NLB_SHARED_MIN"] = "1"
+    # the fixed-basis route (large batches take it by default: a comb table over the setup's [g | H | G], csrc/comb.hip — the
+    # range-proof commitments and EVERY round commitment of the argument are comb MSMs over the original points with the fold
+    # coefficients multiplied into the scalars; no point is folded, no half-GCD is taken, csrc/nlb.hip) writes the same bytes as well
+    os.environ["BPPP_RP_COMB_MIN"] = "1"
     try:
         assert nat.prove_batch(inputs, prefixes) == got
-        assert nat.prove_batch(inputs[:3], prefixes[:3]) == got[:3]      # the tables are kept by the handle across batches
+        assert nat.prove_batch(inputs[:3], prefixes[:3]) == got[:3]      # the table is kept by the handle across batches
     finally:
-        del os.environ["BPPP_NLB_SHARED_MIN"]
+        del os.environ["BPPP_RP_COMB_MIN"]
+    # ... and with the table in place the point-folding route of the argument is still there (the general bppp_nlb_* entry points use it)
+    os.environ["BPPP_NLB_FOLD_POINTS"] = "1"
+    try:
+        assert nat.prove_batch(inputs, prefixes) == got
+    finally:
+        del os.environ["BPPP_NLB_FOLD_POINTS"]
     # two half-batches in flight on two contexts (the default for large batches, csrc/rpprove.hip): the same bytes, and a refused
     # input in the second half is reported under its index in the whole batch
     os.environ["BPPP_RP_SPLIT_MIN"] = "2"
