@@ -190,6 +190,50 @@ __global__ void __launch_bounds__(256) k_nlb_fill_one(uint32_t *__restrict__ v, 
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < count) fe_store(v + i * 8, fe_one());
 }
+// Round bookkeeping of the fixed-basis mode, one lane per proof, state resident in HBM (no host round trip inside a round):
+// st = [batch][NLB_ST][8]: nn, ln, s, sX, sR;  qs = [batch][2][8]: q, q^-1.
+enum { NLB_ST_NN = 0, NLB_ST_LN = 1, NLB_ST_S = 2, NLB_ST_SX = 3, NLB_ST_SR = 4, NLB_ST = 5 };
+// after k_nlb_round: sX = 2 n^2 q^3 sX' + (linear sX), sR = n^2 q^4 sR' + (linear sR) (NormArgument.hs:113); they are the scalars on g
+__global__ void __launch_bounds__(64) k_nlb_tails(const uint32_t *__restrict__ sums, const uint32_t *__restrict__ qs, uint32_t *__restrict__ stt, uint32_t batch,
+                                                  uint32_t n, uint32_t l, uint32_t T, uint32_t *__restrict__ sc) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= batch) return;
+  uint32_t *S = stt + (size_t)b * NLB_ST * 8;
+  const fe q = fe_load(qs + (size_t)b * 16), nn = fe_load(S + NLB_ST_NN * 8);
+  const fe q2 = fe_sqr<1>(q), q3 = fe_mul<1>(q2, q), q4 = fe_sqr<1>(q2), n2 = fe_sqr<1>(nn);
+  fe sX = fe_zero(), sR = fe_zero();
+  if (n) {
+    sX = fe_mul<1>(fe_mul<1>(fe_add<1>(n2, n2), q3), fe_load(sums + (size_t)b * 32));
+    sR = fe_mul<1>(fe_mul<1>(n2, q4), fe_load(sums + (size_t)b * 32 + 8));
+  }
+  if (l) { sX = fe_add<1>(sX, fe_load(sums + (size_t)b * 32 + 16)); sR = fe_add<1>(sR, fe_load(sums + (size_t)b * 32 + 24)); }
+  fe_store(S + NLB_ST_SX * 8, sX); fe_store(S + NLB_ST_SR * 8, sR);
+  fe_store(sc + ((size_t)(2 * b) * T + T - 1) * 8, sX); fe_store(sc + ((size_t)(2 * b + 1) * T + T - 1) * 8, sR);
+}
+// the challenge e of a round: s' = s + e sX + (e^2 - 1) sR; the unscaled fold constants; n' = n q^-1, q' = q^2
+__global__ void __launch_bounds__(64) k_nlb_collapse_state(const uint32_t *__restrict__ es, uint32_t *__restrict__ qs, uint32_t *__restrict__ stt, uint32_t batch,
+                                                           uint32_t n, uint32_t l, CollapseK *__restrict__ K, uint32_t *__restrict__ A) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= batch) return;
+  uint32_t *S = stt + (size_t)b * NLB_ST * 8;
+  const fe e = fe_load(es + (size_t)b * 8), one = fe_one();
+  const fe e1 = fe_sub<1>(fe_sqr<1>(e), one);
+  fe_store(S + NLB_ST_S * 8, fe_add<1>(fe_load(S + NLB_ST_S * 8), fe_add<1>(fe_mul<1>(e, fe_load(S + NLB_ST_SX * 8)), fe_mul<1>(e1, fe_load(S + NLB_ST_SR * 8)))));
+  CollapseK &k = K[b];
+  if (n) {
+    const fe q = fe_load(qs + (size_t)b * 16), qi = fe_load(qs + (size_t)b * 16 + 8);
+    for (int i = 0; i < 8; i++) k.nu[i] = one.v[i];
+    const fe nv = fe_mul<1>(e, q);
+    for (int i = 0; i < 8; i++) k.nv[i] = nv.v[i];
+    fe_store(A + (size_t)b * 16, fe_mul<1>(e, qi));
+    fe_store(S + NLB_ST_NN * 8, fe_mul<1>(fe_load(S + NLB_ST_NN * 8), qi));
+    fe_store(qs + (size_t)b * 16, fe_sqr<1>(q)); fe_store(qs + (size_t)b * 16 + 8, fe_sqr<1>(qi));
+  }
+  if (l) {
+    for (int i = 0; i < 8; i++) { k.cu[i] = one.v[i]; k.cv[i] = e.v[i]; k.lu[i] = one.v[i]; k.lv[i] = e.v[i]; }
+    fe_store(A + (size_t)b * 16 + 8, e);
+  }
+}
 }  // namespace bppp
 
 using namespace bppp;
@@ -214,7 +258,7 @@ struct bppp_nlb {
   uint32_t *sc, *sums, *qs;
   CollapseK *dK;
   const bppp::CombTable *comb; // fixed-basis mode: comb over [g | lin | norm]; the points are never folded (P[] is not allocated)
-  uint32_t *coefn, *coefl, *full, *dA, *d_out;
+  uint32_t *coefn, *coefl, *full, *dA, *d_out, *stt, *d_es;   // stt: per-proof round state in HBM (k_nlb_tails / k_nlb_collapse_state)
   uint32_t folds;              // completed folds (the level shift of an original index)
   int cur;
   std::vector<U256> q, qinv, nn, ln, s, sX, sR;
@@ -235,7 +279,7 @@ void bppp_nlb_destroy(bppp_nlb *o) {
   hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(o->x[k]); hipFree(o->lx[k]); hipFree(o->lc[k]); hipFree(o->P[k]); }
   hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK);
-  hipFree(o->coefn); hipFree(o->coefl); hipFree(o->full); hipFree(o->dA); hipFree(o->d_out);
+  hipFree(o->coefn); hipFree(o->coefl); hipFree(o->full); hipFree(o->dA); hipFree(o->d_out); hipFree(o->stt); hipFree(o->d_es);
   delete o;
   ctx_release(ctx);
 }
@@ -271,7 +315,7 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   o->cap = evb(nlen) + evb(llen) + 1; o->xstride = evb(nlen) + 2; o->lstride = evb(llen) + 2;
   for (int k = 0; k < 2; k++) { o->x[k] = o->lx[k] = o->lc[k] = o->P[k] = nullptr; }
   o->sc = o->sums = o->qs = nullptr; o->dK = nullptr;
-  o->comb = comb; o->coefn = o->coefl = o->full = o->dA = o->d_out = nullptr; o->folds = 0;
+  o->comb = comb; o->coefn = o->coefl = o->full = o->dA = o->d_out = o->stt = o->d_es = nullptr; o->folds = 0;
   bool bad = false;
   for (int k = 0; k < 2; k++) {
     bad |= hipMalloc(&o->x[k], batch * o->xstride * 32) != hipSuccess || hipMalloc(&o->lx[k], batch * o->lstride * 32) != hipSuccess;
@@ -283,6 +327,7 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
     const size_t Tc = 1 + llen + nlen;
     bad |= hipMalloc(&o->coefn, batch * std::max<size_t>(nlen, 1) * 32) != hipSuccess || hipMalloc(&o->coefl, batch * std::max<size_t>(llen, 1) * 32) != hipSuccess;
     bad |= hipMalloc(&o->full, 2 * batch * Tc * 32) != hipSuccess || hipMalloc(&o->dA, batch * 64) != hipSuccess || hipMalloc(&o->d_out, 2 * batch * 64) != hipSuccess;
+    bad |= hipMalloc(&o->stt, batch * NLB_ST * 32) != hipSuccess || hipMalloc(&o->d_es, batch * 32) != hipSuccess;
   }
   if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
   hipStream_t st = ctx->stream;
@@ -323,11 +368,69 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   }
   for (size_t b = 0; b < batch; b++) { o->q[b] = U256::load(q + 4 * b); o->qinv[b] = o->q[b]; o->s[b] = U256::load(s + 4 * b); }
   batch_minv(o->qinv.data(), batch, M);
+  if (comb) {                                // the round state lives in HBM from here on
+    std::vector<uint64_t> hqs(batch * 8), hst(batch * NLB_ST * 4, 0);
+    for (size_t b = 0; b < batch; b++) {
+      o->q[b].store(&hqs[8 * b]); o->qinv[b].store(&hqs[8 * b + 4]);
+      hst[(b * NLB_ST + NLB_ST_NN) * 4] = 1; hst[(b * NLB_ST + NLB_ST_LN) * 4] = 1;
+      o->s[b].store(&hst[(b * NLB_ST + NLB_ST_S) * 4]);
+    }
+    NLB_HIP(o, hipMemcpyAsync(o->qs, hqs.data(), batch * 64, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemcpyAsync(o->stt, hst.data(), batch * NLB_ST * 32, hipMemcpyHostToDevice, st));
+    NLB_HIP(o, hipMemsetAsync(o->dK, 0, batch * sizeof(CollapseK), st));
+  }
   NLB_HIP(o, hipStreamSynchronize(st));
   return BPPP_OK;
   };
   if (int rc = fill()) { bppp_nlb_destroy(o); return rc; }
   *out = o;
+  return BPPP_OK;
+}
+}  // namespace bppp
+namespace bppp {
+bool nlb_fixed_basis(const bppp_nlb *o) { return o && o->comb != nullptr; }
+// Fixed-basis mode, first half of a round for every proof, nothing leaves the device: d_XR [batch][2][16] receives X_b, R_b
+// (canonical affine).  Asynchronous on the context's stream.
+int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR) {
+  if (!o || !o->comb || !d_XR) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = o->ctx;
+  hipSetDevice(ctx->device);
+  const size_t B = o->batch, ne = evb(o->n), le = evb(o->l), T = ne + le + 1;
+  const int c = o->cur;
+  hipStream_t st = ctx->stream;
+  NLB_HIP(o, hipMemsetAsync(o->sc, 0, 2 * B * T * 32, st));
+  unsigned round_threads = 64;
+  while (round_threads < 256 && round_threads < std::max((o->n + 1) / 2, (o->l + 1) / 2)) round_threads <<= 1;
+  k_nlb_round<<<dim3((unsigned)B), dim3(round_threads), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride, (uint32_t)o->lstride,
+                                                                 o->qs, (uint32_t)T, o->sc, o->sums);
+  k_nlb_tails<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(o->sums, o->qs, o->stt, (uint32_t)B, (uint32_t)o->n, (uint32_t)o->l, (uint32_t)T, o->sc);
+  const uint32_t Tc = (uint32_t)(1 + o->l0 + o->n0);
+  k_nlb_expand<<<dim3((Tc + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds, o->coefn, o->coefl, (uint32_t)o->n0,
+                                                                                (uint32_t)o->l0, o->full);
+  NLB_HIP(o, hipGetLastError());
+  int rc = comb_msm(o->comb, o->full, 2 * B, d_XR, st, true);
+  if (rc) return fail(ctx, rc, bppp_last_error(o->comb->ctx));
+  return BPPP_OK;
+}
+// second half: d_es [batch][8] are the challenges, in HBM.  Asynchronous.
+int nlb_round_collapse_dev(bppp_nlb *o, const uint32_t *d_es) {
+  if (!o || !o->comb || !d_es) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = o->ctx;
+  hipSetDevice(ctx->device);
+  const size_t B = o->batch;
+  const int c = o->cur, d = 1 - c;
+  const size_t n2 = (o->n + 1) / 2, l2 = (o->l + 1) / 2;
+  hipStream_t st = ctx->stream;
+  k_nlb_collapse_state<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(d_es, o->qs, o->stt, (uint32_t)B, (uint32_t)o->n, (uint32_t)o->l, o->dK, o->dA);
+  NLB_HIP(o, hipMemsetAsync(o->x[d], 0, B * o->xstride * 32, st));
+  NLB_HIP(o, hipMemsetAsync(o->lx[d], 0, B * o->lstride * 32, st));
+  NLB_HIP(o, hipMemsetAsync(o->lc[d], 0, B * o->lstride * 32, st));
+  const uint32_t maxp = (uint32_t)std::max(n2, l2), maxc = (uint32_t)std::max(o->n0, o->l0);
+  if (maxp) k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l,
+                                                                                           (uint32_t)o->xstride, (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
+  k_nlb_coef_update<<<dim3((maxc + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->coefn, o->coefl, (uint32_t)(o->n ? o->n0 : 0), (uint32_t)(o->l ? o->l0 : 0), o->folds, o->dA);
+  NLB_HIP(o, hipGetLastError());
+  o->n = o->n ? n2 : 0; o->l = o->l ? l2 : 0; o->cur = d; o->folds++;
   return BPPP_OK;
 }
 }  // namespace bppp
@@ -354,6 +457,19 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
   const size_t B = o->batch, ne = evb(o->n), le = evb(o->l), T = ne + le + 1;
   const int c = o->cur;
   hipStream_t st = ctx->stream;
+  if (o->comb) {                             // fixed-basis mode: the device routine, results brought to the host
+    int rcd = nlb_round_commit_dev(o, o->d_out);
+    if (rcd) return rcd;
+    std::vector<uint64_t> outs(2 * B * 8), hst(B * NLB_ST * 4);
+    NLB_HIP(o, hipMemcpyAsync(outs.data(), o->d_out, 2 * B * 64, hipMemcpyDeviceToHost, st));
+    NLB_HIP(o, hipMemcpyAsync(hst.data(), o->stt, B * NLB_ST * 32, hipMemcpyDeviceToHost, st));
+    NLB_HIP(o, hipStreamSynchronize(st));
+    for (size_t b = 0; b < B; b++) {
+      memcpy(X_xy + 8 * b, &outs[16 * b], 64); memcpy(R_xy + 8 * b, &outs[16 * b + 8], 64);
+      memcpy(sX + 4 * b, &hst[(b * NLB_ST + NLB_ST_SX) * 4], 32); memcpy(sR + 4 * b, &hst[(b * NLB_ST + NLB_ST_SR) * 4], 32);
+    }
+    return BPPP_OK;
+  }
   std::vector<uint64_t> h(B * 16);
   for (size_t b = 0; b < B; b++) { o->q[b].store(&h[8 * b]); o->qinv[b].store(&h[8 * b + 4]); }
   NLB_HIP(o, hipMemcpyAsync(o->qs, h.data(), B * 64, hipMemcpyHostToDevice, st));
@@ -378,18 +494,6 @@ int bppp_nlb_round_commit(bppp_nlb *o, uint64_t *sX, uint64_t *X_xy, uint64_t *s
   // the scalar on g is the last term of each instance: instance 2b (X) and 2b+1 (R)
   NLB_HIP(o, hipMemcpy2DAsync(o->sc + (T - 1) * 8, T * 32, tails.data(), 32, 32, 2 * B, hipMemcpyHostToDevice, st));
   std::vector<uint64_t> outs(2 * B * 8);
-  if (o->comb) {
-    const uint32_t Tc = (uint32_t)(1 + o->l0 + o->n0);
-    k_nlb_expand<<<dim3((Tc + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds, o->coefn, o->coefl, (uint32_t)o->n0,
-                                                                                  (uint32_t)o->l0, o->full);
-    NLB_HIP(o, hipGetLastError());
-    int rcc = comb_msm(o->comb, o->full, 2 * B, o->d_out, st, true);
-    if (rcc) return fail(ctx, rcc, bppp_last_error(o->comb->ctx));
-    NLB_HIP(o, hipMemcpyAsync(outs.data(), o->d_out, 2 * B * 64, hipMemcpyDeviceToHost, st));
-    NLB_HIP(o, hipStreamSynchronize(st));
-    for (size_t b = 0; b < B; b++) { memcpy(X_xy + 8 * b, &outs[16 * b], 64); memcpy(R_xy + 8 * b, &outs[16 * b + 8], 64); }
-    return BPPP_OK;
-  }
   int rc = msm_run(ctx, o->sc, o->P[c], T, 2 * B, 2, 0, outs.data());   // X and R of a proof share that proof's basis
   if (rc) return rc;
   for (size_t b = 0; b < B; b++) { memcpy(X_xy + 8 * b, &outs[16 * b], 64); memcpy(R_xy + 8 * b, &outs[16 * b + 8], 64); }
@@ -415,40 +519,11 @@ int bppp_nlb_round_collapse(bppp_nlb *o, const uint64_t *es) {
   std::vector<U256> s_new(o->s), nn_new(o->nn), q_new(o->q), qinv_new(o->qinv), ln_new(o->ln);
   for (size_t b = 0; b < B; b++)
     if (cmp(U256::load(es + 4 * b), M.m) >= 0) return fail(ctx, BPPP_ERR_ARG, "nlb_round_collapse: challenge not canonical");
-  if (o->comb) {
-    // fixed-basis mode: the unscaled fold (a, b) = (x, 1) — no half-GCD, no point fold; the basis coefficients take the factor a
-    std::vector<uint32_t> A(B * 16, 0);
-    parallel_ranges(B, [&](size_t lo, size_t hi) {
-     for (size_t b = lo; b < hi; b++) {
-      const U256 e = U256::load(es + 4 * b);
-      U256 e1 = msub(mmul(e, e, M), U256::one(), M);
-      s_new[b] = madd(o->s[b], madd(mmul(e, o->sX[b], M), mmul(e1, o->sR[b], M), M), M);
-      memset(&K[b], 0, sizeof(CollapseK));
-      if (o->n) {
-        put8(K[b].nu, U256::one()); put8(K[b].nv, mmul(e, o->q[b], M));
-        put8(&A[16 * b], mmul(e, o->qinv[b], M));
-        nn_new[b] = mmul(o->nn[b], o->qinv[b], M);
-        q_new[b] = mmul(o->q[b], o->q[b], M); qinv_new[b] = mmul(o->qinv[b], o->qinv[b], M);
-      }
-      if (o->l) {
-        put8(K[b].cu, U256::one()); put8(K[b].cv, e); put8(K[b].lu, U256::one()); put8(K[b].lv, e);
-        put8(&A[16 * b + 8], e);
-      }
-     }
-    });
-    NLB_HIP(o, hipMemcpyAsync(o->dK, K.data(), B * sizeof(CollapseK), hipMemcpyHostToDevice, st));
-    NLB_HIP(o, hipMemcpyAsync(o->dA, A.data(), B * 64, hipMemcpyHostToDevice, st));
-    NLB_HIP(o, hipMemsetAsync(o->x[d], 0, B * o->xstride * 32, st));
-    NLB_HIP(o, hipMemsetAsync(o->lx[d], 0, B * o->lstride * 32, st));
-    NLB_HIP(o, hipMemsetAsync(o->lc[d], 0, B * o->lstride * 32, st));
-    const uint32_t maxp = (uint32_t)std::max(n2, l2), maxc = (uint32_t)std::max(o->n0, o->l0);
-    if (maxp) k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l,
-                                                                                             (uint32_t)o->xstride, (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
-    k_nlb_coef_update<<<dim3((maxc + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->coefn, o->coefl, (uint32_t)(o->n ? o->n0 : 0), (uint32_t)(o->l ? o->l0 : 0), o->folds, o->dA);
-    NLB_HIP(o, hipGetLastError());
+  if (o->comb) {                             // fixed-basis mode: the device routine on the uploaded challenges
+    NLB_HIP(o, hipMemcpyAsync(o->d_es, es, B * 32, hipMemcpyHostToDevice, st));
+    int rcd = nlb_round_collapse_dev(o, o->d_es);
+    if (rcd) return rcd;
     NLB_HIP(o, hipStreamSynchronize(st));
-    o->s.swap(s_new); o->nn.swap(nn_new); o->q.swap(q_new); o->qinv.swap(qinv_new); o->ln.swap(ln_new);
-    o->n = o->n ? n2 : 0; o->l = o->l ? l2 : 0; o->cur = d; o->folds++;
     return BPPP_OK;
   }
   std::atomic<int> too_big{0};
@@ -518,7 +593,17 @@ int bppp_nlb_get_witness(bppp_nlb *o, uint64_t *norm_w, uint64_t *lin_w, uint64_
   hipStream_t st = ctx->stream;
   if (o->n) NLB_HIP(o, hipMemcpy2DAsync(norm_w, o->n * 32, o->x[c], o->xstride * 32, o->n * 32, o->batch, hipMemcpyDeviceToHost, st));
   if (o->l) NLB_HIP(o, hipMemcpy2DAsync(lin_w, o->l * 32, o->lx[c], o->lstride * 32, o->l * 32, o->batch, hipMemcpyDeviceToHost, st));
+  std::vector<uint64_t> hst;
+  if (o->comb) {                             // fixed-basis mode keeps n, l, s of every proof in HBM
+    hst.resize(o->batch * NLB_ST * 4);
+    NLB_HIP(o, hipMemcpyAsync(hst.data(), o->stt, o->batch * NLB_ST * 32, hipMemcpyDeviceToHost, st));
+  }
   NLB_HIP(o, hipStreamSynchronize(st));
+  if (o->comb)
+    for (size_t b = 0; b < o->batch; b++) {
+      o->nn[b] = U256::load(&hst[(b * NLB_ST + NLB_ST_NN) * 4]); o->ln[b] = U256::load(&hst[(b * NLB_ST + NLB_ST_LN) * 4]);
+      o->s[b] = U256::load(&hst[(b * NLB_ST + NLB_ST_S) * 4]);
+    }
   for (size_t b = 0; b < o->batch; b++) {
     for (size_t i = 0; i < o->n; i++) mmul(U256::load(norm_w + 4 * (b * o->n + i)), o->nn[b], M).store(norm_w + 4 * (b * o->n + i));
     for (size_t i = 0; i < o->l; i++) mmul(U256::load(lin_w + 4 * (b * o->l + i)), o->ln[b], M).store(lin_w + 4 * (b * o->l + i));

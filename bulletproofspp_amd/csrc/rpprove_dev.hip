@@ -446,7 +446,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   uint32_t *in_sc = nullptr, *in_pt = nullptr, *dig = nullptr, *mul = nullptr, *mss = nullptr, *rnd = nullptr, *rows_dm_m = nullptr, *row_r = nullptr, *row_bl = nullptr,
            *ccbuf = nullptr, *invtab = nullptr, *aux = nullptr, *ch = nullptr, *es = nullptr, *tstart = nullptr, *ptbuf = nullptr, *a_s = nullptr, *a_q = nullptr,
            *a_lx = nullptr, *a_nx = nullptr, *p_sp = nullptr, *p_norm = nullptr, *p_cs = nullptr, *p_init = nullptr;
-  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr;
+  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr; uint32_t *d_resp = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv(pass ? rp->pwork : nullptr, rp->pwork_bytes);
     in_sc = cv.take<uint32_t>(B * nr * 24); in_pt = cv.take<uint32_t>(B * nr * 16);
@@ -458,7 +458,8 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     ptbuf = cv.take<uint32_t>(B * (2 + nr) * 16);
     a_s = cv.take<uint32_t>(B * 8); a_q = cv.take<uint32_t>(B * 8); a_lx = cv.take<uint32_t>(B * llen * 8); a_nx = cv.take<uint32_t>(B * nlen * 8);
     p_sp = cv.take<uint32_t>(B * 8); p_norm = cv.take<uint32_t>(B * nlen * 8); p_cs = cv.take<uint32_t>(B * llen * 8); p_init = cv.take<uint32_t>(B * (4 + nr) * 8);
-    text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<RppHdrs>(1);
+    text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<RppHdrs>(1 + k);
+    d_resp = cv.take<uint32_t>(k * B * 32 + 16);
     if (!pass) { int rc = rpp_ensure_pwork(rp, cv.off); if (rc) return rc; }
   }
   // ---- uploads: inputs, digits, multiplicities, prefixes
@@ -541,6 +542,34 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   rc = nlb_create_impl(ctx, B, (const uint64_t *)a_s, (const uint64_t *)rp->d_g(), (const uint64_t *)a_q, (const uint64_t *)a_nx, (const uint64_t *)rp->d_G(), nlen,
                        (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, getenv("BPPP_NLB_FOLD_POINTS") ? nullptr : rp->comb);
   if (rc) return rc;
+  if (nlb_fixed_basis(nlb)) {
+    // fixed-basis mode: the k rounds are one stream of kernels — round scalars, comb MSM, transcript text, SHA-256, fold of the
+    // scalars — with the per-proof state in HBM; the host only queues them.  The oracle headers of all rounds go up first.
+    std::vector<RppHdrs> hh(k);
+    for (size_t round = 0; round < k; round++) {
+      memset(&hh[round], 0, sizeof(RppHdrs));
+      const std::string hs = rp->tag + "1" + std::to_string(npoints + 2 * (round + 1));
+      if (hs.size() > 64) { rc = fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: oracle tag too long"); break; }
+      rp_pack_header(hs, hh[round].hdr_be[0]); hh[round].hlen[0] = (uint32_t)hs.size(); hh[round].slot[0] = 7;
+    }
+    if (!rc && (hipMemcpyAsync(hdrs + 1, hh.data(), k * sizeof(RppHdrs), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: header upload");
+    for (size_t round = 0; round < k && !rc; round++) {
+      uint32_t *xr_dev = d_resp + round * B * 32;
+      rc = nlb_round_commit_dev(nlb, xr_dev); if (rc) break;
+      npoints += 2;
+      k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), 3 * 4, st>>>(xr_dev, 2u, text, stride, tstart);
+      k_rpp_hash<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(hdrs + 1 + round, 1u, (uint32_t)B, text, stride, tstart, tend, ch, es);
+      if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: round kernels"); break; }
+      rc = nlb_round_collapse_dev(nlb, es);
+    }
+    std::vector<uint64_t> hresp(k * B * 16);
+    if (!rc && (hipMemcpyAsync(hresp.data(), d_resp, k * B * 128, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: response download");
+    if (!rc)
+      for (size_t round = 0; round < k; round++)
+        for (size_t b = 0; b < B; b++) memcpy(out.resp + (b * k + (k - 1 - round)) * 16, &hresp[(round * B + b) * 16], 128);   // responses LAST round first (:359)
+  } else {
   std::vector<uint64_t> sX(B * 4), sR(B * 4), X(B * 8), R(B * 8), eh(B * 4), xr(B * 16);
   for (size_t round = 0; round < k && !rc; round++) {
     rc = bppp_nlb_round_commit(nlb, sX.data(), X.data(), sR.data(), R.data());
@@ -554,6 +583,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     rc = oracle(xr.data(), nullptr, 2, 1, slots); if (rc) break;
     if (hipMemcpyAsync(eh.data(), es, B * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: challenge download"); break; }
     rc = bppp_nlb_round_collapse(nlb, eh.data());
+  }
   }
   if (!rc) rc = bppp_nlb_get_witness(nlb, out.wit_norm, out.wit_lin, nullptr);
   bppp_nlb_destroy(nlb);

@@ -34,6 +34,10 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
                     size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out, bool on_device,
                     const struct CombTable *comb);
 
+bool nlb_fixed_basis(const bppp_nlb *o);
+int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR);
+int nlb_round_collapse_dev(bppp_nlb *o, const uint32_t *d_es);
+
 }  // namespace bppp
 
 extern "C" {
