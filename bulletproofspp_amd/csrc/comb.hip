@@ -5,8 +5,9 @@
 // round commitments, src/NormArgument.hs:100-128, over a basis that is a known linear image of the setup's).  With the basis fixed
 // per setup and 288 GB of HBM, every multiple a signed c-bit digit can ask for is stored once:
 //     tab[w][i][d - 1] = d * 2^(c w) * P_i          w < W = ceil(257 / c),   d = 1 .. 2^(c-1)
-// (c = 13: 20 x 775 x 4096 entries of 64 B = 4.1 GB), and an MSM is then nothing but one mixed addition per non-zero digit into ONE
-// accumulator: no digit sort, no buckets, no bucket reduction, no window combine, no doubling — 20 additions per term against
+// (c = 16: 17 x 774 x 32768 entries of 64 B = 27.6 GB — the widest window whose table stays under the caller's budget is taken;
+// c = 13: 4.1 GB), and an MSM is then nothing but one mixed addition per non-zero digit into ONE
+// accumulator: no digit sort, no buckets, no bucket reduction, no window combine, no doubling — 17 additions per term against
 // 29 + sort + reduction on the bucket route at its best window for this shape (csrc/msm.hip, c = 9).
 //
 // k_comb_msm: one wavefront per instance, lane l takes one term of every 64; the table entry of the NEXT digit is requested
@@ -144,7 +145,7 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   hipSetDevice(ctx->device);
   int c = window_bits;
   auto size_of = [&](int cc) { return (size_t)((257 + cc - 1) / cc) * T * ((size_t)1 << (cc - 1)) * 64; };
-  if (!c) { c = 14; while (c > 4 && size_of(c) > budget_bytes) c--; }
+  if (!c) { c = 16; while (c > 4 && size_of(c) > budget_bytes) c--; }
   if (c < 4 || c > 16) return fail(ctx, BPPP_ERR_ARG, "comb_create: window_bits must be in [4,16]");
   CombTable *t = new CombTable();
   t->ctx = ctx; ctx_retain(ctx); t->T = T; t->c = c; t->W = (257 + c - 1) / c; t->D = 1 << (c - 1); t->tab = nullptr; t->bytes = size_of(c);

@@ -274,6 +274,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
+  if (rp->hpin) hipHostFree(rp->hpin);
   if (rp->twin) bppp_rp_destroy(rp->twin);
   if (rp->d_comb_out) hipFree(rp->d_comb_out);
   if (rp->comb && rp->comb_owned) bppp::comb_destroy(rp->comb);

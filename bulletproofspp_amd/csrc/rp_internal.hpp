@@ -74,6 +74,7 @@ struct bppp_rp {
   uint32_t *d_fixed = nullptr;
   bppp_basis *commit_basis = nullptr;           // [g | H | G] registered with its fixed-base table: the range-proof commitments
   void *pwork = nullptr; size_t pwork_bytes = 0;
+  void *hpin = nullptr; size_t hpin_bytes = 0;     // pinned host staging of the batch prover
   // the creation arguments, kept so that a second handle on its OWN context (stream, workspaces) can be made: a large prove batch
   // runs as two half-batches in flight, the host shares of one under the kernels of the other (csrc/rpprove.hip)
   std::vector<bppp_rp_range> c_ranges; std::vector<bppp_rp_public> c_pubs; std::vector<uint64_t> c_points; int c_has_types = 0;

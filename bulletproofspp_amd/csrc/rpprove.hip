@@ -513,12 +513,16 @@ int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t 
 }
 }  // namespace bppp
 
-// the comb table of the setup's basis, built at the first large batch (4 GB at 775 points; BPPP_RP_COMB_BITS / BPPP_RP_NO_COMB)
+// the comb table of the setup's basis, built at the first large batch: the widest window (<= 16 bits) whose table fits the budget —
+// 32 GB by default, BPPP_RP_COMB_GB to change it: 27.6 GB at 774 points (c = 16, built in ~0.3 s), 4.1 GB at c = 13 costs ~15 % more
+// additions; BPPP_RP_COMB_BITS forces a width, BPPP_RP_NO_COMB keeps the bucket route
 int rp_ensure_comb(bppp_rp *rp) {
   if (rp->comb || getenv("BPPP_RP_NO_COMB")) return BPPP_OK;
   int c = 0;
   if (const char *e = getenv("BPPP_RP_COMB_BITS")) c = atoi(e);
-  int rc = bppp::comb_create(rp->ctx, rp->d_basis, 1 + rp->st.llen + rp->st.nlen, c, (size_t)16 << 30, &rp->comb);
+  size_t gb = 32;
+  if (const char *e = getenv("BPPP_RP_COMB_GB")) gb = (size_t)std::max(1, atoi(e));
+  int rc = bppp::comb_create(rp->ctx, rp->d_basis, 1 + rp->st.llen + rp->st.nlen, c, gb << 30, &rp->comb);
   if (rc) { rp->comb = nullptr; return rc; }
   rp->comb_owned = true;
   return BPPP_OK;
@@ -605,8 +609,19 @@ static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, c
   double t_last = now();
   auto lap = [&](const char *what) { if (timing) { double t = now(); fprintf(stderr, "[rp_prove] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
   // ---- the witness on the host: digits and multiplicities are integer work on the plain amounts (TypedReciprocal.hs:125-161)
-  std::vector<uint64_t> h_in_sc(B * nr * 12);
-  std::vector<uint32_t> dig(B * nlen), mul(B * nlen), mss(B * (llen - 6) + 1);
+  // host staging: one pinned grow-only buffer per handle (no page faults on fresh vectors every call; the 50 MB of inputs and the
+  // commitments cross PCIe at the pinned rate)
+  const size_t n_in_sc = B * nr * 12, n_dig = B * nlen, n_mss = B * (llen - 6) + 1, n_in_pt = B * nr * 8;
+  const size_t pin_need = (n_in_sc + n_in_pt) * 8 + (2 * n_dig + n_mss) * 4 + 64;
+  if (pin_need > rp->hpin_bytes) {
+    BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rp->hpin) BPPP_HIP(ctx, hipHostFree(rp->hpin));
+    rp->hpin = nullptr; rp->hpin_bytes = 0;
+    BPPP_HIP(ctx, hipHostMalloc(&rp->hpin, pin_need + pin_need / 8, hipHostMallocDefault));
+    rp->hpin_bytes = pin_need + pin_need / 8;
+  }
+  uint64_t *h_in_sc = (uint64_t *)rp->hpin, *h_in_pt = h_in_sc + n_in_sc;
+  uint32_t *dig = (uint32_t *)(h_in_pt + n_in_pt), *mul = dig + n_dig, *mss = mul + n_dig;
   std::atomic<int> failed{-1};
   std::vector<std::string> errs(B);
   rp_parallel(B, [&](size_t lo, size_t hi) {
@@ -624,9 +639,9 @@ static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, c
   });
   if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed + index_base) + ": " + errs[failed]);
   lap("witness digits (host)");
-  std::vector<uint64_t> in_pt(B * nr * 8), c_dm(B * 8), c_m(B * 8), c_r(B * 8), c_bl(B * 8), resp(B * k * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
-  RppHostInputs in{B, h_in_sc.data(), dig.data(), mul.data(), mss.data(), rand_prefix, prefix_len};
-  RppOutputs out{in_pt.data(), c_dm.data(), c_m.data(), c_r.data(), c_bl.data(), resp.data(), wn.data(), wl.data()};
+  std::vector<uint64_t> c_dm(B * 8), c_m(B * 8), c_r(B * 8), c_bl(B * 8), resp(B * k * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
+  RppHostInputs in{B, h_in_sc, dig, mul, mss, rand_prefix, prefix_len};
+  RppOutputs out{h_in_pt, c_dm.data(), c_m.data(), c_r.data(), c_bl.data(), resp.data(), wn.data(), wl.data()};
   { int rc = rpp_device_prove(rp, in, out); if (rc) return rc; }
   lap("phases + argument (device)");
   encode_batch(rp, B, out, coms_files, proof_files);
