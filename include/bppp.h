@@ -359,10 +359,13 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
  * ZKPT.random, src/ZKP.hs:88-92) with prefix_b = rand_prefix[b * prefix_len ..].  The oracle is the setup's shaOracle (see above).
  * Outputs are the reference's files: coms_files [batch][coms_bytes], proof_files [batch][proof_bytes].  Every commitment is
  * computed on the device (input commitments through a fixed-base table of g, H0, H1; the four range-proof commitments of all
- * proofs as batched MSMs over the registered basis; the argument through bppp_nlb_*, its first round over fixed-base tables of
- * the setup's basis kept by the handle), and so are the per-proof field algebra, the randomness and the transcript hashing; the
- * host cores extract the digits of the plain amounts and run the half-GCDs of the argument's rounds.  A batch of 2048 proofs or
- * more runs as two half-batches in flight, the second on a twin handle with its own context that this handle creates and owns
+ * proofs and the round commitments of the argument), and so are the per-proof field algebra, the randomness and the transcript
+ * hashing; the host cores extract the digits of the plain amounts.  MEMORY: at the first batch of 256 proofs or more the handle
+ * builds a fixed-base comb table over the setup's basis [g | H | G] and keeps it until it is destroyed — the widest window (<= 16
+ * bits) whose table fits 32 GB: 27.6 GB for the 774 points of 64by64, built in ~0.3 s (BPPP_RP_COMB_GB=<GB> changes the budget,
+ * BPPP_RP_COMB_BITS=<c> forces a width: c = 13 is 4.1 GB and ~15 % more additions; BPPP_RP_NO_COMB=1 keeps the bucket route and
+ * the point-folding argument, which smaller batches use anyway).  A batch of 2048 proofs or more runs as two half-batches in
+ * flight, the second on a twin handle with its own context that this handle creates and owns and that shares the table
  * (BPPP_RP_SPLIT_MIN=<n> moves the threshold, BPPP_RP_NO_SPLIT=1 disables it); a handle serves one call at a time.  Same
  * randomness and inputs => byte-identical files to the host protocol code (bulletproofspp_amd/rangeproof.py: prove +
  * encoding.encode_proof), on every one of these routes, which the tests assert. */
