@@ -493,6 +493,50 @@ def main():
                  "note": "precomputation outside the timed region; same result as the arbitrary-point MSM (asserted)"}
         bas.close()
 
+    # the prover's shape: THOUSANDS of MSMs over ONE short basis (4096 instances x 774 terms).  Three routes, same results (asserted):
+    # arbitrary points (bucket method per instance), the registered basis (one bucket set per instance), and the registered basis with
+    # its comb table (every multiple of every window in HBM: one mixed addition per non-zero digit, csrc/comb.hip).
+    fixed_batch = None
+    if world == 1 and not args.headline_only:
+        nb, inst = 774, 4096
+        rngb = np.random.default_rng(77)
+        scb = rngb.integers(0, 2**64, size=(inst * nb, 4), dtype=np.uint64)
+        scb[:, 3] >>= np.uint64(1)
+        dscb = torch.from_numpy(scb.view(np.int64)).to(dev)
+        ptsb = dpts[:nb].contiguous()
+        legs = {}
+        import ctypes as C_
+        vpp = lambda v: C_.c_void_p(v)
+        outs_b = [np.zeros((inst, 8), dtype=np.uint64) for _ in range(3)]       # the C entry points write [batch][8] straight into these
+
+        def plain_call():
+            gpu._check(gpu.lib.bppp_msm_batch_device(gpu.h, vpp(dscb.data_ptr()), vpp(ptsb.data_ptr()), nb, inst, 1, 0, vpp(outs_b[0].ctypes.data)), "bppp_msm_batch_device")
+
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / reps
+        dtb = timed(plain_call)
+        legs["arbitrary_points"] = {"ms": dtb * 1e3, "pairs_per_s": nb * inst / dtb}
+        basb = gpu.basis(ptsb.data_ptr(), device=True, n=nb, batch_hint=inst)
+        dtb = timed(lambda: gpu._check(gpu.lib.bppp_msm_basis(basb.h, vpp(dscb.data_ptr()), nb, inst, vpp(outs_b[1].ctypes.data)), "bppp_msm_basis"))
+        assert np.array_equal(outs_b[1], outs_b[0])
+        legs["registered_basis"] = {"ms": dtb * 1e3, "pairs_per_s": nb * inst / dtb, "window_bits": basb.window_bits, "table_bytes": basb.table_bytes}
+        tcb0 = time.perf_counter()
+        cwb, ctb = basb.enable_comb()
+        torch.cuda.synchronize()
+        comb_build = time.perf_counter() - tcb0
+        dtb = timed(lambda: gpu._check(gpu.lib.bppp_msm_basis(basb.h, vpp(dscb.data_ptr()), nb, inst, vpp(outs_b[2].ctypes.data)), "bppp_msm_basis"))
+        assert np.array_equal(outs_b[2], outs_b[0])
+        legs["registered_basis_comb"] = {"ms": dtb * 1e3, "pairs_per_s": nb * inst / dtb, "window_bits": cwb, "table_bytes": ctb, "table_build_ms": comb_build * 1e3}
+        basb.close()
+        fixed_batch = {"workload": f"{inst} MSMs of {nb} terms over one basis (the prover's commitments), results on the host", "routes": legs}
+        del dscb
+
     # throughput with several MSMs in flight (one context = one stream + one host thread each): the latency-bound stages of one
     # (bucket reduction, window combine, the host round trip) overlap the accumulate kernel of another.  Reported beside the
     # single-stream headline, whose per-kernel durations are what the roofline and the rocprof summaries refer to.
@@ -617,6 +661,8 @@ def main():
             out["msm_2_16"] = small
         if fixed is not None:
             out["msm_fixed_basis"] = fixed
+        if fixed_batch is not None:
+            out["msm_fixed_basis_batch"] = fixed_batch
         if concurrent is not None:
             out["concurrent"] = concurrent
         if host_call is not None:

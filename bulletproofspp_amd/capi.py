@@ -28,7 +28,7 @@ SYMBOLS = [
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
-    "bppp_basis_create", "bppp_basis_create_device", "bppp_basis_destroy", "bppp_basis_info", "bppp_msm_basis",
+    "bppp_basis_create", "bppp_basis_create_device", "bppp_basis_destroy", "bppp_basis_info", "bppp_msm_basis", "bppp_basis_enable_comb",
     "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_shape_of", "bppp_rp_digits", "bppp_hash_to_scalar", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_prove_batch",
 ]
 
@@ -115,6 +115,7 @@ def load_library() -> C.CDLL:
     lib.bppp_basis_destroy.restype = None
     lib.bppp_basis_info.argtypes = [vp, C.POINTER(sz), C.POINTER(i), C.POINTER(sz)]
     lib.bppp_msm_basis.argtypes = [vp, vp, sz, sz, vp]
+    lib.bppp_basis_enable_comb.argtypes = [vp, C.c_int, sz, vp, vp]
     lib.bppp_rp_create.argtypes = [vp, i, i, vp, sz, vp, sz, vp, sz, C.c_char_p, C.POINTER(vp)]
     lib.bppp_rp_destroy.argtypes = [vp]
     lib.bppp_rp_destroy.restype = None
@@ -453,6 +454,12 @@ class Basis:
             self.close()
         except Exception:
             pass
+
+    def enable_comb(self, window_bits: int = 0, budget_bytes: int = 32 << 30):
+        """bppp_basis_enable_comb: keep every multiple of every window; returns (window_bits, table_bytes)"""
+        c_, tb = C.c_int(0), C.c_size_t(0)
+        self.gpu._check(self.gpu.lib.bppp_basis_enable_comb(self.h, window_bits, budget_bytes, C.byref(c_), C.byref(tb)), "bppp_basis_enable_comb")
+        return int(c_.value), int(tb.value)
 
     def msm(self, d_scalars: int, n_terms: int, batch: int = 1):
         out = np.zeros((batch, 8), dtype=np.uint64)

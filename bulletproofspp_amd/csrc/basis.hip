@@ -8,6 +8,7 @@
 // over a registered basis has one bucket reduction instead of W and no window combine (csrc/msm.hip, table_stride != 0).  The
 // group element is the one `innerProduct` defines (src/Commitment.hs:325-335); only the route differs.
 #include <string.h>
+#include "comb.hpp"
 #include "ctx.hpp"
 #include "ec.hip.h"
 
@@ -49,6 +50,8 @@ struct bppp_basis {
   size_t n;
   int c, W;
   uint32_t *table;       // [W][n] affine
+  CombTable *comb;       // optional: every multiple of every window (bppp_basis_enable_comb), for many instances over a short basis
+  uint32_t *d_out; size_t out_cap;
 };
 
 extern "C" {
@@ -59,6 +62,8 @@ void bppp_basis_destroy(bppp_basis *h) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (h->table) hipFree(h->table);
+  if (h->d_out) hipFree(h->d_out);
+  if (h->comb) comb_destroy(h->comb);
   delete h;
   ctx_release(ctx);
 }
@@ -75,7 +80,7 @@ int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, i
   if ((uint64_t)W * n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "basis_create: windows * n must be < 2^31");
   hipSetDevice(ctx->device);
   bppp_basis *h = new bppp_basis();
-  h->ctx = ctx; ctx_retain(ctx); h->n = n; h->c = c; h->W = W; h->table = nullptr;
+  h->ctx = ctx; ctx_retain(ctx); h->n = n; h->c = c; h->W = W; h->table = nullptr; h->comb = nullptr; h->d_out = nullptr; h->out_cap = 0;
   auto fill = [&]() -> int {
     BPPP_HIP(ctx, hipMalloc(&h->table, (size_t)W * n * 64));
     k_basis_table<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream>>>((const uint32_t *)d_points_xy, (uint32_t)n, c, W, h->table);
@@ -117,7 +122,38 @@ int bppp_msm_basis(bppp_basis *h, const void *d_scalars, size_t n_terms, size_t 
   if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   if (n_terms > h->n) return fail(ctx, BPPP_ERR_ARG, "msm_basis: more terms than registered points");
   hipSetDevice(ctx->device);
+  if (h->comb && batch >= 64 && n_terms) {      // one wavefront per instance: pays once there are enough instances to fill the chip's SIMDs
+    if (!d_scalars || !out_xy) return fail(ctx, BPPP_ERR_ARG, "msm_basis: null argument");
+    if (batch > h->out_cap) {
+      BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (h->d_out) BPPP_HIP(ctx, hipFree(h->d_out));
+      h->d_out = nullptr; h->out_cap = 0;
+      BPPP_HIP(ctx, hipMalloc(&h->d_out, batch * 64));
+      h->out_cap = batch;
+    }
+    int rc = comb_msm(h->comb, (const uint32_t *)d_scalars, batch, h->d_out, ctx->stream, false, n_terms);
+    if (rc) return rc;
+    BPPP_HIP(ctx, hipMemcpyAsync(out_xy, h->d_out, batch * 64, hipMemcpyDeviceToHost, ctx->stream));
+    BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BPPP_OK;
+  }
   return msm_run_ex(ctx, d_scalars, h->table, n_terms, batch, 1, h->c, out_xy, h->n);
+}
+
+// Adds the comb table tab[w][i][d-1] = d 2^(c w) P_i (csrc/comb.hip) to a registered basis: bppp_msm_basis of >= 64 instances then
+// costs one mixed addition per non-zero digit and nothing else.  window_bits = 0: the widest window (<= 16) whose table fits
+// budget_bytes.  The table stays until the handle is destroyed; *table_bytes (may be NULL) reports its size.
+int bppp_basis_enable_comb(bppp_basis *h, int window_bits, size_t budget_bytes, int *window_bits_out, size_t *table_bytes) {
+  if (!h) return BPPP_ERR_ARG;
+  bppp_ctx *ctx = h->ctx;
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
+  if (!h->comb) {
+    int rc = comb_create(ctx, h->table, h->n, window_bits, budget_bytes, &h->comb);      // row 0 of the table is the basis itself
+    if (rc) { h->comb = nullptr; return rc; }
+  }
+  if (window_bits_out) *window_bits_out = h->comb->c;
+  if (table_bytes) *table_bytes = h->comb->bytes;
+  return BPPP_OK;
 }
 
 }  // extern "C"

@@ -68,11 +68,11 @@ BPPP_DI aff comb_aff(const CombRaw &r, bool neg) {
 // launch dispatches all heavy ones first, so the light ones fill the slots that free up instead of leaving a tail of heavy ones
 template <int WPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_comb_msm(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
-                                                 const uint32_t *__restrict__ scalars, uint32_t ninst, int heavy_first, uint32_t *__restrict__ out) {
+                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, int heavy_first, uint32_t *__restrict__ out) {
   const uint32_t lane = threadIdx.x, half = ninst >> 1;
   const uint32_t inst = !heavy_first ? blockIdx.x : blockIdx.x < half ? 2 * blockIdx.x : 2 * (blockIdx.x - half) + 1;
   const uint32_t mask = (1u << c) - 1u;
-  const uint32_t *sc = scalars + (size_t)inst * T * 8;
+  const uint32_t *sc = scalars + (size_t)inst * nterms * 8;       // the first nterms <= T registered points
   xyzz acc = xyzz_inf();
   CombRaw pend; pend.a = pend.b = pend.c = pend.d = make_uint4(0, 0, 0, 0);
   bool pend_ok = false, pend_neg = false;
@@ -87,10 +87,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   while (__any(live)) {
     if (live && w == W) {
       live = false;
-      while (k0 < T) {
+      while (k0 < nterms) {
         const uint32_t i = k0 + ((lane + 21u * k) & 63u);
         k0 += 64; k++;
-        if (i >= T) continue;
+        if (i >= nterms) continue;
         const fe s = fe_load(sc + (size_t)i * 8);
         if (fe_is_zero(s)) continue;
         fe t, tmp;
@@ -147,6 +147,7 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   auto size_of = [&](int cc) { return (size_t)((257 + cc - 1) / cc) * T * ((size_t)1 << (cc - 1)) * 64; };
   if (!c) { c = 16; while (c > 4 && size_of(c) > budget_bytes) c--; }
   if (c < 4 || c > 16) return fail(ctx, BPPP_ERR_ARG, "comb_create: window_bits must be in [4,16]");
+  if (!window_bits && size_of(c) > budget_bytes) return fail(ctx, BPPP_ERR_ARG, "comb_create: no window of 4 bits or more fits the budget (" + std::to_string(size_of(c) >> 20) + " MiB needed)");
   CombTable *t = new CombTable();
   t->ctx = ctx; ctx_retain(ctx); t->T = T; t->c = c; t->W = (257 + c - 1) / c; t->D = 1 << (c - 1); t->tab = nullptr; t->bytes = size_of(c);
   uint32_t *bases = nullptr;
@@ -164,8 +165,9 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   return BPPP_OK;
 }
 
-int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first) {
-  if (!t || !d_scalars || !d_out_aff || ninst >= (1u << 31)) return BPPP_ERR_ARG;
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first, size_t nterms) {
+  if (!t || !d_scalars || !d_out_aff || ninst >= (1u << 31) || nterms > t->T) return BPPP_ERR_ARG;
+  if (!nterms) nterms = t->T;
   if (!ninst) return BPPP_OK;
   CombK K; memset(&K, 0, sizeof K);
   for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
@@ -174,7 +176,7 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   if (const char *e = getenv("BPPP_COMB_WPE")) wpe = atoi(e);
   const dim3 grid((unsigned)ninst), block(64);
   const int hf = (heavy_first && !(ninst & 1)) ? 1 : 0;
-#define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)ninst, hf, d_out_aff)
+#define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, hf, d_out_aff)
   if (wpe <= 2) COMB_LAUNCH(2); else COMB_LAUNCH(3);
 #undef COMB_LAUNCH
   if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_msm: launch failed");

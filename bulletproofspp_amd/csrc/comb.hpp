@@ -20,7 +20,8 @@ struct CombTable {
 int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bits, size_t budget_bytes, CombTable **out);
 void comb_destroy(CombTable *t);
 // out[inst] = sum_i scalars[inst][i] * P_i for inst < ninst (canonical affine, infinity = zeros); scalars are canonical (< n),
-// [ninst][T] in HBM.  Asynchronous on `st`.  heavy_first: instances 2b / 2b + 1 are a heavy / light pair (dispatch order only).
-int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first = false);
+// [ninst][nterms] in HBM over the first nterms registered points (0 = all T).  Asynchronous on `st`.  heavy_first: instances
+// 2b / 2b + 1 are a heavy / light pair (dispatch order only).
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first = false, size_t nterms = 0);
 
 }  // namespace bppp

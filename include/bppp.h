@@ -91,6 +91,12 @@ int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, i
 void bppp_basis_destroy(bppp_basis *basis);
 int bppp_basis_info(const bppp_basis *basis, size_t *n, int *window_bits, size_t *table_bytes);
 int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, size_t batch, uint64_t *out_xy);
+/* For MANY instances over a SHORT basis (the prover's commitments: thousands of MSMs of ~775 terms over a setup's points) the handle can
+ * also hold every multiple of every window, tab[w][i][d-1] = d 2^(c w) P_i: bppp_msm_basis of >= 64 instances is then one mixed addition
+ * per non-zero signed c-bit digit into one accumulator — no sort, no buckets, no reduction, no doubling.  window_bits = 0 takes the widest
+ * window (<= 16) whose table fits budget_bytes (W * n * 2^(c-1) * 64 bytes: 27.6 GB for 774 points at c = 16, 4.1 GB at c = 13).  Same
+ * results bit for bit. */
+int bppp_basis_enable_comb(bppp_basis *basis, int window_bits, size_t budget_bytes, int *window_bits_out, size_t *table_bytes);
 
 /* ---- a7: SplitScalar.rationalReduceScalar (host) ------------------------------------------
  * Replaces rationalReduceScalar for `Prime p` (src/Commitment.hs:242-255, instance :269-288):

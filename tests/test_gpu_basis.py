@@ -67,6 +67,46 @@ def test_basis_many_small_instances(gpu, oracle_lib):
     bas.close()
 
 
+@pytest.mark.parametrize("c", [0, 4, 7, 11, 13])
+def test_basis_comb_equals_bucket_route_and_oracle(gpu, oracle_lib, c):
+    """bppp_basis_enable_comb (csrc/comb.hip: every multiple of every window stored, one mixed addition per non-zero digit): the same
+    group elements as the bucket route and the oracle, for several window widths, prefixes of the basis, an infinity point and a
+    repeated point in the basis, zero scalars, the scalars around n / 2 where the sign fold flips, sparse vectors (zeros on a
+    power-of-two pattern, as the argument's R scalars) and all-zero instances."""
+    n, batch = 150, 70
+    pts, rnd = _case(n, 21)
+    pts[9] = pts[8]                                    # the same point twice
+    bas = gpu.basis(points_to_array(pts), batch_hint=batch)
+    cc, tb = bas.enable_comb(window_bits=c, budget_bytes=64 << 20)
+    W = -(-257 // cc)
+    assert (c == 0 or cc == c) and tb == W * n * (1 << (cc - 1)) * 64 and (c != 0 or tb <= (64 << 20))      # the budget picks the width only when none is forced
+    for n_terms in (n, 64, 65, 3):
+        sc = [[rnd.randrange(O.N) for _ in range(n_terms)] for _ in range(batch)]
+        sc[0] = [0] * n_terms                                                        # an empty sum
+        sc[1] = [s_ if (i >> 1) & 1 else 0 for i, s_ in enumerate(sc[1])]            # zeros on every left half of level 1
+        sc[2] = [s_ if i & 1 else 0 for i, s_ in enumerate(sc[2])]
+        sc[3][0], sc[3][1], sc[3][2] = O.N - 1, (O.N + 1) // 2, (O.N - 1) // 2
+        sc[4] = [1] * n_terms
+        sc[5] = [rnd.randrange(16) for _ in range(n_terms)]                         # digits of a range proof: one non-zero window
+        sc[6] = [O.N - 1 - rnd.randrange(16) for _ in range(n_terms)]
+        d_s = gpu.to_device(np.concatenate([scalars_to_array(r) for r in sc]))
+        d_p = gpu.to_device(points_to_array(pts[:n_terms]))
+        try:
+            got = bas.msm(d_s, n_terms, batch)
+            plain = gpu.msm_batch_device(d_s, d_p, n_terms, batch, shared_points=True)
+        finally:
+            gpu.free(d_s); gpu.free(d_p)
+        assert got == plain and got[0] is None
+        for b in (1, 3, 4, 5, 6, batch - 1):
+            assert got[b] == oracle_lib.inner_product(list(zip(sc[b], pts[:n_terms])))
+    # a budget nothing fits into is refused
+    other = gpu.basis(points_to_array(pts))
+    with pytest.raises(Exception):
+        other.enable_comb(budget_bytes=1 << 10)
+    other.close()
+    bas.close()
+
+
 def test_basis_2_14_and_lifetime(gpu, oracle_lib):
     import ctypes
     n = 1 << 14
