@@ -210,6 +210,17 @@ __global__ void __launch_bounds__(64) k_nlb_tails(const uint32_t *__restrict__ s
   fe_store(S + NLB_ST_SX * 8, sX); fe_store(S + NLB_ST_SR * 8, sR);
   fe_store(sc + ((size_t)(2 * b) * T + T - 1) * 8, sX); fe_store(sc + ((size_t)(2 * b + 1) * T + T - 1) * 8, sR);
 }
+// start state from q and s of every proof where they lie in HBM: qs = (q, q^-1), st = (n = 1, l = 1, s, 0, 0)
+__global__ void __launch_bounds__(64) k_nlb_init_state(const uint32_t *__restrict__ q, const uint32_t *__restrict__ s, uint32_t batch, uint32_t *__restrict__ qs,
+                                                       uint32_t *__restrict__ stt) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= batch) return;
+  const fe qq = fe_load(q + (size_t)b * 8);
+  fe_store(qs + (size_t)b * 16, qq); fe_store(qs + (size_t)b * 16 + 8, fe_inv<1>(qq));
+  uint32_t *S = stt + (size_t)b * NLB_ST * 8;
+  fe_store(S + NLB_ST_NN * 8, fe_one()); fe_store(S + NLB_ST_LN * 8, fe_one()); fe_store(S + NLB_ST_S * 8, fe_load(s + (size_t)b * 8));
+  fe_store(S + NLB_ST_SX * 8, fe_zero()); fe_store(S + NLB_ST_SR * 8, fe_zero());
+}
 // the challenge e of a round: s' = s + e sX + (e^2 - 1) sR; the unscaled fold constants; n' = n q^-1, q' = q^2
 __global__ void __launch_bounds__(64) k_nlb_collapse_state(const uint32_t *__restrict__ es, uint32_t *__restrict__ qs, uint32_t *__restrict__ stt, uint32_t batch,
                                                            uint32_t n, uint32_t l, CollapseK *__restrict__ K, uint32_t *__restrict__ A) {
@@ -359,6 +370,12 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   o->q.resize(batch); o->qinv.resize(batch); o->nn.assign(batch, U256::one()); o->ln.assign(batch, U256::one());
   o->s.resize(batch); o->sX.resize(batch); o->sR.resize(batch);
   std::vector<uint64_t> hq, hs;
+  if (on_device && comb) {                   // fixed-basis mode with resident inputs: the state is set up by a kernel, nothing comes to the host
+    k_nlb_init_state<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)q, (const uint32_t *)s, (uint32_t)batch, o->qs, o->stt);
+    NLB_HIP(o, hipMemsetAsync(o->dK, 0, batch * sizeof(CollapseK), st));
+    NLB_HIP(o, hipGetLastError());
+    return BPPP_OK;
+  }
   if (on_device) {                           // the host keeps q, q^-1 and s of every proof (round bookkeeping): bring them over
     hq.resize(4 * batch); hs.resize(4 * batch);
     NLB_HIP(o, hipMemcpyAsync(hq.data(), q, batch * 32, hipMemcpyDeviceToHost, st));

@@ -24,6 +24,7 @@
 #include "modinv.hip.h"
 #include "rp_internal.hpp"
 #include "rphash.hip.h"
+#include "comb.hpp"
 #include "rpprove_dev.hpp"
 #include "trrp.hpp"
 
@@ -446,7 +447,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   uint32_t *in_sc = nullptr, *in_pt = nullptr, *dig = nullptr, *mul = nullptr, *mss = nullptr, *rnd = nullptr, *rows_dm_m = nullptr, *row_r = nullptr, *row_bl = nullptr,
            *ccbuf = nullptr, *invtab = nullptr, *aux = nullptr, *ch = nullptr, *es = nullptr, *tstart = nullptr, *ptbuf = nullptr, *a_s = nullptr, *a_q = nullptr,
            *a_lx = nullptr, *a_nx = nullptr, *p_sp = nullptr, *p_norm = nullptr, *p_cs = nullptr, *p_init = nullptr;
-  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr; uint32_t *d_resp = nullptr;
+  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr; uint32_t *d_resp = nullptr, *d_com = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv(pass ? rp->pwork : nullptr, rp->pwork_bytes);
     in_sc = cv.take<uint32_t>(B * nr * 24); in_pt = cv.take<uint32_t>(B * nr * 16);
@@ -458,8 +459,8 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     ptbuf = cv.take<uint32_t>(B * (2 + nr) * 16);
     a_s = cv.take<uint32_t>(B * 8); a_q = cv.take<uint32_t>(B * 8); a_lx = cv.take<uint32_t>(B * llen * 8); a_nx = cv.take<uint32_t>(B * nlen * 8);
     p_sp = cv.take<uint32_t>(B * 8); p_norm = cv.take<uint32_t>(B * nlen * 8); p_cs = cv.take<uint32_t>(B * llen * 8); p_init = cv.take<uint32_t>(B * (4 + nr) * 8);
-    text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<RppHdrs>(1 + k);
-    d_resp = cv.take<uint32_t>(k * B * 32 + 16);
+    text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<RppHdrs>(3 + k);
+    d_resp = cv.take<uint32_t>(k * B * 32 + 16); d_com = cv.take<uint32_t>(4 * B * 16 + 16);
     if (!pass) { int rc = rpp_ensure_pwork(rp, cv.off); if (rc) return rc; }
   }
   // ---- uploads: inputs, digits, multiplicities, prefixes
@@ -468,17 +469,96 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   BPPP_HIP(ctx, hipMemcpyAsync(mul, in.mul, B * nlen * 4, hipMemcpyHostToDevice, st));
   if (llen > 6) BPPP_HIP(ctx, hipMemcpyAsync(mss, in.mss, B * (llen - 6) * 4, hipMemcpyHostToDevice, st));
   if (in.prefix_len) BPPP_HIP(ctx, hipMemcpyAsync(prefix, in.prefix, B * in.prefix_len, hipMemcpyHostToDevice, st));
+  // fixed-basis mode (comb table in place): the whole proof is ONE stream of kernels — commitments stay on the device until the end,
+  // every oracle call reads its points where they lie, and the headers of all 3 + k oracle calls go up here
+  const bool stream_mode = rp->comb != nullptr && !getenv("BPPP_NLB_FOLD_POINTS");
   {
     std::vector<uint32_t> ts(B, tend);
     BPPP_HIP(ctx, hipMemcpyAsync(tstart, ts.data(), B * 4, hipMemcpyHostToDevice, st));
-    BPPP_HIP(ctx, hipStreamSynchronize(st));          // ts goes out of scope
+    std::vector<RppHdrs> hh(3 + k);
+    if (stream_mode) {
+      size_t np = 0;
+      const size_t add[3] = {2 + nr, 1, 1}; const int cnt[3] = {3, 3, 1}; const uint32_t first_slot[3] = {0, 3, 6};
+      for (size_t c = 0; c < 3 + k; c++) {
+        memset(&hh[c], 0, sizeof(RppHdrs));
+        np += c < 3 ? add[c] : 2;
+        for (int n = 1; n <= (c < 3 ? cnt[c] : 1); n++) {
+          const std::string hs = rp->tag + std::to_string(n) + std::to_string(np);
+          if (hs.size() > 64) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: oracle tag too long");
+          rp_pack_header(hs, hh[c].hdr_be[n - 1]); hh[c].hlen[n - 1] = (uint32_t)hs.size(); hh[c].slot[n - 1] = c < 3 ? first_slot[c] + (uint32_t)(n - 1) : 7u;
+        }
+      }
+      BPPP_HIP(ctx, hipMemcpyAsync(hdrs, hh.data(), (3 + k) * sizeof(RppHdrs), hipMemcpyHostToDevice, st));
+    }
+    BPPP_HIP(ctx, hipStreamSynchronize(st));          // ts, hh go out of scope
   }
+  auto oracle_dev = [&](const uint32_t *pts_dev, size_t m, size_t call, int count) {
+    k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), (m + 1) * 4, st>>>(pts_dev, (uint32_t)m, text, stride, tstart);
+    const uint64_t n = (uint64_t)B * count;
+    k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(hdrs + call, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
+  };
   { const uint64_t n = (uint64_t)B * D.nd; k_rpp_draws<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(prefix, (uint32_t)in.prefix_len, (uint32_t)B, D.nd, rnd); }
   { const uint64_t n = (uint64_t)B * T;
     k_rpp_rows_dm_m<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(D, tb->pos_kind, tb->pos_range, in_sc, dig, mul, mss, rnd, (uint32_t)B, rows_dm_m); }
   BPPP_HIP(ctx, hipGetLastError());
   int rc = rpp_commit_inputs(rp, in_sc, B * nr, in_pt); if (rc) return rc;
   BPPP_HIP(ctx, hipMemcpyAsync(out.input_coms, in_pt, B * nr * 64, hipMemcpyDeviceToHost, st));
+  if (stream_mode) {
+    const size_t lds2 = (2 * (INV_DIG + 256 + nr) + 128 + TRRP_MAX_SLOTS) * 32, lds3 = ((size_t)6 * 64 + nr + TRRP_MAX_SLOTS + 4) * 32;
+    if (lds2 > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges for the device prover");
+    if (lds2 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    if (lds3 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    auto comb = [&](const uint32_t *rows, size_t n, uint32_t *dst) -> int {
+      int r_ = comb_msm(rp->comb, rows, n, dst, st);
+      return r_ ? fail(ctx, r_, bppp_last_error(rp->comb->ctx)) : BPPP_OK;
+    };
+    uint32_t *c_dmm = d_com, *c_r = d_com + 2 * B * 16, *c_bl = d_com + 3 * B * 16;
+    // (e, x, r0) <- oracle ([dmCom, mCom] ++ nComs)   (TypedReciprocal.hs:412)
+    rc = comb(rows_dm_m, 2 * B, c_dmm); if (rc) return rc;
+    BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf, (2 + nr) * 64, c_dmm, 128, 128, B, hipMemcpyDeviceToDevice, st));
+    BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf + 32, (2 + nr) * 64, in_pt, nr * 64, nr * 64, B, hipMemcpyDeviceToDevice, st));
+    oracle_dev(ptbuf, 2 + nr, 0, 3);
+    k_rpp_phase2<<<dim3((unsigned)B), dim3(64), lds2, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_sym, tb->syms, in_sc, dig, rnd, ch, row_r, ccbuf, invtab);
+    // (q, x', r1) <- oracle [rCom]
+    rc = comb(row_r, B, c_r); if (rc) return rc;
+    oracle_dev(c_r, 1, 1, 3);
+    k_rpp_phase3<<<dim3((unsigned)B), dim3(64), lds3, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_coeff, tb->range_assumed, tb->syms, tb->cs_slot, tb->cs_sym,
+                                                            in_sc, dig, mul, rnd, ch, rows_dm_m, row_r, ccbuf, invtab, row_bl, aux);
+    // t <- oracle [blCom]; public constants and linear weights by the verifier's kernel; the combined witness
+    rc = comb(row_bl, B, c_bl); if (rc) return rc;
+    oracle_dev(c_bl, 1, 2, 1);
+    BPPP_HIP(ctx, hipGetLastError());
+    rc = bppp_trrp_public_device(rp->tabs, B, ch, a_q, p_sp, p_norm, p_cs, p_init); if (rc) return rc;
+    { const uint64_t n = (uint64_t)B * T;
+      k_rpp_combine<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(D, (uint32_t)B, ch, rows_dm_m, row_r, row_bl, aux, p_sp, p_norm, a_s, a_lx, a_nx); }
+    BPPP_HIP(ctx, hipGetLastError());
+    // proveBPM in lockstep (src/Bulletproof.hs:357-359): the start state taken where it lies in HBM, k rounds queued back to back
+    bppp_nlb *nlb = nullptr;
+    rc = nlb_create_impl(ctx, B, (const uint64_t *)a_s, (const uint64_t *)rp->d_g(), (const uint64_t *)a_q, (const uint64_t *)a_nx, (const uint64_t *)rp->d_G(), nlen,
+                         (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, rp->comb);
+    if (rc) return rc;
+    for (size_t round = 0; round < k && !rc; round++) {
+      uint32_t *xr_dev = d_resp + round * B * 32;
+      rc = nlb_round_commit_dev(nlb, xr_dev); if (rc) break;
+      oracle_dev(xr_dev, 2, 3 + round, 1);
+      if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: round kernels"); break; }
+      rc = nlb_round_collapse_dev(nlb, es);
+    }
+    // everything the files need comes back now: the four commitments, the 2k responses, the final witness
+    std::vector<uint64_t> hcom(4 * B * 8), hresp(k * B * 16);
+    if (!rc && (hipMemcpyAsync(hcom.data(), d_com, 4 * B * 64, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(hresp.data(), d_resp, k * B * 128, hipMemcpyDeviceToHost, st) != hipSuccess))
+      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: result download");
+    if (!rc) rc = bppp_nlb_get_witness(nlb, out.wit_norm, out.wit_lin, nullptr);        // synchronises the stream
+    bppp_nlb_destroy(nlb);
+    if (rc) return rc;
+    for (size_t b = 0; b < B; b++) {
+      memcpy(out.c_dm + 8 * b, &hcom[16 * b], 64); memcpy(out.c_m + 8 * b, &hcom[16 * b + 8], 64);
+      memcpy(out.c_r + 8 * b, &hcom[(2 * B + b) * 8], 64); memcpy(out.c_bl + 8 * b, &hcom[(3 * B + b) * 8], 64);
+      for (size_t round = 0; round < k; round++) memcpy(out.resp + (b * k + (k - 1 - round)) * 16, &hresp[(round * B + b) * 16], 128);   // responses LAST round first (:359)
+    }
+    return BPPP_OK;
+  }
   std::vector<uint64_t> com(2 * B * 8);
   rc = rpp_commit_rows(rp, rows_dm_m, 2 * B, com.data()); if (rc) return rc;            // synchronises
   for (size_t b = 0; b < B; b++) { memcpy(out.c_dm + 8 * b, &com[16 * b], 64); memcpy(out.c_m + 8 * b, &com[16 * b + 8], 64); }
@@ -540,36 +620,8 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   // ---- proveBPM in lockstep (src/Bulletproof.hs:357-359), the start state taken where it lies in HBM
   bppp_nlb *nlb = nullptr;
   rc = nlb_create_impl(ctx, B, (const uint64_t *)a_s, (const uint64_t *)rp->d_g(), (const uint64_t *)a_q, (const uint64_t *)a_nx, (const uint64_t *)rp->d_G(), nlen,
-                       (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, getenv("BPPP_NLB_FOLD_POINTS") ? nullptr : rp->comb);
+                       (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, nullptr);
   if (rc) return rc;
-  if (nlb_fixed_basis(nlb)) {
-    // fixed-basis mode: the k rounds are one stream of kernels — round scalars, comb MSM, transcript text, SHA-256, fold of the
-    // scalars — with the per-proof state in HBM; the host only queues them.  The oracle headers of all rounds go up first.
-    std::vector<RppHdrs> hh(k);
-    for (size_t round = 0; round < k; round++) {
-      memset(&hh[round], 0, sizeof(RppHdrs));
-      const std::string hs = rp->tag + "1" + std::to_string(npoints + 2 * (round + 1));
-      if (hs.size() > 64) { rc = fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: oracle tag too long"); break; }
-      rp_pack_header(hs, hh[round].hdr_be[0]); hh[round].hlen[0] = (uint32_t)hs.size(); hh[round].slot[0] = 7;
-    }
-    if (!rc && (hipMemcpyAsync(hdrs + 1, hh.data(), k * sizeof(RppHdrs), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: header upload");
-    for (size_t round = 0; round < k && !rc; round++) {
-      uint32_t *xr_dev = d_resp + round * B * 32;
-      rc = nlb_round_commit_dev(nlb, xr_dev); if (rc) break;
-      npoints += 2;
-      k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), 3 * 4, st>>>(xr_dev, 2u, text, stride, tstart);
-      k_rpp_hash<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(hdrs + 1 + round, 1u, (uint32_t)B, text, stride, tstart, tend, ch, es);
-      if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: round kernels"); break; }
-      rc = nlb_round_collapse_dev(nlb, es);
-    }
-    std::vector<uint64_t> hresp(k * B * 16);
-    if (!rc && (hipMemcpyAsync(hresp.data(), d_resp, k * B * 128, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: response download");
-    if (!rc)
-      for (size_t round = 0; round < k; round++)
-        for (size_t b = 0; b < B; b++) memcpy(out.resp + (b * k + (k - 1 - round)) * 16, &hresp[(round * B + b) * 16], 128);   // responses LAST round first (:359)
-  } else {
   std::vector<uint64_t> sX(B * 4), sR(B * 4), X(B * 8), R(B * 8), eh(B * 4), xr(B * 16);
   for (size_t round = 0; round < k && !rc; round++) {
     rc = bppp_nlb_round_commit(nlb, sX.data(), X.data(), sR.data(), R.data());
@@ -583,7 +635,6 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     rc = oracle(xr.data(), nullptr, 2, 1, slots); if (rc) break;
     if (hipMemcpyAsync(eh.data(), es, B * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: challenge download"); break; }
     rc = bppp_nlb_round_collapse(nlb, eh.data());
-  }
   }
   if (!rc) rc = bppp_nlb_get_witness(nlb, out.wit_norm, out.wit_lin, nullptr);
   bppp_nlb_destroy(nlb);
