@@ -141,7 +141,7 @@ int bppp_msm_basis(bppp_basis *h, const void *d_scalars, size_t n_terms, size_t 
 }
 
 // Adds the comb table tab[w][i][d-1] = d 2^(c w) P_i (csrc/comb.hip) to a registered basis: bppp_msm_basis of >= 64 instances then
-// costs one mixed addition per non-zero digit and nothing else.  window_bits = 0: the widest window (<= 16) whose table fits
+// costs one mixed addition per non-zero digit and nothing else.  window_bits = 0: the widest window (<= 18) whose table fits
 // budget_bytes.  The table stays until the handle is destroyed; *table_bytes (may be NULL) reports its size.
 int bppp_basis_enable_comb(bppp_basis *h, int window_bits, size_t budget_bytes, int *window_bits_out, size_t *table_bytes) {
   if (!h) return BPPP_ERR_ARG;

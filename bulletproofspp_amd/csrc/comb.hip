@@ -145,8 +145,8 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   hipSetDevice(ctx->device);
   int c = window_bits;
   auto size_of = [&](int cc) { return (size_t)((257 + cc - 1) / cc) * T * ((size_t)1 << (cc - 1)) * 64; };
-  if (!c) { c = 16; while (c > 4 && size_of(c) > budget_bytes) c--; }
-  if (c < 4 || c > 16) return fail(ctx, BPPP_ERR_ARG, "comb_create: window_bits must be in [4,16]");
+  if (!c) { c = 18; while (c > 4 && size_of(c) > budget_bytes) c--; }
+  if (c < 4 || c > 18) return fail(ctx, BPPP_ERR_ARG, "comb_create: window_bits must be in [4,18]");
   if (!window_bits && size_of(c) > budget_bytes) return fail(ctx, BPPP_ERR_ARG, "comb_create: no window of 4 bits or more fits the budget (" + std::to_string(size_of(c) >> 20) + " MiB needed)");
   CombTable *t = new CombTable();
   t->ctx = ctx; ctx_retain(ctx); t->T = T; t->c = c; t->W = (257 + c - 1) / c; t->D = 1 << (c - 1); t->tab = nullptr; t->bytes = size_of(c);

@@ -513,7 +513,7 @@ int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t 
 }
 }  // namespace bppp
 
-// the comb table of the setup's basis, built at the first large batch: the widest window (<= 16 bits) whose table fits the budget —
+// the comb table of the setup's basis, built at the first large batch: the widest window (<= 18 bits) whose table fits the budget —
 // 32 GB by default, BPPP_RP_COMB_GB to change it: 27.6 GB at 774 points (c = 16, built in ~0.3 s), 4.1 GB at c = 13 costs ~15 % more
 // additions; BPPP_RP_COMB_BITS forces a width, BPPP_RP_NO_COMB keeps the bucket route
 int rp_ensure_comb(bppp_rp *rp) {
