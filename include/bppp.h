@@ -94,7 +94,7 @@ int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, siz
 /* For MANY instances over a SHORT basis (the prover's commitments: thousands of MSMs of ~775 terms over a setup's points) the handle can
  * also hold every multiple of every window, tab[w][i][d-1] = d 2^(c w) P_i: bppp_msm_basis of >= 64 instances is then one mixed addition
  * per non-zero signed c-bit digit into one accumulator — no sort, no buckets, no reduction, no doubling.  window_bits = 0 takes the widest
- * window (<= 16) whose table fits budget_bytes (W * n * 2^(c-1) * 64 bytes: 27.6 GB for 774 points at c = 16, 4.1 GB at c = 13).  Same
+ * window (<= 18) whose table fits budget_bytes (W * n * 2^(c-1) * 64 bytes: 27.6 GB for 774 points at c = 16, 4.1 GB at c = 13).  Same
  * results bit for bit. */
 int bppp_basis_enable_comb(bppp_basis *basis, int window_bits, size_t budget_bytes, int *window_bits_out, size_t *table_bytes);
 
