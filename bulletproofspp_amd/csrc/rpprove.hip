@@ -570,7 +570,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).
   size_t split_min = 2048;
   if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
-  size_t comb_min = 256;
+  size_t comb_min = 1024;          // the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
   if (const char *e = getenv("BPPP_RP_COMB_MIN")) comb_min = (size_t)atol(e);
   if (batch >= comb_min && !rp->is_twin) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
   if (batch < split_min || batch < 2 || rp->is_twin || getenv("BPPP_RP_NO_SPLIT"))
