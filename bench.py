@@ -183,7 +183,7 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     # shares of one half (digits, half-GCDs of the argument's rounds, challenge round trips) fall under the kernels of the other.  The
     # one-context figure is reported beside `value`; both write the same bytes.
     single_context = None
-    if world == 1 and batch >= 2048:
+    if world == 1 and batch >= 4096:
         cf2, pf2 = np.zeros_like(cf), np.zeros_like(pf)
         os.environ["BPPP_RP_NO_SPLIT"] = "1"
         try:
@@ -201,11 +201,12 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
         assert np.array_equal(cf2, cf) and np.array_equal(pf2, pf), "one-context prover output differs"
         single_context = {"value": batch * prove_steps / qdt, "unit": "proofs/s", "ms_per_batch": qdt / prove_steps * 1e3}
     prove = {"metric": "range_proofs_proved_per_sec", "value": world * batch * prove_steps / pdt, "unit": "proofs/s", "ms_per_batch": pdt / prove_steps * 1e3,
-             "half_batches_in_flight": 2 if batch >= 2048 else 1, "single_context": single_context,
+             "half_batches_in_flight": 2 if batch >= 4096 else 1, "single_context": single_context,
              "batch_per_gpu": batch, "replicas": world, "shape": f"{shape}: {count} x 64-bit values per proof, nrmLen {nlen}, linLen {llen}, {k} rounds",
              "scope": "proveM of RangeProof (src/RangeProof.hs:93-97) end to end: host inputs in, the reference's commitments / proof files out; "
-                      "commitments, per-proof field algebra, randomness and SHA-256 transcripts on the GPU, digit extraction and the argument's "
-                      "half-GCDs on the host cores (bppp_rp_prove_batch)"}
+                      "every commitment a fixed-base comb MSM over the setup's basis, the argument's rounds without point folds, per-proof field algebra, "
+                      "randomness and SHA-256 transcripts on the GPU as one stream of kernels; digit extraction of the plain amounts on the host cores "
+                      "(bppp_rp_prove_batch)"}
 
     # ---- verify
     d_c = torch.from_numpy(cf).to(dev)

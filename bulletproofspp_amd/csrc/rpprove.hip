@@ -568,7 +568,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   // A large batch runs as TWO half-batches in flight, the second on a twin handle with its own context (stream, workspaces, host
   // thread): the proofs are independent, and the host shares of a half (digits, the argument's half-GCDs and round bookkeeping,
   // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).
-  size_t split_min = 2048;
+  size_t split_min = 4096;      // measured: 4096 proofs 91-93 ms split against 95-97 ms, but 2048 proofs (128by64) 109 ms split against 104 ms
   if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
   size_t comb_min = 1024;          // the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
   if (const char *e = getenv("BPPP_RP_COMB_MIN")) comb_min = (size_t)atol(e);
