@@ -522,8 +522,12 @@ int rp_ensure_comb(bppp_rp *rp) {
   if (const char *e = getenv("BPPP_RP_COMB_BITS")) c = atoi(e);
   size_t gb = 32;
   if (const char *e = getenv("BPPP_RP_COMB_GB")) gb = (size_t)std::max(1, atoi(e));
+  if (rp->comb_failed) return BPPP_OK;
   int rc = bppp::comb_create(rp->ctx, rp->d_basis, 1 + rp->st.llen + rp->st.nlen, c, gb << 30, &rp->comb);
-  if (rc) { rp->comb = nullptr; return rc; }
+  if (rc) {                                  // no room for the table (or no window fits the budget): the bucket route and the point-folding
+    rp->comb = nullptr; rp->comb_failed = true;   // argument serve the batch; the reason stays in bppp_last_error, the attempt is not repeated
+    return BPPP_OK;
+  }
   rp->comb_owned = true;
   return BPPP_OK;
 }
