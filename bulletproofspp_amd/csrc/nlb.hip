@@ -6,6 +6,12 @@
 // single proof is latency-bound; B proofs share the launches: 2B round commitments are ONE batched MSM (each proof's X and R
 // share that proof's basis), B x ceil(n/2) basis folds are ONE launch with per-proof reduced scalars, and the Fr vector work
 // is one workgroup per proof.  The bases diverge after the first collapse (different challenges), so they are stored per proof.
+//
+// Two routes.  The POINT-FOLDING route above is the general one (bppp_nlb_create; small range-proof batches).  With a comb table of
+// the starting basis attached (csrc/comb.hip; the range-proof prover's large batches) the argument runs in FIXED-BASIS mode: no
+// point is ever folded — the fold coefficients are multiplied into the scalars and every round commitment is a comb MSM over the
+// original points — and the per-proof round state (q, q^-1, n, l, s, sX, sR) lives in HBM, so a round is a stream of kernels
+// (nlb_round_commit_dev / nlb_round_collapse_dev; the bppp_nlb_round_* entry points wrap them).  Same group elements either way.
 #include <string.h>
 #include <atomic>
 #include <thread>

@@ -10,9 +10,11 @@
 //   encodeProof'                    src/RangeProof.hs:60-66, src/Encoding.hs:130-134
 // Work split: every group operation is on the device — the input commitments through a fixed-base window table of (g, H0, H1)
 // (k_rp_commit_inputs: B x #ranges three-term commitments in one launch), the four range-proof commitments of all proofs as
-// batched MSMs over the registered basis (2B, B, B instances of 1 + linLen + nrmLen terms), the argument through bppp_nlb_*.
-// The per-proof field algebra (O(nrmLen) multiplications per phase) and the transcript hashing (the CLI's shaOracle and
-// hashToScalar, app/Main.hs:64-87) run on the host cores in parallel ranges.
+// batched MSMs over the registered basis (2B, B, B instances of 1 + linLen + nrmLen terms; comb MSMs once the handle has its comb
+// table, csrc/comb.hip), the argument through csrc/nlb.hip.  The per-proof field algebra (O(nrmLen) multiplications per phase) and
+// the transcript hashing (the CLI's shaOracle and hashToScalar, app/Main.hs:64-87) run on the device (csrc/rpprove_dev.hip;
+// prove_batch_host below keeps the first version of this file, with both on the host cores, for comparison); the host extracts
+// the digits of the plain amounts, stages inputs in pinned memory and writes the files.  Large batches: two half-batches in flight.
 #include <string.h>
 #include <array>
 #include <atomic>

@@ -16,6 +16,10 @@
 //                       computes exactly makePublicConsts and makeBpCoeffs)
 //   k_rpp_text_prepend / k_rpp_hash   the transcript text of every proof (newest commitment first) grows at its FRONT; a challenge
 //                       is SHA-256 (header <> text from the current start)
+// rpp_device_prove has two flows over these kernels: with the handle's comb table in place (large batches) the whole proof is ONE
+// stream of kernels — commitments stay in HBM, every oracle call reads its points where they lie, the headers of all oracle calls
+// are uploaded up front, the argument runs in fixed-basis mode (csrc/nlb.hip) — and the host waits once, at the end; otherwise
+// (small batches) commitments go through the registered basis and the point-folding argument with a host round trip per step.
 // Fr arithmetic in 8x32 limbs (fe.hip.h); multiply / square as real functions (instruction-cache footprint, as in trrp.hip).
 #include <string.h>
 #include <string>
