@@ -128,10 +128,10 @@ int bppp_msm_basis(bppp_basis *h, const void *d_scalars, size_t n_terms, size_t 
       BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (h->d_out) BPPP_HIP(ctx, hipFree(h->d_out));
       h->d_out = nullptr; h->out_cap = 0;
-      BPPP_HIP(ctx, hipMalloc(&h->d_out, batch * 64));
+      BPPP_HIP(ctx, hipMalloc(&h->d_out, batch * 64 + comb_scratch_bytes(1023)));      // results, then room for the partial sums of any small launch
       h->out_cap = batch;
     }
-    int rc = comb_msm(h->comb, (const uint32_t *)d_scalars, batch, h->d_out, ctx->stream, false, n_terms);
+    int rc = comb_msm(h->comb, (const uint32_t *)d_scalars, batch, h->d_out, ctx->stream, false, n_terms, h->d_out + h->out_cap * 16, comb_scratch_bytes(1023));
     if (rc) return rc;
     BPPP_HIP(ctx, hipMemcpyAsync(out_xy, h->d_out, batch * 64, hipMemcpyDeviceToHost, ctx->stream));
     BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -68,9 +68,12 @@ BPPP_DI aff comb_aff(const CombRaw &r, bool neg) {
 // launch dispatches all heavy ones first, so the light ones fill the slots that free up instead of leaving a tail of heavy ones
 template <int WPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_comb_msm(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
-                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, int heavy_first, uint32_t *__restrict__ out) {
-  const uint32_t lane = threadIdx.x, half = ninst >> 1;
-  const uint32_t inst = !heavy_first ? blockIdx.x : blockIdx.x < half ? 2 * blockIdx.x : 2 * (blockIdx.x - half) + 1;
+                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, int heavy_first, uint32_t parts, uint32_t *__restrict__ partial,
+                                                 uint32_t *__restrict__ out) {
+  // parts > 1 (few instances): `parts` wavefronts share one instance — wavefront p takes the term groups p, p + parts, ... — and leave
+  // their sums in `partial` for k_comb_join; otherwise one wavefront per instance writes the result
+  const uint32_t lane = threadIdx.x, half = ninst >> 1, blk = blockIdx.x / parts, part = blockIdx.x % parts;
+  const uint32_t inst = !heavy_first ? blk : blk < half ? 2 * blk : 2 * (blk - half) + 1;
   const uint32_t mask = (1u << c) - 1u;
   const uint32_t *sc = scalars + (size_t)inst * nterms * 8;       // the first nterms <= T registered points
   xyzz acc = xyzz_inf();
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   // zero moves straight on to its next non-zero one instead of idling through the other lanes' 20 digit steps.  With vectors whose
   // zeros follow a power-of-two pattern in the index (the argument's R scalars vanish on every left half) every lane then has the
   // same share, and the wavefront of such an instance takes half the steps.
-  uint32_t k0 = 0, k = 0, sp[9];
+  uint32_t k0 = 64u * part, k = part, sp[9];
   int w = W;                                                   // w == W: this lane needs its next term
   bool neg = false, live = true;
   const uint32_t *ti = tab;
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
       live = false;
       while (k0 < nterms) {
         const uint32_t i = k0 + ((lane + 21u * k) & 63u);
-        k0 += 64; k++;
+        k0 += 64u * parts; k += parts;
         if (i >= nterms) continue;
         const fe s = fe_load(sc + (size_t)i * 8);
         if (fe_is_zero(s)) continue;
@@ -124,6 +127,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     pend = nxt; pend_ok = ok; pend_neg = nneg;
   }
   if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+  for (int dd = 32; dd >= 1; dd >>= 1) {
+    xyzz o = xyzz_shfl_down(acc, dd);
+    if ((int)lane + dd < 64) xyzz_add(acc, o);
+  }
+  if (lane == 0) {
+    if (parts > 1) xyzz_store(partial + ((size_t)inst * parts + part) * XYZZ_WORDS, acc);
+    else aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
+  }
+}
+// the partial sums of an instance (parts <= 64): one wavefront adds them and normalises
+__global__ void __launch_bounds__(64) k_comb_join(const uint32_t *__restrict__ partial, uint32_t parts, uint32_t *__restrict__ out) {
+  const uint32_t inst = blockIdx.x, lane = threadIdx.x;
+  xyzz acc = lane < parts ? xyzz_load(partial + ((size_t)inst * parts + lane) * XYZZ_WORDS) : xyzz_inf();
   for (int dd = 32; dd >= 1; dd >>= 1) {
     xyzz o = xyzz_shfl_down(acc, dd);
     if ((int)lane + dd < 64) xyzz_add(acc, o);
@@ -165,7 +181,8 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   return BPPP_OK;
 }
 
-int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first, size_t nterms) {
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first, size_t nterms, uint32_t *d_scratch,
+             size_t scratch_bytes) {
   if (!t || !d_scalars || !d_out_aff || ninst >= (1u << 31) || nterms > t->T) return BPPP_ERR_ARG;
   if (!nterms) nterms = t->T;
   if (!ninst) return BPPP_OK;
@@ -174,11 +191,20 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   // wavefronts per SIMD the register allocation aims at: 2 (225 VGPRs) measured 2 % ahead of 3 (168); 4 (128) spills and is 2.4 x slower
   int wpe = 2;
   if (const char *e = getenv("BPPP_COMB_WPE")) wpe = atoi(e);
-  const dim3 grid((unsigned)ninst), block(64);
+  // few instances: several wavefronts per instance (up to one per group of 64 terms), so that a launch is ~1024 wavefronts wide and
+  // its depth is a few additions instead of nterms / 64 x W; needs the caller's scratch for the partial sums
+  uint32_t parts = 1;
+  const uint32_t groups = (uint32_t)((nterms + 63) / 64);
+  if (d_scratch && ninst < 1024 && groups > 1) {
+    parts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((1024 + ninst - 1) / ninst));
+    while (parts > 1 && (size_t)ninst * parts * XYZZ_WORDS * 4 > scratch_bytes) parts--;
+  }
+  const dim3 grid((unsigned)(ninst * parts)), block(64);
   const int hf = (heavy_first && !(ninst & 1)) ? 1 : 0;
-#define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, hf, d_out_aff)
+#define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, hf, parts, d_scratch, d_out_aff)
   if (wpe <= 2) COMB_LAUNCH(2); else COMB_LAUNCH(3);
 #undef COMB_LAUNCH
+  if (parts > 1) k_comb_join<<<dim3((unsigned)ninst), dim3(64), 0, st>>>(d_scratch, parts, d_out_aff);
   if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_msm: launch failed");
   return BPPP_OK;
 }

@@ -275,7 +275,7 @@ struct bppp_nlb {
   uint32_t *sc, *sums, *qs;
   CollapseK *dK;
   const bppp::CombTable *comb; // fixed-basis mode: comb over [g | lin | norm]; the points are never folded (P[] is not allocated)
-  uint32_t *coefn, *coefl, *full, *dA, *d_out, *stt, *d_es;   // stt: per-proof round state in HBM (k_nlb_tails / k_nlb_collapse_state)
+  uint32_t *coefn, *coefl, *full, *dA, *d_out, *stt, *d_es, *cscratch;   // stt: per-proof round state in HBM (k_nlb_tails / k_nlb_collapse_state)
   uint32_t folds;              // completed folds (the level shift of an original index)
   int cur;
   std::vector<U256> q, qinv, nn, ln, s, sX, sR;
@@ -296,7 +296,7 @@ void bppp_nlb_destroy(bppp_nlb *o) {
   hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(o->x[k]); hipFree(o->lx[k]); hipFree(o->lc[k]); hipFree(o->P[k]); }
   hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK);
-  hipFree(o->coefn); hipFree(o->coefl); hipFree(o->full); hipFree(o->dA); hipFree(o->d_out); hipFree(o->stt); hipFree(o->d_es);
+  hipFree(o->coefn); hipFree(o->coefl); hipFree(o->full); hipFree(o->dA); hipFree(o->d_out); hipFree(o->stt); hipFree(o->d_es); hipFree(o->cscratch);
   delete o;
   ctx_release(ctx);
 }
@@ -332,7 +332,7 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   o->cap = evb(nlen) + evb(llen) + 1; o->xstride = evb(nlen) + 2; o->lstride = evb(llen) + 2;
   for (int k = 0; k < 2; k++) { o->x[k] = o->lx[k] = o->lc[k] = o->P[k] = nullptr; }
   o->sc = o->sums = o->qs = nullptr; o->dK = nullptr;
-  o->comb = comb; o->coefn = o->coefl = o->full = o->dA = o->d_out = o->stt = o->d_es = nullptr; o->folds = 0;
+  o->comb = comb; o->coefn = o->coefl = o->full = o->dA = o->d_out = o->stt = o->d_es = o->cscratch = nullptr; o->folds = 0;
   bool bad = false;
   for (int k = 0; k < 2; k++) {
     bad |= hipMalloc(&o->x[k], batch * o->xstride * 32) != hipSuccess || hipMalloc(&o->lx[k], batch * o->lstride * 32) != hipSuccess;
@@ -345,6 +345,7 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
     bad |= hipMalloc(&o->coefn, batch * std::max<size_t>(nlen, 1) * 32) != hipSuccess || hipMalloc(&o->coefl, batch * std::max<size_t>(llen, 1) * 32) != hipSuccess;
     bad |= hipMalloc(&o->full, 2 * batch * Tc * 32) != hipSuccess || hipMalloc(&o->dA, batch * 64) != hipSuccess || hipMalloc(&o->d_out, 2 * batch * 64) != hipSuccess;
     bad |= hipMalloc(&o->stt, batch * NLB_ST * 32) != hipSuccess || hipMalloc(&o->d_es, batch * 32) != hipSuccess;
+    if (comb_scratch_bytes(2 * batch)) bad |= hipMalloc(&o->cscratch, comb_scratch_bytes(2 * batch)) != hipSuccess;
   }
   if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
   hipStream_t st = ctx->stream;
@@ -431,7 +432,7 @@ int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR) {
   k_nlb_expand<<<dim3((Tc + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds, o->coefn, o->coefl, (uint32_t)o->n0,
                                                                                 (uint32_t)o->l0, o->full);
   NLB_HIP(o, hipGetLastError());
-  int rc = comb_msm(o->comb, o->full, 2 * B, d_XR, st, true);
+  int rc = comb_msm(o->comb, o->full, 2 * B, d_XR, st, true, 0, o->cscratch, comb_scratch_bytes(2 * B));
   if (rc) return fail(ctx, rc, bppp_last_error(o->comb->ctx));
   return BPPP_OK;
 }

@@ -81,7 +81,7 @@ struct bppp_rp {
   bppp_rp *twin = nullptr; bppp_ctx *twin_ctx = nullptr; bool is_twin = false;
   // fixed-base comb over [g | H | G] (csrc/comb.hip): the range-proof commitments and the argument's round commitments of large
   // batches; the twin handle uses its parent's table
-  bppp::CombTable *comb = nullptr; bool comb_owned = false, comb_failed = false;
+  bppp::CombTable *comb = nullptr; bool comb_owned = false, comb_failed = false; size_t proved_total = 0;
   uint32_t *d_comb_out = nullptr; size_t comb_out_rows = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
   void *work = nullptr; size_t work_bytes = 0;

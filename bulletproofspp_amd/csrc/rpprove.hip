@@ -507,7 +507,7 @@ int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t 
     BPPP_HIP(ctx, hipMalloc(&rp->d_comb_out, nrows * 64));
     rp->comb_out_rows = nrows;
   }
-  int rc = comb_msm(rp->comb, d_rows, nrows, rp->d_comb_out, ctx->stream);
+  int rc = comb_msm(rp->comb, d_rows, nrows, rp->d_comb_out, ctx->stream);      // one wavefront per instance (the fold route's small batches)
   if (rc) return fail(ctx, rc, bppp_last_error(rp->comb->ctx));
   BPPP_HIP(ctx, hipMemcpyAsync(host_out, rp->d_comb_out, nrows * 64, hipMemcpyDeviceToHost, ctx->stream));
   BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -578,7 +578,12 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
   size_t comb_min = 1024;          // the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
   if (const char *e = getenv("BPPP_RP_COMB_MIN")) comb_min = (size_t)atol(e);
-  if (batch >= comb_min && !rp->is_twin) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
+  // ... or one that has proved that many proofs in smaller batches: with the table in place every batch size is faster (one 64by64 proof:
+  // 12 ms against 22 ms; 256: 22 against 48)
+  if (!rp->is_twin) {
+    rp->proved_total += batch;
+    if (batch >= comb_min || rp->proved_total >= comb_min) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
+  }
   if (batch < split_min || batch < 2 || rp->is_twin || getenv("BPPP_RP_NO_SPLIT"))
     return prove_batch_one(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
   { int rc = rp_ensure_twin(rp); if (rc) return rc; }

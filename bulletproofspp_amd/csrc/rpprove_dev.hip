@@ -451,7 +451,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   uint32_t *in_sc = nullptr, *in_pt = nullptr, *dig = nullptr, *mul = nullptr, *mss = nullptr, *rnd = nullptr, *rows_dm_m = nullptr, *row_r = nullptr, *row_bl = nullptr,
            *ccbuf = nullptr, *invtab = nullptr, *aux = nullptr, *ch = nullptr, *es = nullptr, *tstart = nullptr, *ptbuf = nullptr, *a_s = nullptr, *a_q = nullptr,
            *a_lx = nullptr, *a_nx = nullptr, *p_sp = nullptr, *p_norm = nullptr, *p_cs = nullptr, *p_init = nullptr;
-  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr; uint32_t *d_resp = nullptr, *d_com = nullptr;
+  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr; uint32_t *d_resp = nullptr, *d_com = nullptr, *cscratch = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv(pass ? rp->pwork : nullptr, rp->pwork_bytes);
     in_sc = cv.take<uint32_t>(B * nr * 24); in_pt = cv.take<uint32_t>(B * nr * 16);
@@ -465,6 +465,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     p_sp = cv.take<uint32_t>(B * 8); p_norm = cv.take<uint32_t>(B * nlen * 8); p_cs = cv.take<uint32_t>(B * llen * 8); p_init = cv.take<uint32_t>(B * (4 + nr) * 8);
     text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<RppHdrs>(3 + k);
     d_resp = cv.take<uint32_t>(k * B * 32 + 16); d_com = cv.take<uint32_t>(4 * B * 16 + 16);
+    cscratch = cv.take<uint32_t>(std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B)) / 4 + 16);
     if (!pass) { int rc = rpp_ensure_pwork(rp, cv.off); if (rc) return rc; }
   }
   // ---- uploads: inputs, digits, multiplicities, prefixes
@@ -476,6 +477,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   // fixed-basis mode (comb table in place): the whole proof is ONE stream of kernels — commitments stay on the device until the end,
   // every oracle call reads its points where they lie, and the headers of all 3 + k oracle calls go up here
   const bool stream_mode = rp->comb != nullptr && !getenv("BPPP_NLB_FOLD_POINTS");
+  const size_t cscratch_bytes = std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B));
   {
     std::vector<uint32_t> ts(B, tend);
     BPPP_HIP(ctx, hipMemcpyAsync(tstart, ts.data(), B * 4, hipMemcpyHostToDevice, st));
@@ -513,7 +515,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     if (lds2 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (lds3 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     auto comb = [&](const uint32_t *rows, size_t n, uint32_t *dst) -> int {
-      int r_ = comb_msm(rp->comb, rows, n, dst, st);
+      int r_ = comb_msm(rp->comb, rows, n, dst, st, false, 0, cscratch, cscratch_bytes);
       return r_ ? fail(ctx, r_, bppp_last_error(rp->comb->ctx)) : BPPP_OK;
     };
     uint32_t *c_dmm = d_com, *c_r = d_com + 2 * B * 16, *c_bl = d_com + 3 * B * 16;

@@ -366,7 +366,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
  * Outputs are the reference's files: coms_files [batch][coms_bytes], proof_files [batch][proof_bytes].  Every commitment is
  * computed on the device (input commitments through a fixed-base table of g, H0, H1; the four range-proof commitments of all
  * proofs and the round commitments of the argument), and so are the per-proof field algebra, the randomness and the transcript
- * hashing; the host cores extract the digits of the plain amounts.  MEMORY: at the first batch of 1024 proofs or more (BPPP_RP_COMB_MIN) the handle
+ * hashing; the host cores extract the digits of the plain amounts.  MEMORY: at the first batch of 1024 proofs or more, or once it has proved that many in smaller batches (BPPP_RP_COMB_MIN), the handle
  * builds a fixed-base comb table over the setup's basis [g | H | G] and keeps it until it is destroyed — the widest window (<= 18
  * bits) whose table fits 32 GB: c = 16, 27.6 GB for the 774 points of 64by64, built in ~0.3 s (BPPP_RP_COMB_GB=<GB> changes the budget:
  * 64 GB (c = 17) measured 1 % faster, 128 GB (c = 18) 5 % — the gathers over a larger table cost most of what the fewer additions save;
