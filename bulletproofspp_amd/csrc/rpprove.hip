@@ -157,6 +157,28 @@ void oracle(const std::string &tag, PState &ps, const uint64_t *const *pts, size
   }
 }
 
+}  // namespace
+namespace bppp {
+// the same oracle for the device prover's small batches (csrc/rpprove_dev.hip): `groups` / `npoints` are one proof's transcript so far,
+// pts [m][8] its new commitments; out[count][4].  A host core hashes a 64by64 transcript in ~50 us; one GPU lane needs ~600 us.
+void rpp_host_oracle(const std::string &tag, std::vector<std::string> &groups, size_t &npoints, const uint64_t *pts, size_t m, int count, uint64_t *out) {
+  std::string g;
+  g.reserve(m * 160);
+  for (size_t i = 0; i < m; i++) point_text(g, pts + 8 * i);
+  groups.push_back(std::move(g));
+  npoints += m;
+  for (int n = 1; n <= count; n++) {
+    Sha256 h;
+    const std::string hdr = tag + std::to_string(n) + std::to_string(npoints);
+    h.update(hdr.data(), hdr.size());
+    for (size_t k = groups.size(); k-- > 0;) h.update(groups[k].data(), groups[k].size());
+    uint32_t d[8];
+    h.finish(d);
+    digest_to_fr(d).store(out + 4 * (n - 1));
+  }
+}
+}  // namespace bppp
+namespace {
 // witnessTRRP (TypedReciprocal.hs:372-389) + makePhase1s (:133-161) + getDsMs (:74-80): fills d, mi, pv, ms_shared
 bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds) {
   const size_t nr = st.rds.size();

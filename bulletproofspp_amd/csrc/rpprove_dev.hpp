@@ -2,6 +2,8 @@
 // commitments, encoding; the host-algebra reference path) and csrc/rpprove_dev.hip (field algebra and transcript on the device).
 #pragma once
 #include <stddef.h>
+#include <string>
+#include <vector>
 #include <stdint.h>
 #include "rp_internal.hpp"
 
@@ -34,6 +36,7 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
                     size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out, bool on_device,
                     const struct CombTable *comb);
 
+void rpp_host_oracle(const std::string &tag, std::vector<std::string> &groups, size_t &npoints, const uint64_t *pts, size_t m, int count, uint64_t *out);   // csrc/rpprove.hip
 bool nlb_fixed_basis(const bppp_nlb *o);
 int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR);
 int nlb_round_collapse_dev(bppp_nlb *o, const uint32_t *d_es);
