@@ -128,6 +128,12 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
     try:
         assert nat.prove_batch(inputs, prefixes) == got
         assert nat.prove_batch(inputs[:3], prefixes[:3]) == got[:3]      # the table is kept by the handle across batches
+        # (up to 8 proofs the oracle of that route runs on the host; with it on the device, as for larger batches: the same bytes)
+        os.environ["BPPP_RP_HOST_ORACLE_MAX"] = "0"
+        try:
+            assert nat.prove_batch(inputs, prefixes) == got
+        finally:
+            del os.environ["BPPP_RP_HOST_ORACLE_MAX"]
     finally:
         del os.environ["BPPP_RP_COMB_MIN"]
     # ... and with the table in place the point-folding route of the argument is still there (the general bppp_nlb_* entry points use it)
