@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) k_nlb_init_state(const uint32_t *__restric
   const uint32_t b = blockIdx.x * 64 + threadIdx.x;
   if (b >= batch) return;
   const fe qq = fe_load(q + (size_t)b * 8);
-  fe_store(qs + (size_t)b * 16, qq); fe_store(qs + (size_t)b * 16 + 8, fe_inv<1>(qq));
+  fe_store(qs + (size_t)b * 16, qq); fe_store(qs + (size_t)b * 16 + 8, fe_modinv<1>(qq));      // division steps (modinv.hip.h): ~14 k instructions against ~340 k of the Fermat chain
   uint32_t *S = stt + (size_t)b * NLB_ST * 8;
   fe_store(S + NLB_ST_NN * 8, fe_one()); fe_store(S + NLB_ST_LN * 8, fe_one()); fe_store(S + NLB_ST_S * 8, fe_load(s + (size_t)b * 8));
   fe_store(S + NLB_ST_SX * 8, fe_zero()); fe_store(S + NLB_ST_SR * 8, fe_zero());
