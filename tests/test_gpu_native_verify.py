@@ -162,6 +162,37 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
     nat.close()
 
 
+def test_native_prover_routes_agree_over_batch_sizes(gpu):
+    """The two routes of the library's prover — point-folding argument + bucket MSMs, and fixed-basis mode (comb table, stream of
+    kernels, several wavefronts per instance when the launch is small, host oracle up to 8 proofs, two half-batches in flight) — on
+    batch sizes around every internal boundary (1, the host-oracle limit, 64-lane groups, odd splits): byte-identical files."""
+    st = _setup(gpu, False)
+    rnd = random.Random(99)
+    sizes = [1, 2, 3, 8, 9, 31, 64, 65, 130]
+    nmax = max(sizes)
+    inputs = [[(rnd.randrange(256), 0, rnd.randrange(O.N)), (10 + rnd.randrange(256), 0, rnd.randrange(O.N)), (rnd.randrange(2**64), 0, rnd.randrange(O.N)),
+               (rnd.randrange(100), 0, rnd.randrange(O.N))] for _ in range(nmax)]
+    prefixes = [b"routes %04d" % b for b in range(nmax)]
+    fold = RP.NativeRangeProofs(gpu, st)
+    want = fold.prove_batch(inputs, prefixes)                       # below the comb threshold: the point-folding route
+    assert fold.verify_batch([c for c, _ in want], [p for _, p in want], b"\x21" * 32)
+    fold.close()
+    nat = RP.NativeRangeProofs(gpu, st)
+    os.environ["BPPP_RP_COMB_MIN"] = "1"; os.environ["BPPP_RP_COMB_BITS"] = "7"
+    try:
+        for n in sizes:
+            assert nat.prove_batch(inputs[:n], prefixes[:n]) == want[:n], n
+        os.environ["BPPP_RP_SPLIT_MIN"] = "2"
+        try:
+            for n in (2, 9, 65, 130):
+                assert nat.prove_batch(inputs[:n], prefixes[:n]) == want[:n], n
+        finally:
+            del os.environ["BPPP_RP_SPLIT_MIN"]
+    finally:
+        del os.environ["BPPP_RP_COMB_MIN"]; del os.environ["BPPP_RP_COMB_BITS"]
+    nat.close()
+
+
 def _example_setup(gpu, name, typed_override=None):
     from test_rangeproof import EXAMPLES
     schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
