@@ -136,6 +136,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     else aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
   }
 }
+// MANY instances of a FEW terms each (the prover's input commitments v g + ty H0 + bl H1: batch x #values instances over the first
+// three registered points): one LANE per instance walks its terms and digits; zero scalars and zero digits cost nothing
+__global__ void __launch_bounds__(64) k_comb_lanes(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
+                                                   const uint32_t *__restrict__ scalars, uint32_t nterms, uint64_t ninst, uint32_t *__restrict__ out) {
+  const uint64_t inst = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (inst >= ninst) return;
+  const uint32_t mask = (1u << c) - 1u;
+  xyzz acc = xyzz_inf();
+  for (uint32_t i = 0; i < nterms; i++) {
+    const fe s = fe_load(scalars + (inst * nterms + i) * 8);
+    if (fe_is_zero(s)) continue;
+    fe t, tmp;
+    raw_sub(t, fr_modulus(), s);
+    const bool neg = raw_sub(tmp, t, s) != 0;
+    uint32_t sp[9];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
+    sp[8] = (uint32_t)cy + K.k[8];
+    const uint32_t *ti = tab + (size_t)i * D * 16;
+#pragma unroll 1
+    for (int w = 0; w < W; w++) {
+      const int d = (int)(sp[0] & mask) - (int)D;
+#pragma unroll
+      for (int q = 0; q < 8; q++) sp[q] = (sp[q] >> c) | (sp[q + 1] << (32 - c));
+      sp[8] >>= c;
+      if (d) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint4 *e = (const uint4 *)(ti + ((size_t)w * T * D + (mag - 1)) * 16);
+        CombRaw r; r.a = e[0]; r.b = e[1]; r.c = e[2]; r.d = e[3];
+        xyzz_madd(acc, comb_aff(r, (d < 0) != neg));
+      }
+    }
+  }
+  aff_store(out + inst * 16, xyzz_to_aff(acc));
+}
+
 // the partial sums of an instance (parts <= 64): one wavefront adds them and normalises
 __global__ void __launch_bounds__(64) k_comb_join(const uint32_t *__restrict__ partial, uint32_t parts, uint32_t *__restrict__ out) {
   const uint32_t inst = blockIdx.x, lane = threadIdx.x;
@@ -178,6 +215,16 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return bail("comb_create: table kernels failed");
   hipFree(bases);
   *out = t;
+  return BPPP_OK;
+}
+
+int comb_lanes(const CombTable *t, const uint32_t *d_scalars, size_t nterms, size_t ninst, uint32_t *d_out_aff, hipStream_t st) {
+  if (!t || !d_scalars || !d_out_aff || !nterms || nterms > t->T) return BPPP_ERR_ARG;
+  if (!ninst) return BPPP_OK;
+  CombK K; memset(&K, 0, sizeof K);
+  for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
+  k_comb_lanes<<<dim3((unsigned)((ninst + 63) / 64)), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint64_t)ninst, d_out_aff);
+  if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_lanes: launch failed");
   return BPPP_OK;
 }
 

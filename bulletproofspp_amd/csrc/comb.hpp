@@ -26,6 +26,8 @@ void comb_destroy(CombTable *t);
 // there (160 B per wavefront; comb_scratch_bytes(ninst) is enough); without it a small launch is one wavefront per instance.
 int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first = false, size_t nterms = 0,
              uint32_t *d_scratch = nullptr, size_t scratch_bytes = 0);
+// many instances of a few terms each over the FIRST nterms registered points, one lane per instance: d_scalars [ninst][nterms]
+int comb_lanes(const CombTable *t, const uint32_t *d_scalars, size_t nterms, size_t ninst, uint32_t *d_out_aff, hipStream_t st);
 inline size_t comb_scratch_bytes(size_t ninst) { return ninst < 1024 ? (size_t)(1024 + 64 * ninst) * 160 : 0; }
 
 }  // namespace bppp

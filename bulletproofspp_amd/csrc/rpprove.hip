@@ -515,6 +515,8 @@ namespace bppp {
 int rpp_ensure_pwork(bppp_rp *rp, size_t bytes) { return ensure_pwork(rp, bytes); }
 int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *d_out) {
   bppp_ctx *ctx = rp->ctx;
+  // g, H0, H1 are the first three points of the registered basis: with its comb table a commitment is <= 3 x 17 additions, not 3 x 64
+  if (rp->comb) { int rc = comb_lanes(rp->comb, d_in_sc, FB_BASES, n, d_out, ctx->stream); return rc ? fail(ctx, rc, bppp_last_error(rp->comb->ctx)) : BPPP_OK; }
   k_rp_commit_inputs<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream>>>(rp->d_fixed, d_in_sc, (uint64_t)n, d_out);
   BPPP_HIP(ctx, hipGetLastError());
   return BPPP_OK;
