@@ -23,6 +23,7 @@
 // The same file holds the setup handle (`bppp_rp`: ranges, layout, basis resident in HBM) and, further down, the batch prover.
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ctx.hpp"
 #include "ec.hip.h"
@@ -433,6 +434,65 @@ int rp_ensure_twin(bppp_rp *rp) {
   rp->twin->is_twin = true;
   return BPPP_OK;
 }
+
+// ---- the verifier's oracle on the HOST, for a handful of proofs: one GPU lane walks the ~160 SHA-256 blocks of a 64by64 transcript
+// in ~0.8 ms whatever the batch size; a host core hashes the same 11 KB in ~50 us.  Same inputs and outputs as k_rp_text + k_rp_hash:
+// the decoded points of proof b (an undecodable one reads as "00", like on the device), the 7 + k challenges, the weight rho_b.
+namespace {
+void host_dec_append(std::string &out, U256 v) {
+  char buf[80];
+  int n = 0;
+  if (v.is_zero()) { out.push_back('0'); return; }
+  while (!v.is_zero()) {
+    uint64_t rem = 0;
+    v = bppp_rps::u_div64(v, 10000000000000000000ull, &rem);
+    const bool last = v.is_zero();
+    for (int k = 0; k < 19 && (rem || !last); k++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; }
+  }
+  while (n) out.push_back(buf[--n]);
+}
+U256 host_digest_to_fr(const uint32_t h[8]) {
+  uint32_t v[8];
+  sha256_digest_to_limbs(h, v);
+  U256 r;
+  for (int i = 0; i < 4; i++) r.w[i] = ((uint64_t)v[2 * i + 1] << 32) | v[2 * i];
+  return bppp_rps::u_mod_n(r);
+}
+// init [4 + nr][8], resp [2k][8] (u64 limbs as downloaded); ch_out [7][4], es_out [k][4], rho_out [4]
+void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, const uint8_t seed[32], uint64_t b_index, uint64_t *ch_out, uint64_t *es_out,
+                          uint64_t *rho_out) {
+  const uint32_t k = rp->D.k, nr = rp->D.nr, npts = 2 * k + 4 + nr;
+  std::vector<std::string> txt(npts);
+  for (uint32_t t = 0; t < npts; t++) {
+    const uint64_t *p = t < 2 * k ? resp + (size_t)t * 8 : init + (size_t)(t - 2 * k) * 8;
+    host_dec_append(txt[t], U256::load(p)); host_dec_append(txt[t], U256::load(p + 4));
+  }
+  auto one = [&](uint32_t n, uint32_t count, uint32_t start, uint64_t *out) {
+    Sha256 h;
+    const std::string hdr = rp->tag + std::to_string(n) + std::to_string(count);
+    h.update(hdr.data(), hdr.size());
+    for (uint32_t t = start; t < npts; t++) h.update(txt[t].data(), txt[t].size());
+    uint32_t d[8];
+    h.finish(d);
+    host_digest_to_fr(d).store(out);
+  };
+  for (uint32_t n = 1; n <= 3; n++) one(n, 2 + nr, 2 * k + 2, ch_out + 4 * (n - 1));          // e, x, r0        (the order of rp_build_plan)
+  for (uint32_t n = 1; n <= 3; n++) one(n, 3 + nr, 2 * k + 1, ch_out + 4 * (3 + n - 1));      // q, x', r1
+  one(1, 4 + nr, 2 * k, ch_out + 4 * 6);                                                      // t
+  for (uint32_t j = 1; j <= k; j++) one(1, 4 + nr + 2 * j, 2 * (k - j), es_out + 4 * (k - j));   // round j: es is LAST round first
+  if (b_index == 0) { U256::one().store(rho_out); return; }
+  Sha256 h;
+  h.update(seed, 32);
+  uint8_t le[8];
+  for (int i = 0; i < 8; i++) le[i] = (uint8_t)(b_index >> (8 * i));
+  h.update(le, 8);
+  uint32_t d[8];
+  h.finish(d);
+  U256 r = host_digest_to_fr(d);
+  if (r.is_zero()) r = U256::one();
+  r.store(rho_out);
+}
+}  // namespace
 extern "C" {
 
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
@@ -471,9 +531,31 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
   k_rp_decode_points<<<dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_coms_files, (const uint8_t *)d_proof_files, init_pts,
                                                                            resp_pts, bad);
   if (ns) k_rp_decode_scalars<<<dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_proof_files, wit_norm, wit_lin);
-  k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
-  const uint64_t nh = (uint64_t)B * (rp->nhash + 1);
-  k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, d_seed, ch, es, rho);
+  size_t host_oracle_max = 8;
+  if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_max = (size_t)atol(e);
+  if (B <= host_oracle_max) {
+    std::vector<uint64_t> hi(B * ninit * 8), hr(B * 2 * k * 8 + 8), hch(B * 28), hes(B * k * 4 + 4), hrho(B * 4);
+    BPPP_HIP(ctx, hipMemcpyAsync(hi.data(), init_pts, B * ninit * 64, hipMemcpyDeviceToHost, st));
+    if (k) BPPP_HIP(ctx, hipMemcpyAsync(hr.data(), resp_pts, B * 2 * k * 64, hipMemcpyDeviceToHost, st));
+    BPPP_HIP(ctx, hipStreamSynchronize(st));
+    auto work = [&](size_t lo, size_t hi_) {
+      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, &hi[b * ninit * 8], &hr[b * 2 * k * 8], seed, b, &hch[b * 28], &hes[b * k * 4], &hrho[b * 4]);
+    };
+    if (B <= 2) work(0, B);
+    else {
+      std::vector<std::thread> th;
+      for (size_t b = 0; b < B; b++) th.emplace_back(work, b, b + 1);
+      for (auto &x : th) x.join();
+    }
+    BPPP_HIP(ctx, hipMemcpyAsync(ch, hch.data(), B * 7 * 32, hipMemcpyHostToDevice, st));
+    if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes.data(), B * k * 32, hipMemcpyHostToDevice, st));
+    BPPP_HIP(ctx, hipMemcpyAsync(rho, hrho.data(), B * 32, hipMemcpyHostToDevice, st));
+    BPPP_HIP(ctx, hipStreamSynchronize(st));          // the staging vectors go out of scope
+  } else {
+    k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
+    const uint64_t nh = (uint64_t)B * (rp->nhash + 1);
+    k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, d_seed, ch, es, rho);
+  }
   BPPP_HIP(ctx, hipGetLastError());
   int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
   if (rc) return rc;
