@@ -501,8 +501,9 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   }
   // A handful of proofs: the oracle moves to the host.  One GPU lane walks the ~160 SHA-256 blocks of a 64by64 transcript in ~0.6 ms
   // (11 times per proof); a host core needs ~50 us, which pays for the round trip of the new points and the challenges as long as
-  // the batch is small (BPPP_RP_HOST_ORACLE_MAX, default 8 proofs: 1 proof 6.2 ms against 12.0 ms, 8 proofs 9.5 against 12.5, level from 16).
-  size_t host_oracle_max = 8;
+  // the batch is small (BPPP_RP_HOST_ORACLE_MAX, default 64 proofs: 1 proof 5.2 ms against 12.0 ms, 32 proofs 11.2 against 12.7, level at 128; the
+  // host hashes with the CPU's SHA extensions, csrc/sha256.hip.h, up to 16 threads).
+  size_t host_oracle_max = 64;
   if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_max = (size_t)atol(e);
   const bool host_oracle = stream_mode && B <= host_oracle_max;
   std::vector<std::vector<std::string>> h_groups(host_oracle ? B : 0);
