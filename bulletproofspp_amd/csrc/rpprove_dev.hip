@@ -521,8 +521,8 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     const uint32_t first_slot = call == 0 ? 0u : call == 1 ? 3u : call == 2 ? 6u : 7u;
     {
       auto work = [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) rpp_host_oracle(rp->tag, h_groups[b], h_np[b], &hp[b * m * 8], m, count, &ho[b * 12]); };
-      const size_t nt = std::min<size_t>(B, 16);
-      if (nt <= 2) work(0, B);
+      const size_t nt = std::min<size_t>(B / 16, 16);          // a proof's call is ~10 us of hashing and text: threads only pay from a few dozen proofs
+      if (nt <= 1) work(0, B);
       else {
         std::vector<std::thread> th;
         for (size_t t = 0; t < nt; t++) th.emplace_back(work, B * t / nt, B * (t + 1) / nt);
