@@ -157,36 +157,38 @@ __global__ void __launch_bounds__(256) k_rp_text(RpDims D, const uint32_t *__res
 //                                 7 + j -> e of round j + 1 (first round first), (X, R) prepended    (Bulletproof.hs:374)
 // The hashed message is  header_h <> text[b][off[start_h] ..]  with header_h = tag <> show n <> show (length ps), identical for
 // every proof (precomputed on the host, HashPlan).  Hash 7 + k is the batch weight rho_b = H(seed <> b) (b = 0: rho = 1).
-__global__ void __launch_bounds__(64) k_rp_hash(RpDims D, uint32_t batch, uint32_t nhash, const HashPlan *__restrict__ plan, const uint8_t *__restrict__ text,
-                                                const uint32_t *__restrict__ text_off, const uint8_t *__restrict__ seed, uint32_t *__restrict__ ch,
-                                                uint32_t *__restrict__ es, uint32_t *__restrict__ rho) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint64_t)batch * (nhash + 1)) return;
-  // hashes of one KIND sit in one wavefront (equal lengths, the same header): g = h * batch + b
-  const uint32_t h = (uint32_t)(g / batch), b = (uint32_t)(g % batch);
-  uint32_t st[8];
+// one lane per proof: the batch weight rho_b, one block: seed (32 bytes) <> b as 8 little-endian bytes, padded
+__global__ void __launch_bounds__(64) k_rp_rho(uint32_t batch, const uint8_t *__restrict__ seed, uint32_t *__restrict__ rho) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= batch) return;
+  if (b == 0) { fe one = fe_one(); fe_store(rho, one); return; }
+  uint32_t st[8], w[16];
   sha256_init(st);
-  uint32_t w[16];
-  if (h == nhash) {
-    // rho_b: one block, seed (32 bytes) <> b as 8 little-endian bytes, padded
-    if (b == 0) { fe one = fe_one(); fe_store(rho, one); return; }
 #pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
-    w[8] = __builtin_bswap32(b); w[9] = 0; w[10] = 0x80000000u;
-    w[11] = w[12] = w[13] = w[14] = 0; w[15] = 40 * 8;
-    sha256_compress(st, w);
-    fe v; sha256_digest_to_limbs(st, v.v);
-    fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
-    for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
-    if (fe_is_zero(v)) v = fe_one();
-    fe_store(rho + (size_t)b * 8, v);
-    return;
-  }
+  for (int i = 0; i < 8; i++) w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+  w[8] = __builtin_bswap32(b); w[9] = 0; w[10] = 0x80000000u;
+  w[11] = w[12] = w[13] = w[14] = 0; w[15] = 40 * 8;
+  sha256_compress(st, w);
+  fe v; sha256_digest_to_limbs(st, v.v);
+  fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
+  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  if (fe_is_zero(v)) v = fe_one();
+  fe_store(rho + (size_t)b * 8, v);
+}
+// 64 hashes per workgroup of two wavefronts (producer / consumer, rphash.hip.h); hashes of one KIND sit in one workgroup (equal
+// lengths, the same header): g = h * batch + b
+__global__ void __launch_bounds__(128) k_rp_hash(RpDims D, uint32_t batch, uint32_t nhash, const HashPlan *__restrict__ plan, const uint8_t *__restrict__ text,
+                                                 const uint32_t *__restrict__ text_off, uint32_t *__restrict__ ch, uint32_t *__restrict__ es) {
+  __shared__ uint32_t lds[RP_HASH_PC_LDS_WORDS];
+  const uint64_t g = (uint64_t)blockIdx.x * 64 + (threadIdx.x & 63u);
+  const bool active = g < (uint64_t)batch * nhash;
+  const uint32_t h = active ? (uint32_t)(g / batch) : 0u, b = active ? (uint32_t)(g % batch) : 0u;
   const HashPlan *pl = plan + h;
   const uint32_t npts = rp_npts(D);
   const uint32_t *off = text_off + (size_t)b * (npts + 1);
   const uint32_t t0 = off[pl->start_pt], t1 = off[npts];
-  const fe v = rp_hash_to_fr(pl->hdr_be, pl->hlen, text + (size_t)b * D.text_stride + t0, t1 - t0);   // the suffix of the proof's text this call hashes
+  const fe v = rp_hash_to_fr_pc(active, pl->hdr_be, pl->hlen, text + (size_t)b * D.text_stride + t0, t1 - t0, lds);   // the suffix of the proof's text this call hashes
+  if (!active || threadIdx.x < 64) return;                  // the consumer wavefront holds the digests
   const uint32_t slot = pl->out_slot;
   if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
   else fe_store(es + ((size_t)b * D.k + (slot - 7)) * 8, v);
@@ -553,8 +555,9 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
     BPPP_HIP(ctx, hipStreamSynchronize(st));          // the staging vectors go out of scope
   } else {
     k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
-    const uint64_t nh = (uint64_t)B * (rp->nhash + 1);
-    k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, d_seed, ch, es, rho);
+    const uint64_t nh = (uint64_t)B * rp->nhash;
+    k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(128), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, ch, es);
+    k_rp_rho<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>((uint32_t)B, d_seed, rho);
   }
   BPPP_HIP(ctx, hipGetLastError());
   int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);

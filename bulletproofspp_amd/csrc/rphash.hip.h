@@ -118,4 +118,70 @@ BPPP_DI fe rp_hash_to_fr(const uint32_t *hdr_be, uint32_t hlen, const uint8_t *t
   return v;
 }
 
+// The same hash by a PAIR of wavefronts (workgroup of 128 threads, 64 hashes): threads 0..63 PRODUCE — they fetch the message words of
+// block k + 1, expand its schedule and leave W[t] + K[t] in LDS — while threads 64..127 CONSUME block k (the 64 dependent rounds).  A lane
+// of one wavefront issues ~1700 dependent-ish instructions per block at one wavefront's rate; split this way the critical path is the
+// ~900 instructions of the rounds, and the two wavefronts sit on different SIMDs.  `lds`: 2 x 64 x 64 + 1 words.  Every thread of the
+// workgroup must call this (inactive lanes pass active = false); the result is valid in the consumer threads only.
+static constexpr uint32_t RP_HASH_PC_LDS_WORDS = 2 * 64 * 64 + 1;
+BPPP_DI fe rp_hash_to_fr_pc(bool active, const uint32_t *hdr_be, uint32_t hlen, const uint8_t *tx, uint32_t tlen, uint32_t *lds) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool producer = threadIdx.x < 64u;
+  const uint32_t mlen = hlen + tlen;
+  const uint32_t nblk = active ? (mlen + 9 + 63) / 64 : 0u;
+  uint32_t *maxp = lds + 2 * 64 * 64;
+  if (threadIdx.x == 0) *maxp = 0;
+  __syncthreads();
+  if (producer) atomicMax(maxp, nblk);
+  __syncthreads();
+  const uint32_t maxblk = *maxp;
+  uint32_t st[8];
+  sha256_init(st);
+  // producer state: as in rp_hash_to_fr, interior blocks come as 17 aligned dwords requested one block ahead
+  const uint32_t first_fast = (hlen + 63) / 64, last_fast = mlen / 64;
+  const uintptr_t a0 = (uintptr_t)(tx + ((size_t)first_fast * 64 - hlen));
+  const uint32_t sh = (uint32_t)(a0 & 3) * 8;
+  const uint32_t *q = (const uint32_t *)(a0 & ~(uintptr_t)3);
+  uint32_t nx[17];
+  if (producer && nblk && first_fast < last_fast) {
+#pragma unroll
+    for (int i = 0; i < 17; i++) nx[i] = q[i];
+  }
+  for (uint32_t it = 0; it <= maxblk; it++) {
+    if (producer) {
+      if (it < nblk) {
+        const uint32_t blk = it, p0 = blk * 64;
+        uint32_t w[16];
+        if (blk >= first_fast && blk < last_fast) {
+#pragma unroll
+          for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32((uint32_t)((((uint64_t)nx[i + 1] << 32) | nx[i]) >> sh));
+          if (blk + 1 < last_fast) {
+            const uint32_t *qn = q + (size_t)(blk + 1 - first_fast) * 16;
+#pragma unroll
+            for (int i = 0; i < 17; i++) nx[i] = qn[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; i++) w[i] = rp_msg_word(hdr_be, hlen, tx, mlen, p0 + 4 * i);
+          if (blk == nblk - 1) { w[14] = 0; w[15] = mlen * 8; }
+        }
+        uint32_t *dst = lds + (size_t)(it & 1u) * 64 * 64 + lane;
+        sha256_schedule_wk(w, [&](int t, uint32_t v) { dst[t * 64] = v; });
+      }
+    } else if (it >= 1 && it - 1 < nblk) {
+      const uint32_t *src = lds + (size_t)((it - 1) & 1u) * 64 * 64 + lane;
+      uint32_t wk[64];                                   // all 64 LDS reads are issued before the first round needs one
+#pragma unroll
+      for (int t = 0; t < 64; t++) wk[t] = src[t * 64];
+      sha256_rounds_wk(st, [&](int t) { return wk[t]; });
+    }
+    __syncthreads();
+  }
+  fe v; sha256_digest_to_limbs(st, v.v);
+  fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
+#pragma unroll
+  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  return v;
+}
+
 }  // namespace bppp

@@ -417,13 +417,16 @@ __global__ void __launch_bounds__(256) k_rpp_text_prepend(const uint32_t *__rest
 // challenge n (1 <= n <= count) of every proof: SHA-256 (hdr_n <> text from the current start); out slot of challenge n: ch_slot[n-1]
 // into ch[b][7] (slot < 7) or es[b] (slot = 7)
 struct RppHdrs { uint32_t hdr_be[3][RP_HDR_MAX / 4]; uint32_t hlen[3]; uint32_t slot[3]; };
-__global__ void __launch_bounds__(64) k_rpp_hash(const RppHdrs *__restrict__ H, uint32_t count, uint32_t batch, const uint8_t *__restrict__ text, uint32_t stride,
-                                                 const uint32_t *__restrict__ tstart, uint32_t tend, uint32_t *__restrict__ ch, uint32_t *__restrict__ es) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint64_t)batch * count) return;
-  const uint32_t n = (uint32_t)(g / batch), b = (uint32_t)(g % batch);
+// 64 hashes per workgroup of two wavefronts (producer / consumer, rphash.hip.h): g = n * batch + b
+__global__ void __launch_bounds__(128) k_rpp_hash(const RppHdrs *__restrict__ H, uint32_t count, uint32_t batch, const uint8_t *__restrict__ text, uint32_t stride,
+                                                  const uint32_t *__restrict__ tstart, uint32_t tend, uint32_t *__restrict__ ch, uint32_t *__restrict__ es) {
+  __shared__ uint32_t lds[RP_HASH_PC_LDS_WORDS];
+  const uint64_t g = (uint64_t)blockIdx.x * 64 + (threadIdx.x & 63u);
+  const bool active = g < (uint64_t)batch * count;
+  const uint32_t n = active ? (uint32_t)(g / batch) : 0u, b = active ? (uint32_t)(g % batch) : 0u;
   const uint32_t s = tstart[b];
-  const fe v = rp_hash_to_fr(H->hdr_be[n], H->hlen[n], text + (size_t)b * stride + s, tend - s);
+  const fe v = rp_hash_to_fr_pc(active, H->hdr_be[n], H->hlen[n], text + (size_t)b * stride + s, tend - s, lds);
+  if (!active || threadIdx.x < 64) return;
   const uint32_t slot = H->slot[n];
   if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
   else fe_store(es + (size_t)b * 8, v);
@@ -512,7 +515,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     if (!host_oracle) {
       k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), (m + 1) * 4, st>>>(pts_dev, (uint32_t)m, text, stride, tstart);
       const uint64_t n = (uint64_t)B * count;
-      k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(hdrs + call, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
+      k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st>>>(hdrs + call, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
       return BPPP_OK;
     }
     std::vector<uint64_t> hp(B * m * 8), ho(B * 3 * 4);
@@ -615,7 +618,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     BPPP_HIP(ctx, hipStreamSynchronize(st));          // h and the caller's staging are on the stack / reused
     k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), (m + 1) * 4, st>>>(pts_dev, (uint32_t)m, text, stride, tstart);
     const uint64_t n = (uint64_t)B * count;
-    k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(hdrs, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
+    k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st>>>(hdrs, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
     BPPP_HIP(ctx, hipGetLastError());
     return BPPP_OK;
   };

@@ -76,6 +76,45 @@ BPPP_HD void sha256_compress(uint32_t h[8], uint32_t w[16]) {
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// The same compression split in two for a PAIR of wavefronts (csrc/rphash.hip.h): the message schedule of a block has no dependency on
+// the chaining state, so one wavefront expands W[0..63] (+ K) of block k + 1 while the other runs the 64 rounds of block k.
+BPPP_HD uint32_t sha256_k(int i) {
+  const uint32_t K[64] = {
+      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+      0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+      0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+      0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+      0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+      0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+  return K[i];
+}
+// W[t] + K[t] for t = 0 .. 63, handed to put(t, value); w[16] is clobbered
+template <class Put> BPPP_HD void sha256_schedule_wk(uint32_t w[16], Put put) {
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    uint32_t wi;
+    if (i < 16) wi = w[i];
+    else {
+      const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      const uint32_t s0 = SHA_XOR3(sha_rotr(w15, 7), sha_rotr(w15, 18), (w15 >> 3));
+      const uint32_t s1 = SHA_XOR3(sha_rotr(w2, 17), sha_rotr(w2, 19), (w2 >> 10));
+      wi = w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+    }
+    put(i, wi + sha256_k(i));
+  }
+}
+// the 64 rounds over get(t) = W[t] + K[t]; h += the result
+template <class Get> BPPP_HD void sha256_rounds_wk(uint32_t h[8], Get get) {
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    const uint32_t t1 = hh + SHA_XOR3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25)) + SHA_CH(e, f, g) + get(i);
+    const uint32_t t2 = SHA_XOR3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22)) + SHA_MAJ(a, b, c);
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
 // `decode` of the 32 digest bytes through Binary (Prime p) (src/Encoding.hs:75-79): limb i (64 bits, i = 0 least significant)
 // is the big-endian word at bytes 8i .. 8i+7, i.e. (h[2i] << 32) | h[2i+1].  Output: 8 little-endian 32-bit limbs of the
 // 256-bit integer, NOT yet reduced (toP reduces; the caller subtracts the modulus once — the value is < 2^256 < 2 m).
