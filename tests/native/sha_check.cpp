@@ -35,6 +35,16 @@ int main() {
     portable(m.data(), n, w);
     if (memcmp(d, w, 32)) { if (bad < 5) printf("mismatch at length %zu\n", n); bad++; }
   }
+  // the compression split into its two halves (message schedule + K / the 64 rounds), as the wavefront pairs of the device use it
+  for (int it = 0; it < 2000; it++) {
+    uint32_t w[16], w2[16], h1[8], h2[8], wk[64];
+    for (int i = 0; i < 16; i++) w2[i] = w[i] = (uint32_t)g();
+    for (int i = 0; i < 8; i++) h2[i] = h1[i] = (uint32_t)g();
+    sha256_compress(h1, w);
+    sha256_schedule_wk(w2, [&](int t, uint32_t v) { wk[t] = v; });
+    sha256_rounds_wk(h2, [&](int t) { return wk[t]; });
+    if (memcmp(h1, h2, 32)) { if (bad < 5) printf("split compression mismatch\n"); bad++; }
+  }
 #if defined(BPPP_SHA_NI)
   printf("bad %d; sha extensions %s\n", bad, sha256_have_shani() ? "used" : "absent");
 #else
