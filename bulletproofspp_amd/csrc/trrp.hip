@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, uint32_t batch, 
         fe A = fe_add<1>(lds_get(sl, slot), frm(t3, frm(xr, fe_load(pos_coeff + (size_t)i * 8))));
         if (kind == K_INLINE && sy != NO_SYM) {
           const fe si = lds_get(inv, 2 + sy);                      // "if s == 0 then 0" is tested on the INVERTED value (:205): e + s = 0 gives c = 0
-          if (!fe_is_zero(si)) A = fe_add<1>(A, frm(frm(t4, frm(x3, fr_pow_u32(xx, slot))), fe_sub<1>(e_inv, si)));
+          if (!fe_is_zero(si)) A = fe_add<1>(A, frm(frm(t2, lds_get(sl, slot)), fe_sub<1>(e_inv, si)));      // t^4 v = t^2 (t^2 v): the slot table has t^2 v
         }
         p = fe_add<1>(t2e, frm(qi2, A));
         ts0 = fe_add<1>(frm(q2, fe_add<1>(frs(p), two_t5)), lds_get(sl, TRRP_MAX_SLOTS + slot));
