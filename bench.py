@@ -185,7 +185,7 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     single_context = None
     if world == 1 and batch >= 4096:
         cf2, pf2 = np.zeros_like(cf), np.zeros_like(pf)
-        os.environ["BPPP_RP_NO_SPLIT"] = "1"
+        nat.set_option("split_min", 0)
         try:
             def one():
                 gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bld), vp(pre), plen, vp(cf2), vp(pf2)), "bppp_rp_prove_batch")
@@ -197,7 +197,7 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
             torch.cuda.synchronize()
             qdt = time.perf_counter() - tq0
         finally:
-            del os.environ["BPPP_RP_NO_SPLIT"]
+            nat.set_option("split_min", 4096)
         assert np.array_equal(cf2, cf) and np.array_equal(pf2, pf), "one-context prover output differs"
         single_context = {"value": batch * prove_steps / qdt, "unit": "proofs/s", "ms_per_batch": qdt / prove_steps * 1e3}
     prove = {"metric": "range_proofs_proved_per_sec", "value": world * batch * prove_steps / pdt, "unit": "proofs/s", "ms_per_batch": pdt / prove_steps * 1e3,

@@ -29,7 +29,7 @@ SYMBOLS = [
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
     "bppp_basis_create", "bppp_basis_create_device", "bppp_basis_destroy", "bppp_basis_info", "bppp_msm_basis", "bppp_basis_enable_comb",
-    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_shape_of", "bppp_rp_digits", "bppp_hash_to_scalar", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_prove_batch",
+    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_set_option", "bppp_rp_shape_of", "bppp_rp_digits", "bppp_hash_to_scalar", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_verify_shard_device", "bppp_rp_prove_batch",
 ]
 
 
@@ -120,11 +120,13 @@ def load_library() -> C.CDLL:
     lib.bppp_rp_destroy.argtypes = [vp]
     lib.bppp_rp_destroy.restype = None
     lib.bppp_rp_info.argtypes = [vp, vp]
+    lib.bppp_rp_set_option.argtypes = [vp, i, C.c_uint64]
     lib.bppp_rp_shape_of.argtypes = [i, i, vp, sz, vp]
     lib.bppp_rp_digits.argtypes = [vp, vp, vp, sz, C.POINTER(sz), C.POINTER(i)]
     lib.bppp_hash_to_scalar.argtypes = [vp, sz, vp]
     lib.bppp_rp_verify_batch.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp, vp]
     lib.bppp_rp_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, C.POINTER(i), vp, vp, vp]
+    lib.bppp_rp_verify_shard_device.argtypes = [vp, sz, C.c_uint64, vp, vp, vp, C.POINTER(i), vp, vp, vp]
     lib.bppp_rp_prove_batch.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, vp]
     lib.bppp_profile_enable.argtypes = [vp, i]
     lib.bppp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]
@@ -161,6 +163,7 @@ class RpShape(C.Structure):
                                           "challenges_per_proof")]
 
 
+RP_OPTIONS = {"comb_min": 1, "comb_budget": 2, "comb_bits": 3, "split_min": 4, "host_oracle_max": 5, "fold_points": 6, "host_algebra": 7, "timing": 8}
 RP_SHARED, RP_OUTPUT, RP_ASSUMED = 1, 2, 4
 RP_VALID, RP_INVALID, RP_MALFORMED = 0, 1, 2
 

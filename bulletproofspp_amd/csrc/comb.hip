@@ -205,7 +205,9 @@ int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bi
   t->ctx = ctx; ctx_retain(ctx); t->T = T; t->c = c; t->W = (257 + c - 1) / c; t->D = 1 << (c - 1); t->tab = nullptr; t->bytes = size_of(c);
   uint32_t *bases = nullptr;
   hipStream_t st = ctx->stream;
-  auto bail = [&](const std::string &m) { if (bases) hipFree(bases); comb_destroy(t); return fail(ctx, BPPP_ERR_HIP, m); };
+  // a failed hipMalloc (or launch) leaves its error in the runtime's last-error slot, which later successful calls do NOT clear on
+  // ROCm 7: consume it here, or the next launch check of this context reports a stale out-of-memory
+  auto bail = [&](const std::string &m) { (void)hipGetLastError(); if (bases) hipFree(bases); comb_destroy(t); (void)hipGetLastError(); return fail(ctx, BPPP_ERR_HIP, m); };
   if (hipMalloc(&t->tab, t->bytes) != hipSuccess) return bail("comb_create: hipMalloc of the table failed (" + std::to_string(t->bytes >> 20) + " MiB)");
   if (hipMalloc(&bases, (size_t)t->W * T * 64) != hipSuccess) return bail("comb_create: hipMalloc failed");
   k_comb_bases<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, st>>>(d_points, (uint32_t)T, c, t->W, bases);

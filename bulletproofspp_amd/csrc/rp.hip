@@ -156,22 +156,52 @@ __global__ void __launch_bounds__(256) k_rp_text(RpDims D, const uint32_t *__res
 //                                 6     -> t          third call, blCom prepended                    (:462)
 //                                 7 + j -> e of round j + 1 (first round first), (X, R) prepended    (Bulletproof.hs:374)
 // The hashed message is  header_h <> text[b][off[start_h] ..]  with header_h = tag <> show n <> show (length ps), identical for
-// every proof (precomputed on the host, HashPlan).  Hash 7 + k is the batch weight rho_b = H(seed <> b) (b = 0: rho = 1).
-// one lane per proof: the batch weight rho_b, one block: seed (32 bytes) <> b as 8 little-endian bytes, padded
-__global__ void __launch_bounds__(64) k_rp_rho(uint32_t batch, const uint8_t *__restrict__ seed, uint32_t *__restrict__ rho) {
+// every proof (precomputed on the host, HashPlan).
+//
+// The batch weight rho_b (k_rp_rho, one lane per proof) is bound to the verifier's seed, to the proof's GLOBAL position in the job and
+// to the proof itself:  rho_b = decode (SHA-256 (seed[32] <> le64 (index_offset + b) <> t <> e_last <> final witness scalars)), every
+// scalar as its 32 little-endian bytes; t (the third oracle call, TypedReciprocal.hs:462) and e_last (the last round's challenge,
+// Bulletproof.hs:374) are hashes of every commitment and response of the proof, the final witness scalars are the only proof bytes no
+// challenge covers.  No weight is fixed to 1: with the batch sharded proof-per-GPU the ranks pass their offsets, so no two proofs of a
+// job share a weight and error terms cannot be made to cancel between ranks (or, with a known seed, inside one batch).
+BPPP_DI uint32_t rp_rho_word(const RpDims &D, uint32_t i, const uint8_t *seed, uint64_t idx, const uint32_t *t, const uint32_t *e_last, const uint32_t *wn,
+                             const uint32_t *wl) {
+  if (i < 8) return ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+  if (i == 8) return __builtin_bswap32((uint32_t)idx);
+  if (i == 9) return __builtin_bswap32((uint32_t)(idx >> 32));
+  uint32_t j = i - 10;
+  if (j < 8) return __builtin_bswap32(t[j]);
+  j -= 8;
+  if (D.k) { if (j < 8) return __builtin_bswap32(e_last[j]); j -= 8; }
+  if (j < 8 * D.fn) return __builtin_bswap32(wn[j]);
+  return __builtin_bswap32(wl[j - 8 * D.fn]);
+}
+__global__ void __launch_bounds__(64) k_rp_rho(RpDims D, uint32_t batch, uint64_t index_offset, const uint8_t *__restrict__ seed, const uint32_t *__restrict__ ch,
+                                               const uint32_t *__restrict__ es, const uint32_t *__restrict__ wit_norm, const uint32_t *__restrict__ wit_lin,
+                                               uint32_t *__restrict__ rho) {
   const uint32_t b = blockIdx.x * 64 + threadIdx.x;
   if (b >= batch) return;
-  if (b == 0) { fe one = fe_one(); fe_store(rho, one); return; }
+  const uint32_t *t = ch + ((size_t)b * 7 + 6) * 8, *e_last = es + (size_t)b * D.k * 8;     // es is LAST round first
+  const uint32_t *wn = wit_norm + (size_t)b * D.fn * 8, *wl = wit_lin + (size_t)b * D.fl * 8;
+  const uint32_t nwords = 10 + 8 * (1 + (D.k ? 1 : 0) + D.fn + D.fl);
+  const uint32_t nblocks = (nwords * 4 + 9 + 63) / 64;
   uint32_t st[8], w[16];
   sha256_init(st);
+  for (uint32_t blk = 0; blk < nblocks; blk++) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
-  w[8] = __builtin_bswap32(b); w[9] = 0; w[10] = 0x80000000u;
-  w[11] = w[12] = w[13] = w[14] = 0; w[15] = 40 * 8;
-  sha256_compress(st, w);
+    for (int i = 0; i < 16; i++) {
+      const uint32_t wi = blk * 16 + i;
+      uint32_t v = 0;
+      if (wi < nwords) v = rp_rho_word(D, wi, seed, index_offset + b, t, e_last, wn, wl);
+      else if (wi == nwords) v = 0x80000000u;
+      if (blk == nblocks - 1 && i == 15) v = nwords * 32;
+      w[i] = v;
+    }
+    sha256_compress(st, w);
+  }
   fe v; sha256_digest_to_limbs(st, v.v);
-  fe t; const uint32_t br = raw_sub(t, v, fr_modulus());
-  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : t.v[i];
+  fe r; const uint32_t br = raw_sub(r, v, fr_modulus());
+  for (int i = 0; i < 8; i++) v.v[i] = br ? v.v[i] : r.v[i];
   if (fe_is_zero(v)) v = fe_one();
   fe_store(rho + (size_t)b * 8, v);
 }
@@ -262,6 +292,17 @@ int rp_build_plan(bppp_rp *rp) {
 
 extern "C" void bppp_basis_destroy(bppp_basis *basis);
 
+void RpOptions::from_env() {
+  auto num = [](const char *name, size_t &dst) { if (const char *e = getenv(name)) dst = (size_t)atol(e); };
+  num("BPPP_RP_COMB_MIN", comb_min); num("BPPP_RP_SPLIT_MIN", split_min);
+  if (const char *e = getenv("BPPP_RP_COMB_GB")) comb_budget = (size_t)std::max(1, atoi(e)) << 30;
+  if (const char *e = getenv("BPPP_RP_COMB_BITS")) comb_bits = atoi(e);
+  if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_verify = host_oracle_prove = (size_t)atol(e);
+  no_comb = getenv("BPPP_RP_NO_COMB") != nullptr; no_split = getenv("BPPP_RP_NO_SPLIT") != nullptr;
+  fold_points = getenv("BPPP_NLB_FOLD_POINTS") != nullptr; host_algebra = getenv("BPPP_RP_HOST_ALGEBRA") != nullptr;
+  timing = getenv("BPPP_RP_TIMING") != nullptr;
+}
+
 extern "C" {
 
 void bppp_rp_destroy(bppp_rp *rp) {
@@ -309,6 +350,7 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
   }
   bppp_rp *rp = new bppp_rp();
   rp->ctx = ctx; ctx_retain(ctx);
+  rp->opt.from_env();
   auto fill = [&]() -> int {
     if (!bppp_rps::make_setup(has_types != 0, rds, pv, rp->st, err)) return fail(ctx, BPPP_ERR_ARG, "rp_create: " + err);
     const bppp_rps::Setup &st = rp->st;
@@ -393,6 +435,27 @@ int bppp_hash_to_scalar(const uint8_t *data, size_t len, uint64_t out[4]) {
   return BPPP_OK;
 }
 
+int bppp_rp_set_option(bppp_rp *rp, int option, uint64_t value) {
+  if (!rp) return BPPP_ERR_ARG;
+  RpOptions &o = rp->opt;
+  switch (option) {
+    case BPPP_RP_OPT_COMB_MIN: o.comb_min = (size_t)value; break;
+    case BPPP_RP_OPT_COMB_BUDGET: o.comb_budget = (size_t)value; o.no_comb = value == 0; if (value) rp->comb_failed = false; break;
+    case BPPP_RP_OPT_COMB_BITS: if (value && (value < 4 || value > 18)) return fail(rp->ctx, BPPP_ERR_ARG, "rp_set_option: comb window must be 0 or in [4,18]");
+                                o.comb_bits = (int)value; rp->comb_failed = false; break;
+    case BPPP_RP_OPT_SPLIT_MIN: o.split_min = (size_t)value; o.no_split = value == 0; break;
+    case BPPP_RP_OPT_HOST_ORACLE_MAX: if (value == UINT64_MAX) { o.host_oracle_verify = RpOptions().host_oracle_verify; o.host_oracle_prove = RpOptions().host_oracle_prove; }
+                                      else o.host_oracle_verify = o.host_oracle_prove = (size_t)value;
+                                      break;
+    case BPPP_RP_OPT_FOLD_POINTS: o.fold_points = value != 0; break;
+    case BPPP_RP_OPT_HOST_ALGEBRA: o.host_algebra = value != 0; break;
+    case BPPP_RP_OPT_TIMING: o.timing = value != 0; break;
+    default: return fail(rp->ctx, BPPP_ERR_ARG, "rp_set_option: unknown option");
+  }
+  if (rp->twin) rp->twin->opt = o;
+  return BPPP_OK;
+}
+
 int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out) {
   if (!rp || !out) return BPPP_ERR_ARG;
   const bppp_rps::Setup &st = rp->st;
@@ -434,12 +497,13 @@ int rp_ensure_twin(bppp_rp *rp) {
     return fail(ctx, rc, "rp: second handle: " + m);
   }
   rp->twin->is_twin = true;
+  rp->twin->opt = rp->opt;
   return BPPP_OK;
 }
 
 // ---- the verifier's oracle on the HOST, for a handful of proofs: one GPU lane walks the ~160 SHA-256 blocks of a 64by64 transcript
 // in ~0.8 ms whatever the batch size; a host core hashes the same 11 KB in ~50 us.  Same inputs and outputs as k_rp_text + k_rp_hash:
-// the decoded points of proof b (an undecodable one reads as "00", like on the device), the 7 + k challenges, the weight rho_b.
+// the decoded points of proof b (an undecodable one reads as "00", like on the device), the 7 + k challenges.
 namespace {
 void host_dec_append(std::string &out, U256 v) {
   char buf[80];
@@ -460,9 +524,8 @@ U256 host_digest_to_fr(const uint32_t h[8]) {
   for (int i = 0; i < 4; i++) r.w[i] = ((uint64_t)v[2 * i + 1] << 32) | v[2 * i];
   return bppp_rps::u_mod_n(r);
 }
-// init [4 + nr][8], resp [2k][8] (u64 limbs as downloaded); ch_out [7][4], es_out [k][4], rho_out [4]
-void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, const uint8_t seed[32], uint64_t b_index, uint64_t *ch_out, uint64_t *es_out,
-                          uint64_t *rho_out) {
+// init [4 + nr][8], resp [2k][8] (u64 limbs as downloaded); ch_out [7][4], es_out [k][4]  (the weight rho_b is k_rp_rho's on both routes)
+void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, uint64_t *ch_out, uint64_t *es_out) {
   const uint32_t k = rp->D.k, nr = rp->D.nr, npts = 2 * k + 4 + nr;
   std::vector<std::string> txt(npts);
   for (uint32_t t = 0; t < npts; t++) {
@@ -482,23 +545,17 @@ void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_
   for (uint32_t n = 1; n <= 3; n++) one(n, 3 + nr, 2 * k + 1, ch_out + 4 * (3 + n - 1));      // q, x', r1
   one(1, 4 + nr, 2 * k, ch_out + 4 * 6);                                                      // t
   for (uint32_t j = 1; j <= k; j++) one(1, 4 + nr + 2 * j, 2 * (k - j), es_out + 4 * (k - j));   // round j: es is LAST round first
-  if (b_index == 0) { U256::one().store(rho_out); return; }
-  Sha256 h;
-  h.update(seed, 32);
-  uint8_t le[8];
-  for (int i = 0; i < 8; i++) le[i] = (uint8_t)(b_index >> (8 * i));
-  h.update(le, 8);
-  uint32_t d[8];
-  h.finish(d);
-  U256 r = host_digest_to_fr(d);
-  if (r.is_zero()) r = U256::one();
-  r.store(rho_out);
 }
 }  // namespace
 extern "C" {
 
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
                                 uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
+  return bppp_rp_verify_shard_device(rp, batch, 0, d_coms_files, d_proof_files, seed, accept, proof_status, challenges_out, combined_xy);
+}
+
+int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32],
+                                int *accept, uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
   if (!rp || !accept) return BPPP_ERR_ARG;
   bppp_ctx *ctx = rp->ctx;
   if (ctx_closed(ctx)) return BPPP_ERR_ARG;
@@ -533,15 +590,17 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
   k_rp_decode_points<<<dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_coms_files, (const uint8_t *)d_proof_files, init_pts,
                                                                            resp_pts, bad);
   if (ns) k_rp_decode_scalars<<<dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_proof_files, wit_norm, wit_lin);
-  size_t host_oracle_max = 8;
-  if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_max = (size_t)atol(e);
+  const size_t host_oracle_max = rp->opt.host_oracle_verify;
+  // async copies below target host vectors: whatever path leaves this function, the stream is drained before they are destroyed
+  struct StreamDrain { hipStream_t s; ~StreamDrain() { hipStreamSynchronize(s); } };
   if (B <= host_oracle_max) {
-    std::vector<uint64_t> hi(B * ninit * 8), hr(B * 2 * k * 8 + 8), hch(B * 28), hes(B * k * 4 + 4), hrho(B * 4);
+    std::vector<uint64_t> hi(B * ninit * 8), hr(B * 2 * k * 8 + 8), hch(B * 28), hes(B * k * 4 + 4);
+    StreamDrain drain{st};
     BPPP_HIP(ctx, hipMemcpyAsync(hi.data(), init_pts, B * ninit * 64, hipMemcpyDeviceToHost, st));
     if (k) BPPP_HIP(ctx, hipMemcpyAsync(hr.data(), resp_pts, B * 2 * k * 64, hipMemcpyDeviceToHost, st));
     BPPP_HIP(ctx, hipStreamSynchronize(st));
     auto work = [&](size_t lo, size_t hi_) {
-      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, &hi[b * ninit * 8], &hr[b * 2 * k * 8], seed, b, &hch[b * 28], &hes[b * k * 4], &hrho[b * 4]);
+      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, &hi[b * ninit * 8], &hr[b * 2 * k * 8], &hch[b * 28], &hes[b * k * 4]);
     };
     if (B == 1) work(0, 1);                            // ~0.2 ms per proof (168 decimal conversions, 16 hashes of ~11 KB): one thread per proof
     else {
@@ -551,14 +610,13 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
     }
     BPPP_HIP(ctx, hipMemcpyAsync(ch, hch.data(), B * 7 * 32, hipMemcpyHostToDevice, st));
     if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes.data(), B * k * 32, hipMemcpyHostToDevice, st));
-    BPPP_HIP(ctx, hipMemcpyAsync(rho, hrho.data(), B * 32, hipMemcpyHostToDevice, st));
     BPPP_HIP(ctx, hipStreamSynchronize(st));          // the staging vectors go out of scope
   } else {
     k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
     const uint64_t nh = (uint64_t)B * rp->nhash;
     k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(128), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, ch, es);
-    k_rp_rho<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>((uint32_t)B, d_seed, rho);
   }
+  k_rp_rho<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, index_offset, d_seed, ch, es, wit_norm, wit_lin, rho);
   BPPP_HIP(ctx, hipGetLastError());
   int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
   if (rc) return rc;
@@ -568,6 +626,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
   if (rc) return rc;
   // decode failures (an x with no point on the curve): Nothing in the reference (decodeCommitments, Encoding.hs:119-128)
   std::vector<uint32_t> hbad(B);
+  StreamDrain drain{st};
   BPPP_HIP(ctx, hipMemcpyAsync(hbad.data(), bad, B * 4, hipMemcpyDeviceToHost, st));
   if (challenges_out) {
     BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out, (7 + k) * 32, ch, 7 * 32, 7 * 32, B, hipMemcpyDeviceToHost, st));

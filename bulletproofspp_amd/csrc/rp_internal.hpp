@@ -55,8 +55,25 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
 
 
 namespace bppp { struct CombTable; void comb_destroy(CombTable *); }
+// Tuning knobs of one handle (bppp_rp_set_option, include/bppp.h).  The BPPP_RP_* / BPPP_NLB_* environment variables are read ONCE,
+// when the handle is created, as the initial values; no entry point reads the environment per call.
+struct RpOptions {
+  size_t comb_min = 1024;             // BPPP_RP_COMB_MIN: first batch size (or cumulative proofs) that builds the comb table
+  size_t comb_budget = (size_t)32 << 30;   // BPPP_RP_COMB_GB: table budget; also capped by a share of the free HBM (rp_ensure_comb)
+  int comb_bits = 0;                  // BPPP_RP_COMB_BITS: force a window width (0 = widest that fits the budget)
+  bool no_comb = false;               // BPPP_RP_NO_COMB
+  size_t split_min = 4096;            // BPPP_RP_SPLIT_MIN: smallest batch run as two half-batches in flight
+  bool no_split = false;              // BPPP_RP_NO_SPLIT
+  size_t host_oracle_verify = 8;      // BPPP_RP_HOST_ORACLE_MAX: largest batch whose transcript hashing runs on the host (verifier)
+  size_t host_oracle_prove = 64;      //                          ... (prover)
+  bool fold_points = false;           // BPPP_NLB_FOLD_POINTS: point-folding argument although a table exists
+  bool host_algebra = false;          // BPPP_RP_HOST_ALGEBRA: field algebra and hashing of the prover on the host
+  bool timing = false;                // BPPP_RP_TIMING: phase times on stderr
+  void from_env();
+};
 struct bppp_rp {
   bppp_ctx *ctx = nullptr;
+  RpOptions opt;
   bppp_rps::Setup st;
   bppp_trrp *tabs = nullptr;
   std::string tag;

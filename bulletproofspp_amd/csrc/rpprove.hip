@@ -543,15 +543,17 @@ int rpp_commit_rows(bppp_rp *rp, const uint32_t *d_rows, size_t nrows, uint64_t 
 // 32 GB by default, BPPP_RP_COMB_GB to change it: 27.6 GB at 774 points (c = 16, built in ~0.3 s), 4.1 GB at c = 13 costs ~15 % more
 // additions; BPPP_RP_COMB_BITS forces a width, BPPP_RP_NO_COMB keeps the bucket route
 int rp_ensure_comb(bppp_rp *rp) {
-  if (rp->comb || getenv("BPPP_RP_NO_COMB")) return BPPP_OK;
-  int c = 0;
-  if (const char *e = getenv("BPPP_RP_COMB_BITS")) c = atoi(e);
-  size_t gb = 32;
-  if (const char *e = getenv("BPPP_RP_COMB_GB")) gb = (size_t)std::max(1, atoi(e));
-  if (rp->comb_failed) return BPPP_OK;
-  int rc = bppp::comb_create(rp->ctx, rp->d_basis, 1 + rp->st.llen + rp->st.nlen, c, gb << 30, &rp->comb);
+  if (rp->comb || rp->opt.no_comb || rp->comb_failed) return BPPP_OK;
+  // the table is a persistent allocation of tens of GB: never more than the handle's budget, and never more than half of what is
+  // free on the device right now (other handles, other processes on the same GPU); a forced width (comb_bits) skips the budget
+  size_t budget = rp->opt.comb_budget, free_b = 0, total_b = 0;
+  hipSetDevice(rp->ctx->device);
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 2);
+  else (void)hipGetLastError();
+  int rc = bppp::comb_create(rp->ctx, rp->d_basis, 1 + rp->st.llen + rp->st.nlen, rp->opt.comb_bits, budget, &rp->comb);
   if (rc) {                                  // no room for the table (or no window fits the budget): the bucket route and the point-folding
     rp->comb = nullptr; rp->comb_failed = true;   // argument serve the batch; the reason stays in bppp_last_error, the attempt is not repeated
+    (void)hipGetLastError();                 // a failed hipMalloc leaves its error in the runtime's last-error slot: later launch checks must not see it
     return BPPP_OK;
   }
   rp->comb_owned = true;
@@ -598,20 +600,19 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   // A large batch runs as TWO half-batches in flight, the second on a twin handle with its own context (stream, workspaces, host
   // thread): the proofs are independent, and the host shares of a half (digits, the argument's half-GCDs and round bookkeeping,
   // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).
-  size_t split_min = 4096;      // measured: 4096 proofs 91-93 ms split against 95-97 ms, but 2048 proofs (128by64) 109 ms split against 104 ms
-  if (const char *e = getenv("BPPP_RP_SPLIT_MIN")) split_min = (size_t)atol(e);
-  size_t comb_min = 1024;          // the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
-  if (const char *e = getenv("BPPP_RP_COMB_MIN")) comb_min = (size_t)atol(e);
+  const size_t split_min = rp->opt.split_min;   // default 4096; measured: 4096 proofs 91-93 ms split against 95-97 ms, but 2048 proofs (128by64) 109 ms split against 104 ms
+  const size_t comb_min = rp->opt.comb_min;     // default 1024: the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
   // ... or one that has proved that many proofs in smaller batches: with the table in place every batch size is faster (one 64by64 proof:
   // 12 ms against 22 ms; 256: 22 against 48)
   if (!rp->is_twin) {
     rp->proved_total += batch;
     if (batch >= comb_min || rp->proved_total >= comb_min) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
   }
-  if (batch < split_min || batch < 2 || rp->is_twin || getenv("BPPP_RP_NO_SPLIT"))
+  if (batch < split_min || batch < 2 || rp->is_twin || rp->opt.no_split)
     return prove_batch_one(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
   { int rc = rp_ensure_twin(rp); if (rc) return rc; }
   if (rp->comb && !rp->twin->comb) rp->twin->comb = rp->comb;      // not owned by the twin
+  rp->twin->opt = rp->opt;
   const size_t nr = rp->st.rds.size(), B0 = (batch + 1) / 2, B1 = batch - B0;
   int rc1 = BPPP_OK;
   std::thread second([&] {
@@ -633,13 +634,13 @@ static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, c
   for (const RangeData &rd : st.rds) max_base = std::max(max_base, rd.base);
   // the device algebra looks digits up in a 256-entry table of reciprocals; wider bases (and BPPP_RP_HOST_ALGEBRA=1, kept for
   // comparison) take the host-algebra path: same bytes out
-  if (max_base > 256 || getenv("BPPP_RP_HOST_ALGEBRA")) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
+  if (max_base > 256 || rp->opt.host_algebra) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
   hipSetDevice(ctx->device);
   const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
   if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");
   { int rc = build_fixed_table(rp); if (rc) return rc; }
   if (!rp->commit_basis) { int rc = bppp_basis_create_device(ctx, rp->d_basis, T, 0, 4096, &rp->commit_basis); if (rc) return rc; }
-  const bool timing = getenv("BPPP_RP_TIMING") != nullptr;
+  const bool timing = rp->opt.timing;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_last = now();
   auto lap = [&](const char *what) { if (timing) { double t = now(); fprintf(stderr, "[rp_prove] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
@@ -704,7 +705,7 @@ static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, 
            *d_rows = (uint32_t *)((char *)d_in_pt + ((in_pt + 255) & ~(size_t)255));
 
   // BPPP_RP_TIMING=1: wall time of each phase on stderr (tuning aid)
-  const bool timing = getenv("BPPP_RP_TIMING") != nullptr;
+  const bool timing = rp->opt.timing;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_last = now();
   auto lap = [&](const char *what) { if (timing) { double t = now(); fprintf(stderr, "[rp_prove] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };

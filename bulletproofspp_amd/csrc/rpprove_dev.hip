@@ -480,7 +480,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   if (in.prefix_len) BPPP_HIP(ctx, hipMemcpyAsync(prefix, in.prefix, B * in.prefix_len, hipMemcpyHostToDevice, st));
   // fixed-basis mode (comb table in place): the whole proof is ONE stream of kernels — commitments stay on the device until the end,
   // every oracle call reads its points where they lie, and the headers of all 3 + k oracle calls go up here
-  const bool stream_mode = rp->comb != nullptr && !getenv("BPPP_NLB_FOLD_POINTS");
+  const bool stream_mode = rp->comb != nullptr && !rp->opt.fold_points;
   const size_t cscratch_bytes = std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B));
   {
     std::vector<uint32_t> ts(B, tend);
@@ -506,8 +506,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   // (11 times per proof); a host core needs ~50 us, which pays for the round trip of the new points and the challenges as long as
   // the batch is small (BPPP_RP_HOST_ORACLE_MAX, default 64 proofs: 1 proof 5.2 ms against 12.0 ms, 32 proofs 11.2 against 12.7, level at 128; the
   // host hashes with the CPU's SHA extensions, csrc/sha256.hip.h, up to 16 threads).
-  size_t host_oracle_max = 64;
-  if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_max = (size_t)atol(e);
+  const size_t host_oracle_max = rp->opt.host_oracle_prove;
   const bool host_oracle = stream_mode && B <= host_oracle_max;
   std::vector<std::vector<std::string>> h_groups(host_oracle ? B : 0);
   std::vector<size_t> h_np(host_oracle ? B : 0, 0);

@@ -16,6 +16,7 @@ reference-generated vectors: parity of this layer with the Haskell implementatio
 from __future__ import annotations
 
 import hashlib
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -868,6 +869,11 @@ class NativeRangeProofs:
         except Exception:
             pass
 
+    def set_option(self, name: str, value: int):
+        """bppp_rp_set_option: comb_min, comb_budget, comb_bits, split_min, host_oracle_max, fold_points, host_algebra, timing"""
+        from .capi import RP_OPTIONS
+        self.gpu._check(self.gpu.lib.bppp_rp_set_option(self.h, RP_OPTIONS[name], int(value)), "bppp_rp_set_option")
+
     def prove_batch(self, inputs: Sequence[Sequence[Tuple[int, int, int]]], rand_prefixes: Sequence[bytes]) -> List[Tuple[bytes, bytes]]:
         """bppp_rp_prove_batch: inputs[b] = [(amount, type, blinding) per range]; rand_prefixes[b] = the hashToScalar prefix of
         proof b (all of one length).  Returns [(commitments file, proof file)] — the bytes encoding.encode_proof(prove(...)) gives."""
@@ -892,10 +898,14 @@ class NativeRangeProofs:
         cb, pb = self.shape["coms_bytes"], self.shape["proof_bytes"]
         return [(cf[b * cb:(b + 1) * cb].tobytes(), pf[b * pb:(b + 1) * pb].tobytes()) for b in range(B)]
 
-    def verify_batch(self, coms_files: Sequence[bytes], proof_files: Sequence[bytes], seed: bytes, want_status: bool = False, want_challenges: bool = False):
-        """bppp_rp_verify_batch on host byte strings: returns accept, or (accept, status list, challenges per proof) as asked"""
+    def verify_batch(self, coms_files: Sequence[bytes], proof_files: Sequence[bytes], seed: Optional[bytes] = None, want_status: bool = False,
+                     want_challenges: bool = False):
+        """bppp_rp_verify_batch on host byte strings: returns accept, or (accept, status list, challenges per proof) as asked.
+        `seed` is the verifier's randomness behind the batch weights: fresh from os.urandom unless given (fixed seeds are for tests)."""
         import ctypes as C
         import numpy as np
+        if seed is None:
+            seed = os.urandom(32)
         B = len(proof_files)
         if len(coms_files) != B or len(seed) != 32:
             raise ValueError("one commitments file per proof and a 32-byte seed are required")
@@ -904,20 +914,23 @@ class NativeRangeProofs:
         cb, pb = np.frombuffer(b"".join(coms_files), dtype=np.uint8), np.frombuffer(b"".join(proof_files), dtype=np.uint8)
         return self._verify(self.gpu.lib.bppp_rp_verify_batch, B, C.c_void_p(cb.ctypes.data), C.c_void_p(pb.ctypes.data), seed, want_status, want_challenges, (cb, pb))
 
-    def verify_batch_device(self, batch: int, d_coms: int, d_proofs: int, seed: bytes, want_status: bool = False, want_challenges: bool = False):
+    def verify_batch_device(self, batch: int, d_coms: int, d_proofs: int, seed: Optional[bytes] = None, want_status: bool = False, want_challenges: bool = False):
         import ctypes as C
+        if seed is None:
+            seed = os.urandom(32)
         return self._verify(self.gpu.lib.bppp_rp_verify_batch_device, batch, C.c_void_p(d_coms), C.c_void_p(d_proofs), seed, want_status, want_challenges, None)
 
-    def verify_batch_device_point(self, batch: int, d_coms: int, d_proofs: int, seed: bytes) -> Tuple[bool, Point]:
-        """(accept, the combined point) — the partial result of one rank when the batch is sharded proof-per-GPU"""
+    def verify_batch_device_point(self, batch: int, d_coms: int, d_proofs: int, seed: bytes, index_offset: int = 0) -> Tuple[bool, Point]:
+        """bppp_rp_verify_shard_device: (accept, the combined point) — the partial result of one rank when the job is sharded
+        proof-per-GPU; this rank holds proofs [index_offset, index_offset + batch) of the job, every rank passes the same seed."""
         import ctypes as C
         import numpy as np
         from .capi import array_to_point
         acc, out = C.c_int(0), np.zeros(8, dtype=np.uint64)
         sd = np.frombuffer(seed, dtype=np.uint8)
-        rc = self.gpu.lib.bppp_rp_verify_batch_device(self.h, batch, C.c_void_p(d_coms), C.c_void_p(d_proofs), C.c_void_p(sd.ctypes.data), C.byref(acc), None, None,
-                                                      C.c_void_p(out.ctypes.data))
-        self.gpu._check(rc, "bppp_rp_verify_batch_device")
+        rc = self.gpu.lib.bppp_rp_verify_shard_device(self.h, batch, index_offset, C.c_void_p(d_coms), C.c_void_p(d_proofs), C.c_void_p(sd.ctypes.data),
+                                                      C.byref(acc), None, None, C.c_void_p(out.ctypes.data))
+        self.gpu._check(rc, "bppp_rp_verify_shard_device")
         return bool(acc.value), array_to_point(out)
 
     def _verify(self, fn, B, pc, pp, seed, want_status, want_challenges, keep):

@@ -25,9 +25,18 @@
  * bppp_ctx_destroy closes the context (further calls through it or its children fail with BPPP_ERR_ARG) and drops the caller's
  * reference; the stream and workspaces are released when the last child is destroyed, so finalisers may run in any order.
  *
- * Untrusted input: the verifier entry points (bppp_nl_verify, bppp_ip_verify, bppp_nl_verify_batch_device, bppp_rp_verify_batch*)
+ * Untrusted input: the verifier entry points that take DECODED values (bppp_nl_verify, bppp_ip_verify, bppp_nl_verify_batch_device)
  * check that proof-supplied scalars are canonical (< n) and points are on the curve (or the infinity encoding) and return
- * BPPP_ERR_ARG / BPPP_ERR_POINT otherwise; the batch weights rho must be non-zero.
+ * BPPP_ERR_ARG / BPPP_ERR_POINT otherwise; the batch weights rho must be non-zero.  The entry points that take the reference's FILES
+ * (bppp_rp_verify_batch*, bppp_rp_verify_shard_device) decode them as the reference does: `get` of Binary (Prime p) ends in toP
+ * (src/Encoding.hs:76-80), i.e. a coordinate >= p or a scalar >= n is REDUCED, not refused, so a proof has more than one accepted
+ * byte encoding (the files are malleable exactly as the reference's are); an x with no curve point is BPPP_RP_MALFORMED.
+ *
+ * Side channels: the PROVER entry points are not constant-time.  The fixed-base comb walk (csrc/comb.hip) indexes its HBM table by
+ * the signed digits of secret scalars (blindings included) and skips zero scalars per lane, and the bucket method sorts by secret
+ * digits; memory access pattern and running time depend on the witness.  The reference is not constant-time either (Integer /
+ * GMP arithmetic, testBit-driven additions, src/Commitment.hs:325-335); a deployment that shares the GPU with an adversary needs
+ * its own isolation.
  */
 #ifndef BPPP_H
 #define BPPP_H
@@ -327,6 +336,28 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
                    const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out);
 void bppp_rp_destroy(bppp_rp *rp);
 int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out);
+/* Tuning knobs of one handle.  Every knob has a measured default; the BPPP_RP_* environment variables of the
+ * same names are read ONCE, at bppp_rp_create, as initial values — no entry point reads the environment per call.  None changes a
+ * result (asserted byte for byte by the tests).
+ *   COMB_MIN        first batch size — or cumulative number of proofs proved — at which the PROVER builds its fixed-base comb table
+ *                   (default 1024).  The table is a persistent allocation that lives until bppp_rp_destroy.
+ *   COMB_BUDGET     bytes the table may take (default 32 GiB; additionally never more than half of the HBM free at build time);
+ *                   0 = never build one (bucket MSMs and the point-folding argument serve every batch).
+ *   COMB_BITS       force the table's window width (4..18; skips the budget), 0 = widest that fits.
+ *   SPLIT_MIN       smallest prove batch run as two half-batches in flight on a twin context (default 4096); 0 = never split.
+ *   HOST_ORACLE_MAX largest batch whose Fiat-Shamir hashing runs on host cores (defaults: 8 proofs verifying, 64 proving; UINT64_MAX
+ *                   restores them).
+ *   FOLD_POINTS     1 = the point-folding argument although a table exists;  HOST_ALGEBRA 1 = prover's field algebra on the host;
+ *   TIMING          1 = phase times on stderr. */
+#define BPPP_RP_OPT_COMB_MIN 1
+#define BPPP_RP_OPT_COMB_BUDGET 2
+#define BPPP_RP_OPT_COMB_BITS 3
+#define BPPP_RP_OPT_SPLIT_MIN 4
+#define BPPP_RP_OPT_HOST_ORACLE_MAX 5
+#define BPPP_RP_OPT_FOLD_POINTS 6
+#define BPPP_RP_OPT_HOST_ALGEBRA 7
+#define BPPP_RP_OPT_TIMING 8
+int bppp_rp_set_option(bppp_rp *rp, int option, uint64_t value);
 /* Host-only helpers (no context, no GPU): the shape `setup` gives a schema (nrmLen, linLen, rounds = optimalWitnessSize, file sizes);
  * `digits` of one value in one range (src/RangeProof/TypedReciprocal.hs:125-127: greedy mixed-radix digits, the first one binary when
  * the range needs a bit; cap = capacity of out_digits); and the CLI's hash-to-field `hash = decode . SHA.hash` (app/Main.hs:64-65:
@@ -339,16 +370,22 @@ int bppp_hash_to_scalar(const uint8_t *data, size_t len, uint64_t out[4]);
  * proof_files [batch][proof_bytes] — decodeProof (src/RangeProof.hs:68-85, src/Encoding.hs:97-128: x-only points, square roots and
  * sign selection on the device), verifyM (src/RangeProof.hs:103-105): verifyTRRPM with its three oracle calls
  * (TypedReciprocal.hs:447-467) and verifyBPM with one per round (src/Bulletproof.hs:370-378), all SHA-256 on the device, then ONE
- * combined MSM over sum_b rho_b T_b (rho_0 = 1, rho_b = decode(SHA-256(seed <> b)), `seed` = 32 bytes of the
- * VERIFIER's randomness).  *accept = 1 iff every proof decodes and the combination is the identity.
+ * combined MSM over sum_b rho_b T_b.  `seed` = 32 bytes of the VERIFIER's fresh secret randomness (never a constant
+ * outside tests); rho_b = decode(SHA-256(seed <> le64(index_offset + b) <> t_b <> e_last_b <> final witness scalars of b)): bound to
+ * the seed, to the proof's position in the whole job and to every byte of the proof (t and e_last are transcript hashes over all its
+ * commitments and responses), never fixed to 1.  *accept = 1 iff every proof decodes and the combination is the identity.
  * proof_status (may be NULL, [batch]): BPPP_RP_VALID / _INVALID / _MALFORMED (an x coordinate with no curve point: `Nothing` in
  * the reference); when the batch is rejected the culprits are found by bisection over sub-batches (each a combined MSM).
  * challenges_out (may be NULL, [batch][7 + rounds][4]): (e, x, r0, q, x', r1, t) then the argument's challenges LAST ROUND FIRST
  * (src/Bulletproof.hs:374) — what the injected-oracle route would have been given; for parity tests.
- * combined_xy (may be NULL): the combined point sum_b rho_b MSM(T_b) itself (infinity = all zero).  With the batch sharded
- * proof-per-GPU every rank gets its own partial point; the ranks all-gather the 64-byte points (RCCL) and add them with
- * bppp_sum_points: the whole job verifies iff that sum is the identity and no rank saw a malformed proof.
- * _device: the files are already in HBM (the timed configuration of bench.py); the host variant uploads them first. */
+ * combined_xy (may be NULL): the combined point sum_b rho_b MSM(T_b) itself (infinity = all zero).
+ * _device: the files are already in HBM (the timed configuration of bench.py); the host variant uploads them first.
+ * bppp_rp_verify_shard_device: one rank's share of a job sharded proof-per-GPU: this rank holds proofs
+ * [index_offset, index_offset + batch) of the job and every rank passes the SAME seed; the ranks all-gather their 64-byte combined
+ * points (RCCL) and add them with bppp_sum_points: the job verifies iff that sum is the identity and no rank saw a malformed proof.
+ * Because the weights are indexed by the position in the JOB (and bound to the proofs), error terms cannot cancel between ranks: the
+ * sum over ranks is the same random linear combination a single rank would have formed over all proofs.  bppp_rp_verify_batch_device
+ * is the shard with index_offset = 0. */
 #define BPPP_RP_VALID 0u
 #define BPPP_RP_INVALID 1u
 #define BPPP_RP_MALFORMED 2u
@@ -356,6 +393,8 @@ int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, c
                          uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy);
 int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32], int *accept,
                                 uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy);
+int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32],
+                                int *accept, uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy);
 
 /* Batch prover: `batch` proofs of this setup in lockstep — proveM of RangeProof (src/RangeProof.hs:93-97) = proveTRRPM
  * (src/RangeProof/TypedReciprocal.hs:399-446; blinding algebra src/RangeProof/Internal.hs:118-196) followed by proveBPM
@@ -366,7 +405,7 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
  * Outputs are the reference's files: coms_files [batch][coms_bytes], proof_files [batch][proof_bytes].  Every commitment is
  * computed on the device (input commitments through a fixed-base table of g, H0, H1; the four range-proof commitments of all
  * proofs and the round commitments of the argument), and so are the per-proof field algebra, the randomness and the transcript
- * hashing; the host cores extract the digits of the plain amounts.  MEMORY: at the first batch of 1024 proofs or more, or once it has proved that many in smaller batches (BPPP_RP_COMB_MIN), the handle
+ * hashing; the host cores extract the digits of the plain amounts.  MEMORY: at the first batch of 1024 proofs or more, or once it has proved that many in smaller batches (bppp_rp_set_option COMB_MIN), the handle
  * builds a fixed-base comb table over the setup's basis [g | H | G] and keeps it until it is destroyed — the widest window (<= 18
  * bits) whose table fits 32 GB: c = 16, 27.6 GB for the 774 points of 64by64, built in ~0.3 s (BPPP_RP_COMB_GB=<GB> changes the budget:
  * 64 GB (c = 17) measured 1 % faster, 128 GB (c = 18) 5 % — the gathers over a larger table cost most of what the fewer additions save;

@@ -19,6 +19,23 @@ from bulletproofspp_amd import rangeproof as RP
 
 pytestmark = pytest.mark.gpu
 
+_OPT_DEFAULTS = {"comb_min": 1024, "comb_bits": 0, "split_min": 4096, "host_oracle_max": 2**64 - 1, "fold_points": 0, "host_algebra": 0}
+
+
+class _options:
+    """bppp_rp_set_option for the duration of a block (the handle's defaults afterwards)"""
+
+    def __init__(self, nat, **kw):
+        self.nat, self.kw = nat, kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.nat.set_option(k, v)
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            self.nat.set_option(k, _OPT_DEFAULTS[k])
+
 
 def _setup(gpu, typed):
     pts = O.hash_points(b"native verify", 120)
@@ -90,6 +107,58 @@ def test_native_reject_and_identify(gpu):
     nat.close()
 
 
+def test_sharded_weights_are_global_and_bound_to_the_proofs(gpu):
+    """The job sharded proof-per-GPU (bppp_rp_verify_shard_device): the weights rho are indexed by the position in the
+    JOB and bound to the proof bytes.  Two copies of one honest proof whose first linear witness scalar is shifted by +d and -d have
+    error terms that cancel under EQUAL weights (the final witness scalars enter no transcript hash, so both copies have the same
+    challenges): placed on two ranks, each at its local slot 0, they must still be rejected by the sum of the rank points.  And the
+    sum of the rank points equals the combined point one rank forms over the whole job."""
+    import torch
+    from bulletproofspp_amd.capi import points_to_array
+    st = _setup(gpu, False)
+    proofs = _proofs(st, 3, False, seed=5)
+    nat = RP.NativeRangeProofs(gpu, st)
+    files = [E.encode_proof(4, p) for p in proofs]
+    fn = st.final_lens[0]
+    d = 0x1234567
+
+    def shifted(pf, delta):
+        b = bytearray(pf)
+        v = E.get_field(bytes(b[32 * fn:32 * fn + 32]), O.N)
+        b[32 * fn:32 * fn + 32] = E.put_field((v + delta) % O.N)
+        return bytes(b)
+    plus, minus = shifted(files[0][1], d), shifted(files[0][1], -d)
+    seed = hashlib.sha256(b"one seed for every rank").digest()
+    dev = torch.device("cuda", 0)
+    up = lambda bs: torch.frombuffer(bytearray(b"".join(bs)), dtype=torch.uint8).to(dev)
+
+    def shard(coms, prfs, offset):
+        dc, dp = up(coms), up(prfs)
+        ok, pt = nat.verify_batch_device_point(len(prfs), dc.data_ptr(), dp.data_ptr(), seed, index_offset=offset)
+        return ok, pt
+    c0 = files[0][0]
+    ok_a, pt_a = shard([c0], [plus], 0)
+    ok_b, pt_b = shard([c0], [minus], 1)
+    assert not ok_a and not ok_b and pt_a is not None and pt_b is not None
+    assert gpu.sum_points(points_to_array([pt_a, pt_b])) is not None, "cancelling pair split across two ranks was accepted"
+    # the same pair inside ONE batch: rejected too (no weight is fixed, every weight depends on the proof's own bytes)
+    ok_ab, pt_ab = shard([c0, c0], [plus, minus], 0)
+    assert not ok_ab and pt_ab == gpu.sum_points(points_to_array([pt_a, pt_b]))
+    # with the offsets dropped (both shards at job position 0) the two error terms differ only by the bytes of the final witness:
+    # still no cancellation, because rho hashes those bytes
+    ok_c, pt_c = shard([c0], [minus], 0)
+    assert gpu.sum_points(points_to_array([pt_a, pt_c])) is not None
+    # honest job [p0, p1 | p2] on two ranks: every rank accepts, the points are the identity; a job with one bad member equals the
+    # single-rank combination point for point
+    ok0, q0 = shard([files[0][0], files[1][0]], [files[0][1], files[1][1]], 0)
+    ok1, q1 = shard([files[2][0]], [files[2][1]], 2)
+    assert ok0 and ok1 and q0 is None and q1 is None
+    ok0, q0 = shard([files[0][0], files[1][0]], [plus, files[1][1]], 0)
+    okw, qw = shard([f[0] for f in files], [plus, files[1][1], files[2][1]], 0)
+    assert not ok0 and not okw and qw == gpu.sum_points(points_to_array([q0, q1]))
+    nat.close()
+
+
 @pytest.mark.parametrize("typed", [False, True])
 def test_native_prover_equals_host_protocol_bytes(gpu, typed):
     """bppp_rp_prove_batch against rangeproof.prove: same inputs, same hashToScalar randomness, same oracle => the same
@@ -116,44 +185,29 @@ def test_native_prover_equals_host_protocol_bytes(gpu, typed):
     assert nat.verify_batch([c for c, _ in got], [p for _, p in got], b"\x07" * 32)
     # the host-algebra path of the library (per-proof field work and hashing in C++ on the host cores; the default does both on the
     # device, csrc/rpprove_dev.hip) writes the same bytes
-    os.environ["BPPP_RP_HOST_ALGEBRA"] = "1"
-    try:
+    with _options(nat, host_algebra=1):
         assert nat.prove_batch(inputs, prefixes) == got
-    finally:
-        del os.environ["BPPP_RP_HOST_ALGEBRA"]
     # the fixed-basis route (large batches take it by default: a comb table over the setup's [g | H | G], csrc/comb.hip — the
     # range-proof commitments and EVERY round commitment of the argument are comb MSMs over the original points with the fold
     # coefficients multiplied into the scalars; no point is folded, no half-GCD is taken, csrc/nlb.hip) writes the same bytes as well
-    os.environ["BPPP_RP_COMB_MIN"] = "1"
-    try:
+    with _options(nat, comb_min=1):
         assert nat.prove_batch(inputs, prefixes) == got
         assert nat.prove_batch(inputs[:3], prefixes[:3]) == got[:3]      # the table is kept by the handle across batches
-        # (up to 8 proofs the oracle of that route runs on the host; with it on the device, as for larger batches: the same bytes)
-        os.environ["BPPP_RP_HOST_ORACLE_MAX"] = "0"
-        try:
+        # (up to 64 proofs the oracle of that route runs on the host; with it on the device, as for larger batches: the same bytes)
+        with _options(nat, host_oracle_max=0):
             assert nat.prove_batch(inputs, prefixes) == got
-        finally:
-            del os.environ["BPPP_RP_HOST_ORACLE_MAX"]
-    finally:
-        del os.environ["BPPP_RP_COMB_MIN"]
     # ... and with the table in place the point-folding route of the argument is still there (the general bppp_nlb_* entry points use it)
-    os.environ["BPPP_NLB_FOLD_POINTS"] = "1"
-    try:
+    with _options(nat, fold_points=1):
         assert nat.prove_batch(inputs, prefixes) == got
-    finally:
-        del os.environ["BPPP_NLB_FOLD_POINTS"]
     # two half-batches in flight on two contexts (the default for large batches, csrc/rpprove.hip): the same bytes, and a refused
     # input in the second half is reported under its index in the whole batch
-    os.environ["BPPP_RP_SPLIT_MIN"] = "2"
-    try:
+    with _options(nat, split_min=2):
         assert nat.prove_batch(inputs, prefixes) == got
         assert nat.prove_batch(inputs[:5], prefixes[:5]) == got[:5]
         worse = [list(r) for r in inputs]
         worse[4][3] = (100 if not typed else 1000, worse[4][3][1], worse[4][3][2])
         with pytest.raises(Exception, match="proof 4"):
             nat.prove_batch(worse, prefixes)
-    finally:
-        del os.environ["BPPP_RP_SPLIT_MIN"]
     # a value outside its range is refused
     bad = [list(r) for r in inputs]
     bad[2][3] = (100 if not typed else 1000, bad[2][3][1], bad[2][3][2])
@@ -178,18 +232,36 @@ def test_native_prover_routes_agree_over_batch_sizes(gpu):
     assert fold.verify_batch([c for c, _ in want], [p for _, p in want], b"\x21" * 32)
     fold.close()
     nat = RP.NativeRangeProofs(gpu, st)
-    os.environ["BPPP_RP_COMB_MIN"] = "1"; os.environ["BPPP_RP_COMB_BITS"] = "7"
-    try:
+    with _options(nat, comb_min=1, comb_bits=7):
         for n in sizes:
             assert nat.prove_batch(inputs[:n], prefixes[:n]) == want[:n], n
-        os.environ["BPPP_RP_SPLIT_MIN"] = "2"
-        try:
+        with _options(nat, split_min=2):
             for n in (2, 9, 65, 130):
                 assert nat.prove_batch(inputs[:n], prefixes[:n]) == want[:n], n
-        finally:
-            del os.environ["BPPP_RP_SPLIT_MIN"]
-    finally:
-        del os.environ["BPPP_RP_COMB_MIN"]; del os.environ["BPPP_RP_COMB_BITS"]
+    nat.close()
+
+
+def test_comb_table_allocation_failure_falls_back_to_the_bucket_route(gpu):
+    """A comb table that cannot be allocated (a forced 18-bit window over 2662 points = 335 GB, more than the card has) must not fail
+    the batch it was meant to speed up: the handle notes the failure, clears the runtime's sticky error and proves on the bucket /
+    point-folding route — byte-identical to a handle that never builds a table; later batches work too."""
+    pts = O.hash_points(b"comb alloc failure", 2 + 261 + 2400)
+    rds = [RP.make_range_data(256, 0, 2**64, True, True, False)] * 300
+    st = RP.setup(RP.GpuBackend(gpu), pts, False, [], rds, "NL")
+    assert (st.nrm_len, st.lin_len) == (2400, 261)
+    rnd = random.Random(4)
+    inputs = [[(rnd.randrange(2**64), 0, rnd.randrange(O.N)) for _ in range(300)] for _ in range(2)]
+    prefixes = [b"alloc %d" % b for b in range(2)]
+    plain = RP.NativeRangeProofs(gpu, st)
+    plain.set_option("comb_budget", 0)
+    want = plain.prove_batch(inputs, prefixes)
+    assert plain.verify_batch([c for c, _ in want], [p for _, p in want])
+    plain.close()
+    nat = RP.NativeRangeProofs(gpu, st)
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 18)
+    assert nat.prove_batch(inputs, prefixes) == want
+    assert nat.prove_batch(inputs[:1], prefixes[:1]) == want[:1]
+    assert nat.verify_batch([c for c, _ in want], [p for _, p in want])
     nat.close()
 
 
@@ -290,11 +362,8 @@ def test_native_layer_on_a_mixed_schema(gpu):
         proof = RP.prove(st, RP.witness(st, inputs[b]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[b]))
         assert got[b] == E.encode_proof(4, proof), b
         assert RP.verify(st, proof, RP.sha256_oracle())
-    os.environ["BPPP_RP_HOST_ALGEBRA"] = "1"
-    try:
+    with _options(nat, host_algebra=1):
         assert nat.prove_batch(inputs, prefixes) == got
-    finally:
-        del os.environ["BPPP_RP_HOST_ALGEBRA"]
     seed = bytes(range(1, 33))
     ok, status, chs = nat.verify_batch([c for c, _ in got], [p for _, p in got], seed, want_status=True, want_challenges=True)
     assert ok and status == [0] * B
