@@ -7,7 +7,11 @@ A "step" is one complete MSM of 2^20 (scalar, affine point) pairs per GPU, input
 HBM, output = the canonical affine sum on the host.  With N > 1 GPUs (one process per GPU,
 torch.distributed over RCCL) every rank owns its own 2^20-term slice of one N*2^20-term MSM (weak
 scaling, no data-path collective); the only exchange is an all-gather of one 64-byte partial point
-per rank, summed locally through the same library.
+per rank, summed locally through the same library.  `python bench.py --gpus N` started plainly
+launches its N ranks itself (launch_ranks: child processes made before torch or HIP are touched);
+under `python -m torch.distributed.run` the ranks are the launcher's.  For N > 1 the line also holds
+the STRONG-scaling figures: `msm_strong_scaling` (one 2^20-term MSM over N ranks) and the verify
+legs as BASELINE.json states configs 4 / 5 (one job of proofs split over the ranks).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_acc_points) against the
 HBM roofline with the ALGORITHMIC 96 bytes per pair (32-B scalar + 64-B affine point, SURVEY.md
@@ -129,7 +133,7 @@ def make_rp_setup(gpu, torch, dev, rank: int, shape: str):
 
 
 def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, steps: int, warmup: int, shape: str = "64by64",
-                      cpu_baseline_leg: bool = False, prove_steps: int = 1):
+                      cpu_baseline_leg: bool = False, prove_steps: int = 1, coll_dev=None):
     """Both range-proof legs on `batch` DISTINCT real proofs of an examples/ shape per GPU, through the library's end-to-end entry points.
 
     prove  (bppp_rp_prove_batch): proveM of RangeProof (src/RangeProof.hs:93-97) for the whole batch in lockstep — phases 1-3 of
@@ -139,7 +143,10 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
            (commitments file + proof file per proof, as the reference writes them) resident in HBM: decodeProof (square roots, sign
            selection), all SHA-256 transcript hashing of verifyTRRPM and verifyBPM, the public scalars, challenge expansion,
            shared-basis merge and ONE combined MSM.  Nothing of a verification is left outside the timed region.  N > 1: proofs are
-           sharded per GPU; the ranks all-gather their 64-byte combined points and add them (the only exchange)."""
+           sharded per GPU; the ranks all-gather their 64-byte combined points and add them (the only exchange).  Two figures for
+           N > 1: STRONG scaling — the configuration BASELINE.json states (config 5: ONE job of `batch` proofs, batch / N per rank;
+           config 4: one job of 128by64+typed proofs on N ranks), which is `value` — and WEAK scaling (`batch` proofs per rank),
+           reported beside it under "weak"."""
     import ctypes as C
     st, nat, count, typed, amount, rng = make_rp_setup(gpu, torch, dev, rank, shape)
     nlen, llen, k, fn, fl, ninit = SHAPES[shape]
@@ -235,6 +242,40 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert res is None
+    # ---- STRONG scaling (BASELINE configs 4 / 5 as stated): ONE job of `batch` proofs, rank r holds proofs [lo_r, hi_r) of it — its own
+    # first hi_r - lo_r files; the proofs of different ranks are distinct — verified by bppp_rp_verify_shard_device with the job-wide seed
+    # (rank 0's os.urandom, broadcast) and the rank's offset; the combined points are all-gathered and added: identity <=> the job verifies
+    strong = None
+    if world > 1:
+        from bulletproofspp_amd.dist import shard_range
+        lo, hi = shard_range(batch, rank, world)
+        mine = hi - lo
+        sd_t = torch.zeros(32, dtype=torch.uint8, device=coll_dev if coll_dev is not None else "cpu")
+        if rank == 0:
+            sd_t.copy_(torch.frombuffer(bytearray(os.urandom(32)), dtype=torch.uint8))
+        dist.broadcast(sd_t, 0)
+        job_seed = bytes(sd_t.cpu().numpy().tobytes())
+
+        def sstep():
+            ok, part = nat.verify_batch_device_point(mine, d_c.data_ptr(), d_p.data_ptr(), job_seed, index_offset=lo)
+            assert ok, "shard of valid proofs did not verify"
+            return combine(part)
+        for _ in range(max(warmup, 1)):
+            sres = sstep()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(steps):
+            sres = sstep()
+        torch.cuda.synchronize()
+        dist.barrier()
+        sdt = time.perf_counter() - ts0
+        t = torch.tensor([sdt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sdt = float(t.item())
+        assert sres is None, "the sum of the rank points of a valid job is not the identity"
+        strong = {"scaling": "strong", "job_proofs": batch, "batch_per_gpu": mine, "value": batch * steps / sdt, "unit": "verifies/s",
+                  "ms_per_job": sdt / steps * 1e3}
     # two verifier handles on two contexts (stream + workspace each), one host thread each, the same files: the hashing stage of one
     # batch — one wavefront per SIMD at this batch size, i.e. half of the chip's issue slots — overlaps the arithmetic of the other.
     # Reported beside the single-call figure (which stays `value`), like the MSM's `concurrent` leg.
@@ -279,8 +320,8 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     # algorithmic bytes per proof: (ninit + 2k) per-proof pairs x 96 B + (nlen + llen + 1) shared-basis scalars x 32 B
     bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
     file_bytes = shp["coms_bytes"] + shp["proof_bytes"]
-    verify = {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s",
-              "ms_per_batch": dt / steps * 1e3, "batch_per_gpu": batch, "combined_msm_terms": terms,
+    verify = {"metric": "aggregated_64bit_range_proof_verifies_per_sec", "value": world * batch * steps / dt, "unit": "verifies/s", "scaling": "weak" if world > 1 else "strong",
+              "ms_per_batch": dt / steps * 1e3, "batch_per_gpu": batch, "job_proofs": world * batch, "combined_msm_terms": terms,
               "algorithmic_bytes_per_proof": bytes_per_proof, "encoded_bytes_per_proof": file_bytes,
               "achieved_GBps": world * batch * steps * bytes_per_proof / dt / 1e9, "hbm_frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world),
               "shape": f"{shape}: nrmLen {nlen}, linLen {llen}, {k} rounds, {ninit}+{2 * k} per-proof points (SURVEY.md App. B)",
@@ -292,6 +333,14 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
               "concurrent": concurrent,
               "host_buffer_call": {"entry": "bppp_rp_verify_batch (files in pageable host memory, %d B per proof over PCIe)" % file_bytes,
                                    "ms_per_batch": hdt * 1e3, "value": batch / hdt, "unit": "verifies/s"}}
+    if strong is not None:
+        # N > 1: the stated configuration (one job, strong scaling) is the leg's `value`; the weak figure (a full batch per GPU) stays beside it
+        weak = {k_: verify[k_] for k_ in ("value", "unit", "ms_per_batch", "batch_per_gpu", "job_proofs", "achieved_GBps", "hbm_frac")}
+        weak["scaling"] = "weak"
+        verify.update({"value": strong["value"], "scaling": "strong", "ms_per_batch": strong["ms_per_job"], "batch_per_gpu": strong["batch_per_gpu"],
+                       "job_proofs": batch, "achieved_GBps": strong["value"] * bytes_per_proof / 1e9,
+                       "hbm_frac": strong["value"] * bytes_per_proof / 1e9 / (HBM_PEAK_GBS * world), "weak": weak,
+                       "combined_msm_terms": nlen + llen + 1 + strong["batch_per_gpu"] * (ninit + 2 * k)})
     if cpu_baseline_leg and rank == 0:
         # the reference verifies ONE proof with ONE 256-row Straus MSM over nlen + llen + 1 + ninit + 2k terms
         # (src/Bulletproof.hs:377): time the oracle's restatement of that on this host (single thread)
@@ -342,6 +391,55 @@ def gpu_device(dev) -> int:
     return dev.index if getattr(dev, "index", None) is not None else 0
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` started plainly: this process — which has imported neither torch nor the library and has made no
+    HIP call — starts N fresh child processes of this same script (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, rendezvous on 127.0.0.1), relays rank 0's JSON line and returns non-zero if any rank failed.  Nothing is
+    exec'ed from a GPU-initialised process; `python -m torch.distributed.run ... bench.py --gpus N` keeps working (the children of
+    that launcher find WORLD_SIZE set and go straight to the benchmark)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p_ in enumerate(procs):
+            if p_.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, p_ in enumerate(procs) if p_.returncode != 0), None)
+    if failed is not None:                      # the others may sit in a collective waiting for the dead rank: end exactly the processes started here
+        time.sleep(2.0)
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+    reader.join(timeout=10)
+    text = out0[0] if out0 else ""
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if failed is not None:
+        print(f"bench.py: rank {failed} exited with {procs[failed].returncode}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,6 +458,9 @@ def main():
                                                                   "from their seeds) and asserts the combined point equals it")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # plain start: become the launcher BEFORE torch / HIP are touched
+
     import torch
     import bulletproofspp_amd as b
     from bulletproofspp_amd.capi import array_to_point, points_to_array
@@ -368,8 +469,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` plainly, or under torch.distributed.run with --nproc-per-node N")
     if args.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -434,6 +534,32 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # STRONG scaling of the MSM metric beside the weak headline: ONE 2^log2n-term MSM, rank r owns the contiguous slice
+    # shard_range(n, r, N) of it (here: the first hi - lo pairs of its own inputs), partial points all-gathered and added
+    msm_strong = None
+    if world > 1:
+        from bulletproofspp_amd.dist import shard_range
+        lo_, hi_ = shard_range(n, rank, world)
+        ns_ = hi_ - lo_
+
+        def strong_step():
+            part = gpu.msm_device(dsc.data_ptr(), dpts.data_ptr(), ns_, args.window)
+            return combine(part)
+        for _ in range(max(1, args.warmup)):
+            sres_ = strong_step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tS = time.perf_counter()
+        for _ in range(args.steps):
+            sres_ = strong_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        sdt_ = time.perf_counter() - tS
+        t = torch.tensor([sdt_], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sdt_ = float(t.item())
+        msm_strong = {"scaling": "strong", "workload": f"ONE pedersen_msm_2^{args.log2n}_secp256k1 sharded terms/{world}", "pairs_per_gpu": ns_,
+                      "value": n * args.steps / sdt_, "unit": "pairs/s", "ms_per_msm": sdt_ / args.steps * 1e3}
     combined_check = None
     if world > 1 and args.check_combined and rank == 0:
         # the sharded job as ONE single-rank MSM: every rank's slice regenerated from its seed, concatenated in rank order
@@ -586,8 +712,8 @@ def main():
     if args.verify_batch > 0 and not args.headline_only:
         vsteps = max(3, args.steps // 2)
         verify, prove = bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, args.verify_batch, vsteps, 1, "64by64",
-                                          cpu_baseline_leg=(world == 1 and not args.no_cpu_baseline))
-        v2, p2 = bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, max(1, args.verify_batch // 2), vsteps, 1, "128by64+typed")
+                                          cpu_baseline_leg=(world == 1 and not args.no_cpu_baseline), coll_dev=coll_dev)
+        v2, p2 = bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, max(1, args.verify_batch // 2), vsteps, 1, "128by64+typed", coll_dev=coll_dev)
         verify["other_shapes"] = [v2]
         prove["other_shapes"] = [p2]
         if world == 1 and not args.no_cpu_baseline:
@@ -656,6 +782,8 @@ def main():
             mt_rate, mt_cores, mt_dt = cpu_baseline_threads(sc_np, pts_np, per_thread)
             out["cpu_baseline_all_cores"] = {"value": mt_rate, "unit": "pairs/s", "cores": mt_cores, "kind": "port",
                                              "sample": f"{mt_cores} threads x {per_thread} pairs, same restatement, one slice per thread", "seconds": mt_dt}
+        if msm_strong is not None:
+            out["msm_strong_scaling"] = msm_strong
         if combined_check is not None:
             out["combined_check"] = combined_check
         if small is not None:

@@ -1,8 +1,11 @@
-"""Multi-GPU readiness on ONE card: bench.py's N > 1 path with two ranks on cuda:0 (gloo for the 64-byte exchange, processes
-started by torch.distributed.run before anything touches the GPU), every kernel the real HIP one.  The MSM leg shards the terms,
-the verify leg shards the proofs; in both the ranks all-gather their partial points and add them (bulletproofspp_amd/dist.py).
-Checked: the combined MSM point equals the single-rank MSM over all terms (--check-combined), every rank's batch verifies and the
-combined verification point is the identity (asserted inside bench.py), and the JSON line reports n_gpus = 2."""
+"""Multi-GPU readiness on ONE card: bench.py's N > 1 path with two ranks on cuda:0 (gloo for the 64-byte exchange), every kernel the
+real HIP one.  `python bench.py --gpus 2` is started PLAINLY, as the driver starts it: the parent launches its two ranks itself before
+anything touches the GPU (bench.py launch_ranks).  The MSM legs shard the terms, the verify legs shard the proofs; in both the ranks
+all-gather their partial points and add them (bulletproofspp_amd/dist.py).  Checked: the combined MSM point equals the single-rank
+MSM over all terms (--check-combined); the verify leg reports BOTH scaling modes — strong (BASELINE configs 4 / 5: one job of proofs
+split over the ranks, bppp_rp_verify_shard_device with the job-wide seed and per-rank offsets; the summed rank points are the
+identity, asserted inside bench.py) and weak (a full batch per rank) — and the JSON line reports n_gpus = 2.  The torch.distributed.run
+route is kept working too (second test, headline leg only)."""
 import json
 import os
 import random
@@ -15,17 +18,34 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_gpu():
-    port = 29600 + random.randrange(1500)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2n", "17", "--verify-batch", "256", "--backend", "gloo",
-           "--same-device", "--check-combined", "--no-cpu-baseline", "--msm-streams", "1"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+def _json_line(p):
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_two_ranks_plain_start_both_scaling_modes():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2n", "17", "--verify-batch", "256", "--backend", "gloo",
+           "--same-device", "--check-combined", "--no-cpu-baseline", "--msm-streams", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = _json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["combined_check"].startswith("sum of 2 rank-local MSMs == single-rank MSM")
-    assert out["verify"]["batch_per_gpu"] == 256 and out["verify"]["value"] > 0
+    ms = out["msm_strong_scaling"]
+    assert ms["scaling"] == "strong" and ms["pairs_per_gpu"] == (1 << 17) // 2 and ms["value"] > 0
+    v = out["verify"]
+    assert v["scaling"] == "strong" and v["job_proofs"] == 256 and v["batch_per_gpu"] == 128 and v["value"] > 0        # config 5's layout
+    assert v["weak"]["scaling"] == "weak" and v["weak"]["batch_per_gpu"] == 256 and v["weak"]["job_proofs"] == 512 and v["weak"]["value"] > 0
+    v4 = v["other_shapes"][0]                                                                                          # config 4's layout
+    assert v4["scaling"] == "strong" and v4["job_proofs"] == 128 and v4["batch_per_gpu"] == 64 and v4["weak"]["batch_per_gpu"] == 128
     assert out["prove"]["replicas"] == 2
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    port = 29600 + random.randrange(1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "16", "--verify-batch", "0", "--backend", "gloo",
+           "--same-device", "--no-cpu-baseline", "--msm-streams", "1"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = _json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
+    assert out["n_gpus"] == 2 and out["msm_strong_scaling"]["pairs_per_gpu"] == (1 << 16) // 2
