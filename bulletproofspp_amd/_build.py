@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "lib")
 HIP_SOURCES = ["msm.hip", "basis.hip", "comb.hip", "fold.hip", "rounds.hip", "nl.hip", "nlb.hip", "nlbatch.hip", "ip.hip", "trrp.hip", "rp.hip", "rpprove.hip", "rpprove_dev.hip", "glv.hip", "capi.hip"]
 TEST_SOURCES = ["testhooks.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def _newer(target: str, deps) -> bool:
@@ -49,15 +49,15 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(cc, jobs))
     out = os.path.join(LIB, "libbppp_hip.so")
     objs = [os.path.join(LIB, "obj", s.replace(".hip", ".o")) for s in HIP_SOURCES]
-    if force or jobs or _newer(out, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    if force or jobs or _newer(out, objs + [os.path.join(CSRC, "exports.map")]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     tout = os.path.join(LIB, "libbppp_hip_test.so")
     tobjs = [os.path.join(LIB, "obj", s.replace(".hip", ".o")) for s in TEST_SOURCES]
     if force or jobs or _newer(tout, tobjs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tout] + tobjs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", tout] + tobjs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -47,6 +47,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#pragma GCC visibility push(default)
 
 #define BPPP_OK 0
 #define BPPP_ERR_ARG (-1)      /* bad length / null pointer / unsupported parameter */
@@ -444,6 +446,7 @@ int bppp_download(bppp_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int bppp_profile_enable(bppp_ctx *ctx, int on);
 int bppp_profile_read(bppp_ctx *ctx, double ms[BPPP_NUM_STAGES], uint64_t *calls, int reset);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

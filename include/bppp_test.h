@@ -10,6 +10,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 #define BPPP_FE_ADD 0
 #define BPPP_FE_SUB 1
 #define BPPP_FE_MUL 2
@@ -24,6 +25,7 @@ int bppp_test_point_op(bppp_ctx *ctx, int op, const uint64_t *p, const uint64_t 
 /* Measured ceiling of the field layer: modular multiplications per second of a kernel that does nothing but independent
  * Fq multiplications (10x26-bit limbs) at 8 wavefronts per SIMD.  bench.py quotes the MSM's multiplication rate against it. */
 int bppp_test_mulmod_rate(bppp_ctx *ctx, int iters, double *mulmods_per_sec);
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

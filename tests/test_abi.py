@@ -34,6 +34,15 @@ def test_library_exports_every_declared_symbol():
     assert lib.bppp_version().startswith(b"bppp-hip")
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table of the product library holds the bppp_* entry points of
+    include/bppp.h and nothing else (no C++ internals, no kernel handles)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.lib_path()], capture_output=True, text=True, check=True).stdout
+    names = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert names == _declared("bppp.h"), sorted(set(names) ^ set(_declared("bppp.h")))
+
+
 def test_rational_reduce_host_entry_point():
     import pyoracle as O
     lib = capi.load_library()
