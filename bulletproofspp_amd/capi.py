@@ -23,7 +23,7 @@ SYMBOLS = [
     "bppp_nl_create", "bppp_nl_destroy", "bppp_nl_lengths", "bppp_nl_round_commit", "bppp_nl_round_collapse",
     "bppp_nl_get_witness", "bppp_nl_download", "bppp_nl_verify", "bppp_nl_verify_batch_device", "bppp_nl_prove", "bppp_nl_verify_challenges",
     "bppp_nlb_create", "bppp_nlb_destroy", "bppp_nlb_lengths", "bppp_nlb_round_commit", "bppp_nlb_round_collapse", "bppp_nlb_get_witness",
-    "bppp_ip_create", "bppp_ip_destroy", "bppp_ip_lengths", "bppp_ip_round_commit", "bppp_ip_round_collapse", "bppp_ip_get_witness", "bppp_ip_verify",
+    "bppp_ip_create", "bppp_ip_destroy", "bppp_ip_lengths", "bppp_ip_round_commit", "bppp_ip_round_collapse", "bppp_ip_get_witness", "bppp_ip_verify", "bppp_ip_verify_batch_device",
     "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
     lib.bppp_ip_get_witness.argtypes = [vp, vp, vp, vp]
     lib.bppp_ip_verify.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, vp]
     lib.bppp_nl_verify_batch_device.argtypes = [vp] + [sz] * 7 + [vp] * 16
+    lib.bppp_ip_verify_batch_device.argtypes = [vp] + [sz] * 7 + [vp] * 16
     lib.bppp_nl_verify.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, vp]
     lib.bppp_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.bppp_device_free.argtypes = [vp, vp]

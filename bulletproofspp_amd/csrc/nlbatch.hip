@@ -14,6 +14,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "fe.hip.h"
+#include "modinv.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -217,6 +218,126 @@ __global__ void __launch_bounds__(256) k_vb_validate_points(const uint32_t *__re
   if (!ok) atomicOr(flags, 2u);
 }
 
+
+// ------------------------------------------------------------------------------------------------ inner-product flavour
+// The same batch check for B arguments of src/Bulletproof/InnerProductArgument.hs.  Per proof b, with r_b the argument of makeNorm
+// (:194-206; q = r^4), fm = fn / 2 final pairs, es LAST round first:
+//   witness through makeNorm 1 (RangeProof.hs:81):  vx_j = (w_2j + w_2j+1) / 2,  vy_j = (w_2j+1 - w_2j) / 2
+//   tsX = tensor' vx (1/es) (iterate (^2) q),  tsY = tensor' vy es (repeat 1)                                   (:118-119)
+//   the verifier's scalars on the TRANSFORMED basis g'_j = g_2j+1 + r g_2j, h'_j = g_2j+1 - r g_2j are px_j - tsX_j and
+//   py_j - tsY_j with px = pub_2j / (2r) + pub_2j+1 / 2, py = -pub_2j / (2r) + pub_2j+1 / 2 (makeNorm of the public vector).
+// r differs per proof, so the transformed basis cannot be shared — but the commit is linear in the points:
+//   (px - tsX) g' + (py - tsY) h' = [pub_2j - r (tsX_j - tsY_j)] g_2j + [pub_2j+1 - (tsX_j + tsY_j)] g_2j+1
+// i.e. the basis change folds into the scalars on the ORIGINAL shared basis (no scalar multiplication per pair, no 1 / r), and the
+// sums over the batch land on [G | H | g] exactly as in the norm-linear flavour.
+//   Linear (:172-181): challenges inverted, tl = tensor' (n x) (1/es) (repeat 1); scalar on H_j = pub_lin_x_j - tl_j
+//   sc = 4 sum_j qF^(j+1) vx_j vy_j + sum_j c_j tl_j,  qF = q^(2^k)  (:116, :176-178; s = 4 from makeNorm);  g: sp - sc
+//   responses: makeEs e = (1 / e, e) (:68)
+// facx[b] = [q^(2^r) (r < k) | 1 / e_r (first round first)], facy[b] = [unused | e_r]; v[b] = [vx (fm) | vy (fm)]
+__global__ void __launch_bounds__(64) k_ipvb_factors(const uint32_t *__restrict__ r_in, const uint32_t *__restrict__ es, const uint32_t *__restrict__ wit_norm,
+                                                     uint32_t batch, int k, uint32_t fm, uint32_t *__restrict__ facx, uint32_t *__restrict__ facy,
+                                                     uint32_t *__restrict__ qf, uint32_t *__restrict__ v, uint32_t *__restrict__ flags) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const fe r = fe_load(r_in + (size_t)b * 8), r2 = fe_sqr<1>(r);
+  fe qp = fe_sqr<1>(r2);
+  uint32_t *fx = facx + (size_t)b * 2 * k * 8, *fy = facy + (size_t)b * 2 * k * 8;
+  // 1 / e for the k challenges: one inversion (Montgomery's trick along the lane); a zero challenge has no inverse: flagged
+  fe run = fe_one();
+  for (int i = 0; i < k; i++) {
+    const fe e = fe_load(es + ((size_t)b * k + (k - 1 - i)) * 8);         // first round first
+    if (fe_is_zero(e)) atomicOr(flags, 8u);
+    fe_store(fx + (size_t)i * 8, qp);
+    fe_store(fy + (size_t)i * 8, fe_one());
+    fe_store(fy + (size_t)(k + i) * 8, e);
+    fe_store(fx + (size_t)(k + i) * 8, run);                               // prefix product e_0 .. e_{i-1}
+    run = fe_mul<1>(run, e);
+    qp = fe_sqr<1>(qp);
+  }
+  fe_store(qf + (size_t)b * 8, qp);
+  fe inv = fe_modinv<1>(run);
+  for (int i = k - 1; i >= 0; i--) {
+    const fe e = fe_load(fy + (size_t)(k + i) * 8), pre = fe_load(fx + (size_t)(k + i) * 8);
+    fe_store(fx + (size_t)(k + i) * 8, fe_mul<1>(inv, pre));
+    inv = fe_mul<1>(inv, e);
+  }
+  fe half = fe_zero();                                                     // (n + 1) / 2
+  { const fe n = fr_modulus(); uint32_t carry = 1;
+    fe t; for (int i = 0; i < 8; i++) { const uint64_t x = (uint64_t)n.v[i] + carry; t.v[i] = (uint32_t)x; carry = (uint32_t)(x >> 32); }
+    for (int i = 0; i < 8; i++) half.v[i] = (t.v[i] >> 1) | (i < 7 ? t.v[i + 1] << 31 : carry << 31); }
+  for (uint32_t j = 0; j < fm; j++) {
+    const fe w0 = fe_load(wit_norm + ((size_t)b * 2 * fm + 2 * j) * 8), w1 = fe_load(wit_norm + ((size_t)b * 2 * fm + 2 * j + 1) * 8);
+    fe_store(v + ((size_t)b * 2 * fm + j) * 8, fe_mul<1>(half, fe_add<1>(w0, w1)));
+    fe_store(v + ((size_t)b * 2 * fm + fm + j) * 8, fe_mul<1>(half, fe_sub<1>(w1, w0)));
+  }
+}
+// partial[kt][i] = sum_{b in tile kt} rho_b * (coefficient of proof b on G_i), one (tile, position) per lane
+__global__ void __launch_bounds__(256) k_ipvb_norm(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ r_in, const uint32_t *__restrict__ pub,
+                                                   const uint32_t *__restrict__ v, uint32_t fm, const uint32_t *__restrict__ facx, const uint32_t *__restrict__ facy,
+                                                   uint32_t batch, uint32_t nlen, int k, uint32_t ntiles, uint32_t *__restrict__ partial) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)ntiles * nlen) return;
+  const uint32_t kt = (uint32_t)(g / nlen), i = (uint32_t)(g % nlen), j = i >> 1;
+  fe acc = fe_zero();
+  const uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
+  for (uint32_t b = b0; b < b1; b++) {
+    const fe tx = tensor_at(v + (size_t)b * 2 * fm * 8, fm, facx + (size_t)b * 2 * k * 8, k, j, true);
+    const fe ty = tensor_at(v + ((size_t)b * 2 * fm + fm) * 8, fm, facy + (size_t)b * 2 * k * 8, k, j, false);
+    const fe p = fe_load(pub + ((size_t)b * nlen + i) * 8);
+    const fe d = (i & 1u) ? fe_sub<1>(p, fe_add<1>(tx, ty)) : fe_sub<1>(p, fe_mul<1>(fe_load(r_in + (size_t)b * 8), fe_sub<1>(tx, ty)));
+    acc = fe_add<1>(acc, fe_mul<1>(fe_load(rho + (size_t)b * 8), d));
+  }
+  fe_store(partial + ((size_t)kt * nlen + i) * 8, acc);
+}
+// per proof: gs[b] = rho_b (sp_b - sc_b) and the tail scalars rho_b [init ..., 1 / e_r, e_r ...] in the order the responses are stored
+__global__ void __launch_bounds__(256) k_ipvb_proof(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ sp, const uint32_t *__restrict__ qf,
+                                                    const uint32_t *__restrict__ v, uint32_t fm, const uint32_t *__restrict__ wit_lin, uint32_t fl,
+                                                    const uint32_t *__restrict__ pub_c, uint32_t llen, const uint32_t *__restrict__ facx, int k,
+                                                    const uint32_t *__restrict__ init_sc, uint32_t ninit, const uint32_t *__restrict__ es,
+                                                    uint32_t *__restrict__ gs, uint32_t *__restrict__ tail) {
+  __shared__ uint32_t lds[256 * 8];
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  const uint32_t *f = facx + (size_t)b * 2 * k * 8;
+  const fe r = fe_load(rho + (size_t)b * 8);
+  fe acc = fe_zero();
+  for (uint32_t j = t; j < llen; j += 256) {
+    const fe tl = tensor_at(wit_lin + (size_t)b * fl * 8, fl, f, k, j, false);
+    acc = fe_add<1>(acc, fe_mul<1>(fe_load(pub_c + ((size_t)b * llen + j) * 8), tl));
+  }
+  for (int i = 0; i < 8; i++) lds[t * 8 + i] = acc.v[i];
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)t < d) {
+      fe x, y;
+      for (int i = 0; i < 8; i++) { x.v[i] = lds[t * 8 + i]; y.v[i] = lds[(t + d) * 8 + i]; }
+      x = fe_add<1>(x, y);
+      for (int i = 0; i < 8; i++) lds[t * 8 + i] = x.v[i];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    fe sc; for (int i = 0; i < 8; i++) sc.v[i] = lds[i];
+    const fe q = fe_load(qf + (size_t)b * 8);
+    fe w = q, nrm = fe_zero();
+    for (uint32_t j = 0; j < fm; j++) {
+      nrm = fe_add<1>(nrm, fe_mul<1>(w, fe_mul<1>(fe_load(v + ((size_t)b * 2 * fm + j) * 8), fe_load(v + ((size_t)b * 2 * fm + fm + j) * 8))));
+      w = fe_mul<1>(w, q);
+    }
+    nrm = fe_dbl<1>(fe_dbl<1>(nrm));                                        // s = 4 (makeNorm)
+    fe_store(gs + (size_t)b * 8, fe_mul<1>(r, fe_sub<1>(fe_load(sp + (size_t)b * 8), fe_add<1>(sc, nrm))));
+  }
+  const uint32_t per = ninit + 2 * (uint32_t)k;
+  for (uint32_t m = t; m < per; m += 256) {
+    fe val;
+    if (m < ninit) val = fe_load(init_sc + ((size_t)b * ninit + m) * 8);
+    else {
+      const uint32_t rr = (m - ninit) >> 1;                                 // stored last round first; facx holds 1 / e first round first
+      val = ((m - ninit) & 1u) ? fe_load(es + ((size_t)b * k + rr) * 8) : fe_load(f + (size_t)(k + (k - 1 - rr)) * 8);
+    }
+    fe_store(tail + ((size_t)b * per + m) * 8, fe_mul<1>(r, val));
+  }
+}
+
 }  // namespace bppp
 
 using namespace bppp;
@@ -296,6 +417,89 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
     if (hflags & 2u) rc = fail(ctx, BPPP_ERR_POINT, "nl_verify_batch: a point is not on the curve");
     else if (hflags & 1u) rc = fail(ctx, BPPP_ERR_ARG, "nl_verify_batch: a scalar is not canonical (>= n)");
     else if (hflags & 4u) rc = fail(ctx, BPPP_ERR_ARG, "nl_verify_batch: a weight rho is zero (it would drop its proof from the combination)");
+  } while (0);
+  hipStreamSynchronize(st);
+  return rc;
+}
+
+// verifyBPM for B arguments of the inner-product flavour (src/Bulletproof/InnerProductArgument.hs; verifyBPM src/Bulletproof.hs:370-378):
+// same layout and result contract as bppp_nl_verify_batch_device; d_r holds the per-proof argument of makeNorm (the range proofs'
+// challenge q, src/RangeProof/TypedReciprocal.hs:356), fn counts SCALARS of the final norm witness (even).
+extern "C" int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                                           const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_r,
+                                           const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                                           const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                                           const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]) {
+  if (!ctx || !out_xy) return BPPP_ERR_ARG;
+  if (!batch) { memset(out_xy, 0, 64); return BPPP_OK; }
+  if (!d_g_xy || !d_rho || !d_r || !d_sp || (nlen && (!d_norm_g_xy || !d_pub_norm)) || (llen && (!d_lin_h_xy || !d_pub_lin_c || !d_pub_lin_x)) ||
+      (k && (!d_es || !d_responses_xy)) || (fn && !d_wit_norm) || (fl && !d_wit_lin) || (ninit && (!d_init_scalars || !d_init_points_xy)) || k > 30 || (fn & 1) ||
+      batch >= (1u << 24) || nlen >= (1u << 24) || llen >= (1u << 24))
+    return fail(ctx, BPPP_ERR_ARG, "ip_verify_batch: bad arguments");
+  if (ctx_closed(ctx)) return BPPP_ERR_ARG;
+  hipSetDevice(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t per = ninit + 2 * k, shared = nlen + llen + 1, T = shared + batch * per, fm = fn / 2, kk = k ? k : 1;
+  const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
+  const size_t maxlen = nlen > llen ? nlen : llen;
+  size_t words = (2 * batch * 2 * kk + batch + batch * (fn ? fn : 2) + (size_t)ntiles * maxlen + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16 + 64;
+  { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
+  uint32_t *buf = (uint32_t *)ctx->ws2;
+  uint32_t *facx = buf, *facy = facx + batch * 2 * kk * 8, *qf = facy + batch * 2 * kk * 8, *v = qf + batch * 8, *partial = v + batch * (fn ? fn : 2) * 8,
+           *partial2 = partial + (size_t)ntiles * maxlen * 8, *gs = partial2 + (size_t)SUM_GROUPS * maxlen * 8, *sc = gs + batch * 8, *pts = sc + (T + 32) * 8,
+           *flags = pts + T * 16;
+  int rc = BPPP_OK;
+  do {
+    if (hipMemsetAsync(flags, 0, 4, st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "ip_verify_batch: memset"); break; }
+    auto vs = [&](const void *p, uint64_t n, int nz) {
+      if (n) k_vb_validate_scalars<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, nz, flags);
+    };
+    auto vp = [&](const void *p, uint64_t n) {
+      if (n) k_vb_validate_points<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, flags);
+    };
+    vs(d_rho, batch, 1); vs(d_r, batch, 0); vs(d_sp, batch, 0); vs(d_pub_norm, batch * nlen, 0); vs(d_pub_lin_c, batch * llen, 0);
+    vs(d_pub_lin_x, batch * llen, 0); vs(d_es, batch * k, 0); vs(d_wit_norm, batch * fn, 0); vs(d_wit_lin, batch * fl, 0);
+    vs(d_init_scalars, batch * ninit, 0);
+    vp(d_g_xy, 1); vp(d_norm_g_xy, nlen); vp(d_lin_h_xy, llen); vp(d_init_points_xy, batch * ninit); vp(d_responses_xy, batch * 2 * k);
+    k_ipvb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_r, (const uint32_t *)d_es, (const uint32_t *)d_wit_norm, (uint32_t)batch,
+                                                                            (int)k, (uint32_t)fm, facx, facy, qf, v, flags);
+    const uint32_t sper = (ntiles + SUM_GROUPS - 1) / SUM_GROUPS, groups = (ntiles + sper - 1) / sper;
+    if (nlen) {
+      const uint64_t lanes = (uint64_t)ntiles * nlen;
+      k_ipvb_norm<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_r, (const uint32_t *)d_pub_norm, v, (uint32_t)fm,
+                                                                               facx, facy, (uint32_t)batch, (uint32_t)nlen, (int)k, ntiles, partial);
+      k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, sper, (uint32_t)nlen, partial2);
+      k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)nlen, sc);
+    }
+    if (llen) {
+      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, facx, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, facx, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, sper, (uint32_t)llen, partial2);
+      k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)llen, sc + nlen * 8);
+    }
+    k_ipvb_proof<<<dim3((unsigned)batch), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf, v, (uint32_t)fm, (const uint32_t *)d_wit_lin, (uint32_t)fl,
+                                                              (const uint32_t *)d_pub_lin_c, (uint32_t)llen, facx, (int)k, (const uint32_t *)d_init_scalars, (uint32_t)ninit,
+                                                              (const uint32_t *)d_es, gs, sc + shared * 8);
+    k_vb_sum_gs<<<dim3(1), dim3(256), 0, st>>>(gs, (uint32_t)batch, sc + (nlen + llen) * 8);
+    hipError_t he = hipSuccess;
+    if (nlen) he = hipMemcpyAsync(pts, d_norm_g_xy, nlen * 64, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess && llen) he = hipMemcpyAsync(pts + nlen * 16, d_lin_h_xy, llen * 64, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(pts + (nlen + llen) * 16, d_g_xy, 64, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess && ninit)
+      he = hipMemcpy2DAsync(pts + shared * 16, per * 64, d_init_points_xy, ninit * 64, ninit * 64, batch, hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess && k)
+      he = hipMemcpy2DAsync(pts + (shared + ninit) * 16, per * 64, d_responses_xy, 2 * k * 64, 2 * k * 64, batch, hipMemcpyDeviceToDevice, st);
+    if (he != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "ip_verify_batch: assembling the MSM failed"); break; }
+    rc = msm_run(ctx, sc, pts, T, 1, 1, 0, out_xy);
+    if (rc) break;
+    uint32_t hflags = 0;
+    if (hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(ctx, BPPP_ERR_HIP, "ip_verify_batch: reading the validation flags failed"); break;
+    }
+    if (hflags & 2u) rc = fail(ctx, BPPP_ERR_POINT, "ip_verify_batch: a point is not on the curve");
+    else if (hflags & 1u) rc = fail(ctx, BPPP_ERR_ARG, "ip_verify_batch: a scalar is not canonical (>= n)");
+    else if (hflags & 4u) rc = fail(ctx, BPPP_ERR_ARG, "ip_verify_batch: a weight rho is zero (it would drop its proof from the combination)");
+    else if (hflags & 8u) rc = fail(ctx, BPPP_ERR_ARG, "ip_verify_batch: a challenge is zero (makeEs needs its inverse)");
   } while (0);
   hipStreamSynchronize(st);
   return rc;

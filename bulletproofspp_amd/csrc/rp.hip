@@ -259,7 +259,7 @@ int rp_build_tables(bppp_rp *rp) {
   auto p32 = [](std::vector<uint32_t> &v) { if (v.empty()) v.push_back(0); return v.data(); };
   auto p64 = [](std::vector<uint64_t> &v) { if (v.empty()) v.assign(4, 0); return v.data(); };
   const size_t nsyms = sym_vals.size();
-  return bppp_trrp_create(rp->ctx, 0, st.has_types ? 1 : 0, st.nlen, st.llen, st.rds.size(), p32(kind), p32(rng), p32(slot), p32(psym), p64(coeff), p64(mins),
+  return bppp_trrp_create(rp->ctx, st.flavour, st.has_types ? 1 : 0, st.nlen, st.llen, st.rds.size(), p32(kind), p32(rng), p32(slot), p32(psym), p64(coeff), p64(mins),
                           p32(assumed), nsyms, p64(syms), p32(cs_slot), p32(cs_sym), st.pubs.size(), p32(pub_out), p64(pub_amt), p32(pub_sym), &rp->tabs);
 }
 
@@ -332,7 +332,7 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
   if (!ctx || !out || ctx_closed(ctx)) return BPPP_ERR_ARG;
   *out = nullptr;
   if (!ranges || !nranges || (npub && !pubs) || !points_xy) return fail(ctx, BPPP_ERR_ARG, "rp_create: null argument");
-  if (flavour != 0) return fail(ctx, BPPP_ERR_ARG, "rp_create: only the norm-linear (NL) argument flavour has a batch path; use bppp_ip_* for IP");
+  if (flavour != 0 && flavour != 1) return fail(ctx, BPPP_ERR_ARG, "rp_create: flavour must be 0 (norm-linear argument) or 1 (inner-product argument)");
   if (nranges >= (1u << 20) || npub >= (1u << 20)) return fail(ctx, BPPP_ERR_ARG, "rp_create: too many ranges");
   std::vector<bppp_rps::RangeData> rds(nranges);
   std::string err;
@@ -352,7 +352,7 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
   rp->ctx = ctx; ctx_retain(ctx);
   rp->opt.from_env();
   auto fill = [&]() -> int {
-    if (!bppp_rps::make_setup(has_types != 0, rds, pv, rp->st, err)) return fail(ctx, BPPP_ERR_ARG, "rp_create: " + err);
+    if (!bppp_rps::make_setup(has_types != 0, rds, pv, rp->st, err, flavour)) return fail(ctx, BPPP_ERR_ARG, "rp_create: " + err);
     const bppp_rps::Setup &st = rp->st;
     // points = h : g : hs (linLen) ++ gs (nrmLen)   (TypedReciprocal.hs:334, :348-349); h is not used by the proof
     if (npoints < 2 + st.llen + st.nlen) return fail(ctx, BPPP_ERR_ARG, "rp_create: not enough basis points (need 2 + linLen + nrmLen)");
@@ -384,7 +384,7 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
 
 // host-only: the shape a setup would have (no context, no GPU) — setup's arithmetic of TypedReciprocal.hs:332-359 alone
 int bppp_rp_shape_of(int flavour, int has_types, const bppp_rp_range *ranges, size_t nranges, bppp_rp_shape *out) {
-  if (!ranges || !nranges || !out || flavour != 0 || nranges >= (1u << 20)) return BPPP_ERR_ARG;
+  if (!ranges || !nranges || !out || (flavour != 0 && flavour != 1) || nranges >= (1u << 20)) return BPPP_ERR_ARG;
   std::vector<bppp_rps::RangeData> rds(nranges);
   std::string err;
   for (size_t i = 0; i < nranges; i++) {
@@ -394,7 +394,7 @@ int bppp_rp_shape_of(int flavour, int has_types, const bppp_rp_range *ranges, si
       return BPPP_ERR_ARG;
   }
   bppp_rps::Setup st;
-  if (!bppp_rps::make_setup(has_types != 0, rds, std::vector<bppp_rps::PublicVT>(), st, err)) return BPPP_ERR_ARG;
+  if (!bppp_rps::make_setup(has_types != 0, rds, std::vector<bppp_rps::PublicVT>(), st, err, flavour)) return BPPP_ERR_ARG;
   const size_t nr = nranges, k = st.rounds, npp = 4 + 2 * k;
   out->nranges = nr; out->norm_len = st.nlen; out->lin_len = st.llen; out->rounds = k; out->final_norm = st.fn; out->final_lin = st.fl;
   out->coms_bytes = (nr + 7) / 8 + 32 * nr;
@@ -481,6 +481,10 @@ int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t
                                 const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q, const void *d_sp, const void *d_pub_norm,
                                 const void *d_pub_lin_c, const void *d_pub_lin_x, const void *d_es, const void *d_wit_norm, const void *d_wit_lin,
                                 const void *d_init_scalars, const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
+int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit, const void *d_g_xy,
+                                const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_r, const void *d_sp, const void *d_pub_norm,
+                                const void *d_pub_lin_c, const void *d_pub_lin_x, const void *d_es, const void *d_wit_norm, const void *d_wit_lin,
+                                const void *d_init_scalars, const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
 
 }  // extern "C"
 // a second handle of the same setup on its own context (stream, workspaces): the two halves of a large batch run side by side
@@ -489,7 +493,7 @@ int rp_ensure_twin(bppp_rp *rp) {
   bppp_ctx *ctx = rp->ctx;
   int rc = bppp_ctx_create(ctx->device, &rp->twin_ctx);
   if (rc) { rp->twin_ctx = nullptr; return fail(ctx, rc, "rp: creating the second context failed"); }
-  rc = bppp_rp_create(rp->twin_ctx, 0, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
+  rc = bppp_rp_create(rp->twin_ctx, rp->st.flavour, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
                       rp->c_points.data(), rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
   if (rc) {
     const std::string m = bppp_last_error(rp->twin_ctx);
@@ -621,8 +625,10 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
   int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
   if (rc) return rc;
   uint64_t out_xy[8];
-  rc = bppp_nl_verify_batch_device(ctx, B, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho, q, sp, pub_norm,
-                                   pub_lin_c, pub_lin_x, es, wit_norm, wit_lin, init_sc, init_pts, resp_pts, out_xy);
+  // verifyBPM of the setup's argument flavour (q is makeNorm's r for the inner-product one)
+  auto verify_bp = S.flavour ? bppp_ip_verify_batch_device : bppp_nl_verify_batch_device;
+  rc = verify_bp(ctx, B, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho, q, sp, pub_norm,
+                 pub_lin_c, pub_lin_x, es, wit_norm, wit_lin, init_sc, init_pts, resp_pts, out_xy);
   if (rc) return rc;
   // decode failures (an x with no point on the curve): Nothing in the reference (decodeCommitments, Encoding.hs:119-128)
   std::vector<uint32_t> hbad(B);
@@ -653,7 +659,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     bool ok = false;
     if (!r.known_bad) {
       const size_t o = r.lo, n = r.hi - r.lo;
-      rc = bppp_nl_verify_batch_device(ctx, n, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho + o * 8, q + o * 8,
+      rc = verify_bp(ctx, n, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho + o * 8, q + o * 8,
                                        sp + o * 8, pub_norm + o * nlen * 8, pub_lin_c + o * llen * 8, pub_lin_x + o * llen * 8, es + o * k * 8, wit_norm + o * D.fn * 8,
                                        wit_lin + o * D.fl * 8, init_sc + o * ninit * 8, init_pts + o * ninit * 16, resp_pts + o * 2 * k * 16, out_xy);
       if (rc) return rc;

@@ -597,6 +597,7 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   if (!batch) return BPPP_OK;
   if (!amounts || !types || !blinds || (prefix_len && !rand_prefix) || !coms_files || !proof_files || batch >= (1u << 20) || prefix_len > 4096)
     return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: bad arguments");
+  if (rp->st.flavour != 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: the lockstep prover exists for the norm-linear argument; inner-product proofs are made through bppp_ip_*");
   // A large batch runs as TWO half-batches in flight, the second on a twin handle with its own context (stream, workspaces, host
   // thread): the proofs are independent, and the host shares of a half (digits, the argument's half-GCDs and round bookkeeping,
   // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).

@@ -140,6 +140,20 @@ inline void optimal_witness_size_nl(size_t n_len, size_t l_len, size_t &rounds, 
   else { rounds = r; fn = n1; fl = l1; }
 }
 
+// IP flavour (src/Bulletproof/InnerProductArgument.hs:253-267): the norm vector is paired up first (nLen padded to even, halved) and reduced
+// with numberRoundsReduce' (src/Bulletproof.hs:307-308: one more round while more than 2 pairs are left); fn counts SCALARS (2 per pair)
+inline void optimal_witness_size_ip(size_t n_len, size_t l_len, size_t &rounds, size_t &fn, size_t &fl) {
+  size_t nR, n1, lR, l1;
+  number_rounds_reduce((n_len + (n_len % 2)) / 2, nR, n1);
+  if (n1 > 2) { nR++; n1 = round_reduce(n1); }
+  number_rounds_reduce(l_len, lR, l1);
+  size_t r = std::max(nR, lR);
+  for (size_t i = nR; i < r; i++) n1 = round_reduce(n1);
+  for (size_t i = lR; i < r; i++) l1 = round_reduce(l1);
+  if (2 * n1 + l1 > 5) { rounds = r + 1; fn = 2 * round_reduce(n1); fl = round_reduce(l1); }
+  else { rounds = r; fn = 2 * n1; fl = l1; }
+}
+
 // ---- Phase1 layout of the norm vector (one record per position; private fields live with the witness)
 enum : uint32_t { POS_TYPING = 0, POS_INLINE = 1, POS_SHARED = 2, POS_F_IO = 1u << 8, POS_F_IA = 1u << 9, POS_NO_SYM = 0xFFFFFFFFu };
 struct Pos {
@@ -154,6 +168,7 @@ struct Pos {
 struct PublicVT { bool is_output; U256 type, amount; };   // (isOutput, type, amount), field elements
 
 struct Setup {
+  int flavour = 0;                      // 0 = Bulletproof.NormArgument (NL), 1 = Bulletproof.InnerProductArgument (IP)
   bool has_types = false;
   std::vector<RangeData> rds;
   std::vector<PublicVT> pubs;
@@ -168,8 +183,9 @@ struct Setup {
 };
 
 // setup (TypedReciprocal.hs:332-359) + the verifier's Phase1 list (makePhase1sVer :163-169)
-inline bool make_setup(bool has_types, const std::vector<RangeData> &rds, const std::vector<PublicVT> &pubs, Setup &st, std::string &err) {
+inline bool make_setup(bool has_types, const std::vector<RangeData> &rds, const std::vector<PublicVT> &pubs, Setup &st, std::string &err, int flavour = 0) {
   st = Setup();
+  st.flavour = flavour;
   st.has_types = has_types; st.rds = rds; st.pubs = pubs;
   bool any_has_bit = false, any_shared_has_bit = false;
   std::vector<uint32_t> mb, sb;
@@ -189,7 +205,8 @@ inline bool make_setup(bool has_types, const std::vector<RangeData> &rds, const 
   st.llen = 6;
   for (uint32_t b : mb) st.llen += b - 1;
   if (!st.nlen) { err = "empty norm vector"; return false; }
-  optimal_witness_size_nl(st.nlen, st.llen, st.rounds, st.fn, st.fl);
+  if (flavour) optimal_witness_size_ip(st.nlen, st.llen, st.rounds, st.fn, st.fl);
+  else optimal_witness_size_nl(st.nlen, st.llen, st.rounds, st.fn, st.fl);
   // Phase1 records
   if (has_types)
     for (size_t i = 0; i < rds.size(); i++)

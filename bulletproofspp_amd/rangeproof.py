@@ -825,13 +825,12 @@ class DeviceVerifierTables:
 class NativeRangeProofs:
     """One setup registered with the library (bppp_rp_create): ranges, layout and basis live on the device; batches of ENCODED
     proofs (the reference's commitments / proof files, bulletproofspp_amd.encoding) are verified end to end there — decoding,
-    all SHA-256 transcript hashing (the CLI's shaOracle), verifyTRRPM's scalars, challenge expansion and one combined MSM."""
+    all SHA-256 transcript hashing (the CLI's shaOracle), verifyTRRPM's scalars, challenge expansion and one combined MSM.
+    Both argument flavours verify; prove_batch (the lockstep prover) serves the norm-linear one."""
 
     def __init__(self, gpu, st: SetupTRRP, oracle_tag: bytes = b"", h: Point = None):
         import ctypes as C
         from .capi import RP_ASSUMED, RP_OUTPUT, RP_SHARED, RpPublic, RpRange, RpShape, int_to_limbs, points_to_array
-        if st.flavour != "NL":
-            raise ValueError("the native batch paths exist for the norm-linear argument flavour")
         self.gpu, self.st, self.h = gpu, st, None
         rng = (RpRange * len(st.rds))()
         for r, rd in zip(rng, st.rds):
@@ -846,7 +845,7 @@ class NativeRangeProofs:
             p_.amount[:] = [int(x) for x in int_to_limbs(v % N)]
         pts = points_to_array([h if h is not None else st.g, st.g] + list(st.hs) + list(st.gs))
         hnd = C.c_void_p()
-        rc = gpu.lib.bppp_rp_create(gpu.h, 0, int(st.has_types), C.cast(rng, C.c_void_p), len(st.rds), C.cast(pubs, C.c_void_p), len(st.pub_vt),
+        rc = gpu.lib.bppp_rp_create(gpu.h, 0 if st.flavour == "NL" else 1, int(st.has_types), C.cast(rng, C.c_void_p), len(st.rds), C.cast(pubs, C.c_void_p), len(st.pub_vt),
                                     C.c_void_p(pts.ctypes.data), pts.shape[0], oracle_tag if oracle_tag else None, C.byref(hnd))
         gpu._check(rc, "bppp_rp_create")
         self.h = hnd
@@ -881,6 +880,8 @@ class NativeRangeProofs:
         import numpy as np
         from .capi import scalars_to_array
         B, nr = len(inputs), len(self.st.rds)
+        if self.st.flavour != "NL":
+            raise ValueError("the lockstep batch prover exists for the norm-linear argument flavour")
         if B == 0:
             return []
         if len(rand_prefixes) != B or len({len(p_) for p_ in rand_prefixes}) != 1 or any(len(row) != nr for row in inputs):

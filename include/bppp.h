@@ -270,6 +270,19 @@ int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t
                                 const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
                                 const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
 
+/* The same batch check for the inner-product flavour (src/Bulletproof/InnerProductArgument.hs; verifyBPM src/Bulletproof.hs:370-378 with
+ * expandChallenges :103-124, :172-181 and makeEs e = (1/e, e) :68).  Same layout and result as bppp_nl_verify_batch_device; d_r holds the
+ * per-proof argument of makeNorm (:194-206; the range proofs pass their challenge q), fn counts the SCALARS of the final norm witness
+ * (two per inner-product pair, as getWitness :222-223 lays them out).  makeNorm's basis change g' = g1 + r g0, h' = g1 - r g0 depends
+ * on the proof, so it is folded into the scalars on the ORIGINAL basis — x' g' + y' h' = r (x' - y') g0 + (x' + y') g1 — and the
+ * per-proof scalars still sum onto the one shared basis [G | H | g]: no scalar multiplication per basis pair (the reference's TODO at
+ * InnerProductArgument.hs:187-190, :225-227) and one MSM of (nlen + llen + 1) + batch * (ninit + 2k) terms for the whole batch. */
+int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                                const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_r,
+                                const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                                const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                                const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]);
+
 /* ---- the optional endomorphism (GLV) path ---------------------------------------------------------------
  * bppp_glv_decompose_device: decomposeFastPrimeEis (src/Data/Field/Galois/FastPrime.hs:186-205) for n canonical scalars:
  * x = a + b*lambda (mod n), the reference's own (a, b) including its one-step rounding.  d_a_mag / d_b_mag: [n][4] magnitudes,
@@ -310,7 +323,9 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
  * `bppp_rp` is one typed-reciprocal setup (setup, src/RangeProof/TypedReciprocal.hs:332-359) resident on the device: the ranges
  * with their digit coefficients (makeRangeData :103-120), the Phase1 layout (:133-169), the round count (optimalWitnessSize,
  * src/Bulletproof/NormArgument.hs:165-178) and the REGISTERED BASIS g, G, H — uploaded once, referenced by every later call
- * (G, H are fixed per setup, TypedReciprocal.hs:348-359).  Argument flavour: 0 = norm-linear (the batch paths exist for this one).
+ * (G, H are fixed per setup, TypedReciprocal.hs:348-359).  Argument flavour: 0 = norm-linear (Bulletproof.NormArgument), 1 = inner product
+ * (Bulletproof.InnerProductArgument, the CLI's default, app/Parse.hs:100).  Both have the batch VERIFIER; the lockstep batch PROVER
+ * (bppp_rp_prove_batch) exists for flavour 0 — inner-product proofs are made one at a time through bppp_ip_*.
  *
  * bppp_rp_create: `ranges` as the schema gives them (app/Parse.hs:125-172): base, min, max (plain 256-bit integers, max exclusive
  * as in makeRangeData), flags.  `pubs`: the public (isOutput, type, amount) triples.  `points_xy` = h : g : hs ++ gs, the stream the
