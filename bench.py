@@ -366,6 +366,82 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     return verify, prove
 
 
+def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, distinct: int = 128, cpu_baseline_leg: bool = True):
+    """The inner-product flavour at batch scale (the CLI's DEFAULT argument, app/Parse.hs:100): `batch` encoded proofs
+    of the examples/64bit shape — ONE 64-bit value, base 16 inline, nrmLen 16, linLen 6, 3 rounds, the paper's 416-byte proof
+    (README.md:169-172) — verified end to end from their files in HBM by bppp_rp_verify_batch_device over a flavour-1 setup: decode,
+    all SHA-256 transcript hashing, verifyTRRPM's scalars, expandChallenges of InnerProductArgument.hs:103-124 / :172-181 with makeNorm's
+    basis change folded into the shared-basis scalars, ONE combined MSM of 23 + batch * 11 terms.  The library has no lockstep prover
+    for this flavour, so `distinct` proofs (random 64-bit values, own blindings and prover randomness; made one at a time by the host
+    protocol code over bppp_ip_*) are tiled to the batch — position-dependent weights make every slot its own term of the combination."""
+    import ctypes as C
+    from bulletproofspp_amd import encoding as E
+    from bulletproofspp_amd import rangeproof as RP
+    schema = json.load(open(os.path.join(ROOT, "tests", "golden", "examples", "64bit", "schema.json")))      # the reference's examples/64bit/schema.json (data fixture)
+    st = RP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    assert (st.flavour, st.nrm_len, st.lin_len, st.rounds, tuple(st.final_lens)) == ("IP", 16, 6, 3, (2, 1))
+    nat = RP.NativeRangeProofs(gpu, st)
+    rng = np.random.default_rng(0x1664)
+    tp0 = time.perf_counter()
+    files, kept = [], []
+    for j in range(distinct):
+        v, bl = int(rng.integers(0, 2**64, dtype=np.uint64)), int(rng.integers(1, 2**63, dtype=np.uint64)) << 64 | int(rng.integers(0, 2**63, dtype=np.uint64))
+        proof = RP.prove(st, RP.witness(st, [(v, 0, bl)]), RP.sha256_oracle(), RP.hash_to_scalar(b"bench ip %06d" % j))
+        files.append(E.encode_proof(4, proof))
+        if j < 3:
+            kept.append(proof)
+    prove_s = time.perf_counter() - tp0
+    assert len(files[0][1]) == 418 and len({p for _, p in files}) == distinct
+    reps = (batch + distinct - 1) // distinct
+    cf = np.frombuffer((b"".join(c for c, _ in files) * reps)[:batch * nat.shape["coms_bytes"]], dtype=np.uint8)
+    pf = np.frombuffer((b"".join(p for _, p in files) * reps)[:batch * nat.shape["proof_bytes"]], dtype=np.uint8)
+    d_c, d_p = torch.from_numpy(cf.copy()).to(dev), torch.from_numpy(pf.copy()).to(dev)
+    seed = os.urandom(32)
+    ok, _ = nat.verify_batch_device_point(batch, d_c.data_ptr(), d_p.data_ptr(), seed)
+    assert ok, "batch of valid inner-product proofs did not verify"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ok, _ = nat.verify_batch_device_point(batch, d_c.data_ptr(), d_p.data_ptr(), seed)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert ok
+    pf_bad = pf.copy(); pf_bad[(batch // 3) * nat.shape["proof_bytes"] + 3] ^= 1
+    acc = C.c_int(1)
+    sd = np.frombuffer(seed, dtype=np.uint8)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(cf), vp(pf_bad), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
+    assert acc.value == 0, "a corrupted inner-product proof was accepted"
+    nlen, llen, k, ninit = st.nrm_len, st.lin_len, st.rounds, 4 + len(st.rds)
+    bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
+    out = {"metric": "single_64bit_range_proof_verifies_per_sec (inner-product argument)", "value": batch / dt, "unit": "verifies/s", "ms_per_batch": dt * 1e3,
+           "batch": batch, "distinct_proofs": distinct, "combined_msm_terms": nlen + llen + 1 + batch * (ninit + 2 * k),
+           "algorithmic_bytes_per_proof": bytes_per_proof, "encoded_bytes_per_proof": nat.shape["coms_bytes"] + nat.shape["proof_bytes"],
+           "achieved_GBps": batch * bytes_per_proof / dt / 1e9, "hbm_frac": batch * bytes_per_proof / dt / 1e9 / HBM_PEAK_GBS,
+           "shape": "examples/64bit: 1 x 64-bit value, base 16 inline, IP argument, nrmLen 16, linLen 6, 3 rounds, 34-term verifier MSM per proof, 418-byte proof file",
+           "proofs": f"{distinct} distinct real proofs (host protocol code over bppp_ip_*, {prove_s / distinct * 1e3:.0f} ms each) tiled to {batch}; all verify; one corrupted member is rejected",
+           "scope": "verifyM of RangeProof end to end from the encoded files in HBM, inner-product flavour (bppp_rp_verify_batch_device, flavour 1)"}
+    if cpu_baseline_leg:
+        # the reference's verifier for ONE such proof: makeNorm's basis change (one 256-row scalar multiplication per basis pair,
+        # InnerProductArgument.hs:204), expandChallenges, one 34-term commit — through the oracle restatement, single thread
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pyoracle
+        from rp_backends import OracleBackend
+        ob = OracleBackend(pyoracle.CEC())
+        sample = [RP.verify_inputs(st, p_, RP.sha256_oracle()) for p_ in kept]
+        tc0 = time.perf_counter()
+        for v in sample:
+            assert ob.verify_bp("IP", v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"], v["responses"], v["wit_norm"],
+                                v["wit_lin"], v["init_terms"])
+        cdt = (time.perf_counter() - tc0) / len(sample)
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                               "sample": f"{len(sample)} proofs of the batch through the oracle's verifyBPM of the inner-product flavour (basis change by 8 full scalar "
+                                         "multiplications, then one 34-term Straus commit; oracle/pyoracle.py driving oracle/bppp_oracle.c); hashing and decoding not included"}
+    nat.close()
+    return out
+
+
 def prove_cpu_baseline(shape: str, reps: int = 2):
     """The reference's proveBPM for one argument of this shape through the oracle (oracle/pyoracle.py driving the C restatement's
     256-row Straus commits and 129-row pair folds), single thread: a reported baseline for the prove leg."""
@@ -450,6 +526,7 @@ def main():
     ap.add_argument("--cpu-sample-log2", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=4096, help="distinct proofs per GPU proved in lockstep and then batch-verified end to end (0 = skip both legs)")
+    ap.add_argument("--ip-batch", type=int, default=1 << 14, help="inner-product flavour leg: single 64-bit proofs (examples/64bit) verified per batch (0 = skip; N = 1 only)")
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -718,6 +795,9 @@ def main():
         prove["other_shapes"] = [p2]
         if world == 1 and not args.no_cpu_baseline:
             prove["cpu_baseline"] = prove_cpu_baseline("64by64")
+    verify_ip = None
+    if world == 1 and args.ip_batch > 0 and not args.headline_only:
+        verify_ip = bench_ip_verify(gpu, torch, dev, args.ip_batch, max(3, args.steps // 2), cpu_baseline_leg=not args.no_cpu_baseline)
 
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
@@ -800,6 +880,8 @@ def main():
             out["verify"] = verify
         if prove is not None:
             out["prove"] = prove
+        if verify_ip is not None:
+            out["verify_ip"] = verify_ip
         print(json.dumps(out), flush=True)
     gpu.close()
     if dist is not None:

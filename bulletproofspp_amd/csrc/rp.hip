@@ -254,7 +254,7 @@ int rp_build_tables(bppp_rp *rp) {
   }
   for (uint32_t b : st.m_bases)
     for (uint32_t s = 1; s < b; s++) { cs_slot.push_back((uint32_t)st.slot_of(b)); cs_sym.push_back(sym(U256::from_u64(s))); }
-  for (const bppp_rps::RangeData &rd : st.rds) { push(mins, bppp_rps::u_mod_n(rd.lo)); assumed.push_back(rd.assumed ? 1u : 0u); }
+  for (const bppp_rps::RangeData &rd : st.rds) { push(mins, bppp_rps::s_mod_n(rd.lo)); assumed.push_back(rd.assumed ? 1u : 0u); }
   for (const bppp_rps::PublicVT &pv : st.pubs) { pub_out.push_back(pv.is_output ? 1u : 0u); pub_sym.push_back(sym(pv.type)); push(pub_amt, pv.amount); }
   auto p32 = [](std::vector<uint32_t> &v) { if (v.empty()) v.push_back(0); return v.data(); };
   auto p64 = [](std::vector<uint64_t> &v) { if (v.empty()) v.assign(4, 0); return v.data(); };
@@ -411,7 +411,7 @@ int bppp_rp_digits(const bppp_rp_range *range, const uint64_t amount[4], uint32_
   std::string err;
   if (!bppp_rps::make_range_data(range->base, U256::load(range->min), U256::load(range->max), false, false, false, rd, err)) return BPPP_ERR_ARG;
   const U256 v = U256::load(amount);
-  if (bppp_rps::u_lt(v, rd.lo) || !bppp_rps::u_lt(v, rd.hi)) return BPPP_ERR_ARG;
+  if (bppp_rps::s_lt(v, rd.lo) || !bppp_rps::s_lt(v, rd.hi)) return BPPP_ERR_ARG;
   const std::vector<uint32_t> ds = bppp_rps::digits(rd, bppp_rps::u_sub(v, rd.lo));
   if (ds.size() > cap) return BPPP_ERR_ARG;
   for (size_t i = 0; i < ds.size(); i++) out_digits[i] = ds[i];

@@ -187,7 +187,7 @@ bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const ui
   for (size_t i = 0; i < nr; i++) {
     amt[i] = U256::load(amounts + 4 * i);
     if (!scalars_canonical(types + 4 * i, 1) || !scalars_canonical(blinds + 4 * i, 1)) { ps.err = "type / blinding not canonical"; return false; }
-    ps.v[i] = bppp_rps::u_mod_n(amt[i]); ps.ty[i] = U256::load(types + 4 * i); ps.bl[i] = U256::load(blinds + 4 * i);
+    ps.v[i] = bppp_rps::s_mod_n(amt[i]); ps.ty[i] = U256::load(types + 4 * i); ps.bl[i] = U256::load(blinds + 4 * i);
   }
   if (st.has_types) {                                     // amounts of every type must balance (:376-381)
     std::vector<std::pair<U256, U256>> sums;
@@ -210,7 +210,7 @@ bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const ui
   for (size_t i = 0; i < nr; i++) {
     const RangeData &rd = st.rds[i];
     if (rd.assumed) continue;
-    if (bppp_rps::u_lt(amt[i], rd.lo) || !bppp_rps::u_lt(amt[i], rd.hi)) { ps.err = "value outside its range"; return false; }
+    if (bppp_rps::s_lt(amt[i], rd.lo) || !bppp_rps::s_lt(amt[i], rd.hi)) { ps.err = "value outside its range"; return false; }
     std::vector<uint32_t> &ds = ps.tmp_ds, &cnt = ps.tmp_cnt, &ms = ps.tmp_ms;       // reused across ranges and proofs
     bppp_rps::digits_into(rd, bppp_rps::u_sub(amt[i], rd.lo), ds);
     const uint32_t b = rd.base;
@@ -428,7 +428,7 @@ void make_public_consts(const Setup &st, const PState &ps, U256 &sc, std::vector
   const U256 xx = fm(ps.x, ps.x);
   U256 z = U256::zero();
   { U256 xp = xx;
-    for (size_t j = 0; j < st.rds.size(); j++) { if (!st.rds[j].assumed) z = fa(z, fm(bppp_rps::u_mod_n(st.rds[j].lo), xp)); xp = fm(xp, xx); } }
+    for (size_t j = 0; j < st.rds.size(); j++) { if (!st.rds[j].assumed) z = fa(z, fm(bppp_rps::s_mod_n(st.rds[j].lo), xp)); xp = fm(xp, xx); } }
   z = fneg(fm(two_t5, z));
   if (st.has_types) {
     std::vector<U256> pr(st.pubs.size());

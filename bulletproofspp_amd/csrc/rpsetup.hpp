@@ -33,6 +33,19 @@ inline U256 u_div64(const U256 &a, uint64_t d, uint64_t *rem = nullptr) {
   if (rem) *rem = (uint64_t)r;
   return q;
 }
+// Range bounds and amounts are INTEGERS that may be negative (examples/rec_test has "min": -20; the reference's Integer): two's complement
+// over 256 bits, |x| < 2^255.  Differences (widths, value - min) come out right from the wrapping subtraction; order and the image in
+// the scalar field need the sign.
+inline bool s_neg(const U256 &a) { return (a.w[3] >> 63) != 0; }
+inline bool s_lt(const U256 &a, const U256 &b) { return s_neg(a) != s_neg(b) ? s_neg(a) : bppp_host::cmp(a, b) < 0; }
+inline U256 u_mod_n(const U256 &a);
+inline U256 s_mod_n(const U256 &a) {      // fromInteger into the scalar field for a signed 256-bit integer
+  if (!s_neg(a)) return u_mod_n(a);
+  U256 m = u_mod_n(u_sub(U256::zero(), a)), r;
+  if (m.is_zero()) return m;
+  bppp_host::sub_raw(r, bppp_host::FR().m, m);
+  return r;
+}
 inline U256 u_mod_n(const U256 &a) {      // fromInteger into the scalar field for a < 2^256 < 2n
   U256 r = a;
   if (bppp_host::cmp(r, bppp_host::FR().m) >= 0) bppp_host::sub_raw(r, r, bppp_host::FR().m);
@@ -56,7 +69,7 @@ inline int integer_log(uint64_t b, U256 n) {
 }
 
 inline bool make_range_data(uint32_t base, const U256 &lo, const U256 &hi, bool shared, bool output, bool assumed, RangeData &out, std::string &err) {
-  if (!(u_lt(lo, hi)) || base < 2) { err = "invalid range (need max > min and base > 1)"; return false; }
+  if (!(s_lt(lo, hi)) || base < 2) { err = "invalid range (need max > min and base > 1)"; return false; }
   const U256 w = u_sub(hi, lo);
   if (bppp_host::cmp(w, bppp_host::FR().m) >= 0) { err = "range wider than the scalar field"; return false; }
   const uint64_t b = base;

@@ -836,8 +836,8 @@ class NativeRangeProofs:
         for r, rd in zip(rng, st.rds):
             r.base = rd.base
             r.flags = (RP_SHARED if rd.is_shared else 0) | (RP_OUTPUT if rd.is_output else 0) | (RP_ASSUMED if rd.is_assumed else 0)
-            r.min[:] = [int(v) for v in int_to_limbs(rd.lo)]
-            r.max[:] = [int(v) for v in int_to_limbs(rd.hi)]
+            r.min[:] = [int(v) for v in int_to_limbs(rd.lo % 2**256)]     # two's complement: a minimum may be negative (examples/rec_test)
+            r.max[:] = [int(v) for v in int_to_limbs(rd.hi % 2**256)]
         pubs = (RpPublic * max(len(st.pub_vt), 1))()
         for p_, (io, ty, v) in zip(pubs, st.pub_vt):
             p_.is_output = 1 if io else 0
@@ -886,7 +886,7 @@ class NativeRangeProofs:
             return []
         if len(rand_prefixes) != B or len({len(p_) for p_ in rand_prefixes}) != 1 or any(len(row) != nr for row in inputs):
             raise ValueError("one equal-length randomness prefix per proof and one (amount, type, blinding) per range are required")
-        amt = scalars_to_array([v for row in inputs for v, _, _ in row])
+        amt = scalars_to_array([v % 2**256 for row in inputs for v, _, _ in row])
         typ = scalars_to_array([t % N for row in inputs for _, t, _ in row])
         bld = scalars_to_array([b_ % N for row in inputs for _, _, b_ in row])
         plen = len(rand_prefixes[0])

@@ -327,7 +327,7 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
  * (Bulletproof.InnerProductArgument, the CLI's default, app/Parse.hs:100).  Both have the batch VERIFIER; the lockstep batch PROVER
  * (bppp_rp_prove_batch) exists for flavour 0 — inner-product proofs are made one at a time through bppp_ip_*.
  *
- * bppp_rp_create: `ranges` as the schema gives them (app/Parse.hs:125-172): base, min, max (plain 256-bit integers, max exclusive
+ * bppp_rp_create: `ranges` as the schema gives them (app/Parse.hs:125-172): base, min, max (plain INTEGERS in 256-bit two's complement — a minimum may be negative, examples/rec_test — max exclusive
  * as in makeRangeData), flags.  `pubs`: the public (isOutput, type, amount) triples.  `points_xy` = h : g : hs ++ gs, the stream the
  * CLI takes from getPoints (app/Main.hs:68-72, :260); at least 2 + lin_len + norm_len points (validated: on the curve).
  * `oracle_tag` (may be NULL = the reference's input) is prepended to every hashed message (domain separation for tests).
@@ -416,7 +416,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
 /* Batch prover: `batch` proofs of this setup in lockstep — proveM of RangeProof (src/RangeProof.hs:93-97) = proveTRRPM
  * (src/RangeProof/TypedReciprocal.hs:399-446; blinding algebra src/RangeProof/Internal.hs:118-196) followed by proveBPM
  * (src/Bulletproof.hs:357-359), then encodeProof' (src/RangeProof.hs:60-66).  Per proof b: amounts / types / blinds are
- * [batch][nranges][4] (amount: a plain integer inside its range; type, blinding: canonical scalars), and the prover's randomness
+ * [batch][nranges][4] (amount: a plain integer inside its range, two's complement when negative; type, blinding: canonical scalars), and the prover's randomness
  * is the CLI's: random n = decode(SHA-256(prefix_b <> show n)) for n = 0, 1, ... (hashToScalar, app/Main.hs:83-87, :189;
  * ZKPT.random, src/ZKP.hs:88-92) with prefix_b = rand_prefix[b * prefix_len ..].  The oracle is the setup's shaOracle (see above).
  * Outputs are the reference's files: coms_files [batch][coms_bytes], proof_files [batch][proof_bytes].  Every commitment is

@@ -19,8 +19,8 @@ def _ranges(rds):
     for r, rd in zip(arr, rds):
         r.base = rd.base
         r.flags = (capi.RP_SHARED if rd.is_shared else 0) | (capi.RP_OUTPUT if rd.is_output else 0) | (capi.RP_ASSUMED if rd.is_assumed else 0)
-        r.min[:] = [int(v) for v in capi.int_to_limbs(rd.lo)]
-        r.max[:] = [int(v) for v in capi.int_to_limbs(rd.hi)]
+        r.min[:] = [int(v) for v in capi.int_to_limbs(rd.lo % 2**256)]         # two's complement: examples/rec_test has a negative minimum
+        r.max[:] = [int(v) for v in capi.int_to_limbs(rd.hi % 2**256)]
     return arr
 
 
@@ -43,24 +43,43 @@ def test_native_setup_shape_equals_host_setup(name, typed):
     assert shp.challenges_per_proof == 7 + st.rounds
 
 
+@pytest.mark.parametrize("name", ["32bit", "64bit", "rec_test"])
+def test_native_setup_shape_inner_product_flavour(name):
+    """the reference's inner-product examples (flavour 1: rounds by InnerProductArgument.hs:253-267, final norm length counted in scalars);
+    rec_test has a NEGATIVE range minimum and an assumed range"""
+    lib = capi.load_library()
+    schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
+    st = RP.setup_from_schema(RP.Backend(), schema, points=[None] * 400)
+    assert st.flavour == "IP"
+    shp = capi.RpShape()
+    arr = _ranges(st.rds)
+    assert lib.bppp_rp_shape_of(1, int(st.has_types), C.cast(arr, C.c_void_p), len(st.rds), C.byref(shp)) == 0
+    assert (shp.norm_len, shp.lin_len, shp.rounds, shp.final_norm, shp.final_lin) == (st.nrm_len, st.lin_len, st.rounds) + tuple(st.final_lens)
+    nl = capi.RpShape()
+    assert lib.bppp_rp_shape_of(0, int(st.has_types), C.cast(arr, C.c_void_p), len(st.rds), C.byref(nl)) == 0
+    st_nl = RP.setup_from_schema(RP.Backend(), dict(schema, argument="NL"), points=[None] * 400)
+    assert (nl.rounds, nl.final_norm, nl.final_lin) == (st_nl.rounds,) + tuple(st_nl.final_lens)
+
+
 def test_native_digits_equal_host_digits():
     """makeRangeData + digits (TypedReciprocal.hs:103-127) for ranges with and without a leading bit, at the edges and at random"""
     lib = capi.load_library()
     rnd = random.Random(3)
     cases = [(2, 0, 2**64), (16, 0, 2**64), (256, 0, 2**64), (3, 0, 100), (4, 10, 266), (4, 0, 101), (9, 0, 2**32), (64, 0, 2**64), (5, 7, 7 + 5**7 + 13),
-             (256, 0, 2**64 + 12345), (7, 0, 2**200)]
+             (256, 0, 2**64 + 12345), (7, 0, 2**200), (16, -20, 73786976294838206463), (3, -1000, -10), (4, -5, 5)]
     for base, lo, hi in cases:
         rd = RP.make_range_data(base, lo, hi)
         arr = _ranges([rd])
         for v in [lo, hi - 1, lo + 1, (lo + hi) // 2] + [rnd.randrange(lo, hi) for _ in range(40)]:
             out = np.zeros(300, dtype=np.uint32)
             nd, hb = C.c_size_t(0), C.c_int(0)
-            amt = capi.int_to_limbs(v)
+            amt = capi.int_to_limbs(v % 2**256)
             assert lib.bppp_rp_digits(C.cast(arr, C.c_void_p), amt.ctypes.data, out.ctypes.data, 300, C.byref(nd), C.byref(hb)) == 0
             assert [int(x) for x in out[:nd.value]] == RP.digits(rd, v - lo), (base, lo, hi, v)
             assert bool(hb.value) == rd.has_bit
-        amt = capi.int_to_limbs(hi)
-        assert lib.bppp_rp_digits(C.cast(arr, C.c_void_p), amt.ctypes.data, out.ctypes.data, 300, C.byref(nd), C.byref(hb)) == -1
+        for outside in (hi, lo - 1):
+            amt = capi.int_to_limbs(outside % 2**256)
+            assert lib.bppp_rp_digits(C.cast(arr, C.c_void_p), amt.ctypes.data, out.ctypes.data, 300, C.byref(nd), C.byref(hb)) == -1
     # invalid ranges are refused
     bad = _ranges([RP.RangeData(1, 0, 10, False, False, False, False, [])])
     assert lib.bppp_rp_shape_of(0, 0, C.cast(bad, C.c_void_p), 1, C.byref(capi.RpShape())) == -1
