@@ -113,7 +113,6 @@ def test_sharded_weights_are_global_and_bound_to_the_proofs(gpu):
     error terms that cancel under EQUAL weights (the final witness scalars enter no transcript hash, so both copies have the same
     challenges): placed on two ranks, each at its local slot 0, they must still be rejected by the sum of the rank points.  And the
     sum of the rank points equals the combined point one rank forms over the whole job."""
-    import torch
     from bulletproofspp_amd.capi import points_to_array
     st = _setup(gpu, False)
     proofs = _proofs(st, 3, False, seed=5)
@@ -129,13 +128,16 @@ def test_sharded_weights_are_global_and_bound_to_the_proofs(gpu):
         return bytes(b)
     plus, minus = shifted(files[0][1], d), shifted(files[0][1], -d)
     seed = hashlib.sha256(b"one seed for every rank").digest()
-    dev = torch.device("cuda", 0)
-    up = lambda bs: torch.frombuffer(bytearray(b"".join(bs)), dtype=torch.uint8).to(dev)
+    def up(bs):                                   # device buffers through the library (this process has no torch GPU context)
+        raw = b"".join(bs)
+        return gpu.to_device(np.frombuffer(raw + b"\0" * (-len(raw) % 8), dtype=np.uint64))
 
     def shard(coms, prfs, offset):
         dc, dp = up(coms), up(prfs)
-        ok, pt = nat.verify_batch_device_point(len(prfs), dc.data_ptr(), dp.data_ptr(), seed, index_offset=offset)
-        return ok, pt
+        try:
+            return nat.verify_batch_device_point(len(prfs), dc, dp, seed, index_offset=offset)
+        finally:
+            gpu.free(dc); gpu.free(dp)
     c0 = files[0][0]
     ok_a, pt_a = shard([c0], [plus], 0)
     ok_b, pt_b = shard([c0], [minus], 1)
