@@ -23,12 +23,31 @@ void ctx_release(bppp_ctx *ctx) {
   if (ctx->refs.fetch_sub(1) != 1) return;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ev_ready) for (int i = 0; i <= BPPP_NUM_STAGES; i++) hipEventDestroy(ctx->ev[i]);
+  if (ctx->aux_fork) hipEventDestroy(ctx->aux_fork);
+  if (ctx->aux_join) hipEventDestroy(ctx->aux_join);
+  if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
+}
+}  // namespace bppp
+void MsmTune::from_env() {
+  auto geti = [](const char *n) { const char *e = getenv(n); return e ? atoi(e) : 0; };
+  if (const char *e = getenv("BPPP_GCOST")) gcost = atof(e);
+  cmin = geti("BPPP_CMIN"); lw = geti("BPPP_LW"); rg = geti("BPPP_RG"); marg_s = geti("BPPP_MARG_S"); lacc = geti("BPPP_LACC");
+  window_batched = geti("BPPP_WINDOW_BATCHED"); comb_wpe = geti("BPPP_COMB_WPE"); reduce_old = getenv("BPPP_REDUCE_OLD") != nullptr;
+}
+namespace bppp {
+int ctx_aux(bppp_ctx *ctx) {
+  if (ctx->aux_stream) return BPPP_OK;
+  BPPP_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  BPPP_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+  BPPP_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+  return BPPP_OK;
 }
 int ensure_workspace(bppp_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return BPPP_OK;
@@ -91,6 +110,7 @@ int bppp_ctx_create(int device, bppp_ctx **out) {
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BPPP_ERR_NODEVICE;
   bppp_ctx *ctx = new bppp_ctx();
   ctx->device = device;
+  ctx->tune.from_env();
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return BPPP_ERR_HIP;

@@ -238,8 +238,7 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   CombK K; memset(&K, 0, sizeof K);
   for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
   // wavefronts per SIMD the register allocation aims at: 2 (225 VGPRs) measured 2 % ahead of 3 (168); 4 (128) spills and is 2.4 x slower
-  int wpe = 2;
-  if (const char *e = getenv("BPPP_COMB_WPE")) wpe = atoi(e);
+  const int wpe = t->ctx->tune.comb_wpe ? t->ctx->tune.comb_wpe : 2;
   // few instances: several wavefronts per instance (up to one per group of 64 terms), so that a launch is ~1024 wavefronts wide and
   // its depth is a few additions instead of nterms / 64 x W; needs the caller's scratch for the partial sums
   uint32_t parts = 1;

@@ -7,7 +7,15 @@
 #include <vector>
 #include "../../include/bppp.h"
 
+// Tuning overrides of the MSM plan (benchmarks/sweep_window.py and friends): the BPPP_* environment is read ONCE, when the context is
+// created; 0 / false = the library's heuristic.  No entry point reads the environment per call.
+struct MsmTune {
+  double gcost = 0; int cmin = 0, lw = 0, rg = 0, marg_s = 0, lacc = 0, window_batched = 0, comb_wpe = 0; bool reduce_old = false;
+  void from_env();
+};
+
 struct bppp_ctx {
+  MsmTune tune;
   // Lifetime: the caller's handle holds one reference, every child handle (bppp_nl, bppp_nlb, bppp_ip, bppp_trrp, bppp_basis,
   // bppp_rp) one more.  bppp_ctx_destroy marks the context closed and drops the caller's reference; the stream, the
   // workspaces and the struct itself go when the LAST reference goes, so a child destroyed after its context (a finaliser
@@ -17,6 +25,10 @@ struct bppp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // stream all work is issued on
   hipStream_t own_stream = nullptr;  // created by the context (used unless the caller binds its own)
+  // second stream + fork / join events, made on first use (ctx_aux): independent halves of ONE call run side by side — the verifier's
+  // round-challenge hashing beside its public-scalar kernel (csrc/rp.hip)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   std::string err;
   // grow-only device workspace, carved per call (no hipMalloc on the steady-state path)
   void *ws = nullptr;
@@ -67,6 +79,7 @@ struct Carver {
 void ctx_retain(bppp_ctx *ctx);
 void ctx_release(bppp_ctx *ctx);          // the last release tears the context down
 inline bool ctx_closed(const bppp_ctx *ctx) { return !ctx || ctx->closed.load(); }
+int ctx_aux(bppp_ctx *ctx);               // creates aux_stream and its two events if needed
 int ensure_workspace(bppp_ctx *ctx, size_t bytes);
 int ensure_pinned(bppp_ctx *ctx, size_t bytes);
 int ensure_scratch(bppp_ctx *ctx, size_t bytes);

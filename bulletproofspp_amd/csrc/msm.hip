@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restric
 
 // ------------------------------------------------------------------------------------------------
 // host orchestration
-static int choose_window(size_t n, size_t batch) {
+static int choose_window(size_t n, size_t batch, const MsmTune &tune) {
   // Cost model in units of one mixed addition (~68 ps chip-wide, measured at 2^20; profiles/):
   //   accumulate: one addition per (scalar, window that holds real bits): ceil(255/c) windows (+ half a window when
   //               c divides 255: the top digit then wraps for half the scalars and a carry window appears);
@@ -537,9 +537,8 @@ static int choose_window(size_t n, size_t batch) {
   // so the model above overprices wide windows; thresholds read off the (n, c, L) table of benchmarks/sweep_window.py
   // (profiles/r02_window_sweep.txt): c = 16 has 17 windows against 20 at c = 13 and no heavy top window.
   if (batch == 1 && n >= 4096) return n < 12288 ? 8 : n < 46000 ? 10 : n < 200000 ? 13 : 16;
-  double gcost = 3.5; int cmin = 4;
-  if (const char *e = getenv("BPPP_GCOST")) gcost = atof(e);            // tuning sweeps
-  if (const char *e = getenv("BPPP_CMIN")) cmin = std::max(2, atoi(e));
+  const double gcost = tune.gcost > 0 ? tune.gcost : 3.5;               // tuning sweeps override both
+  const int cmin = tune.cmin ? std::max(2, tune.cmin) : 4;
   double best = 1e300; int bc = 8;
   for (int c = cmin; c <= 16; c++) {
     int W = 256 / c + 1, full = 254 / c, r = 255 - c * full;       // r = real bits in the top window (1..c)
@@ -564,7 +563,7 @@ struct MsmPlan {
   int ntiles;
 };
 
-static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
+static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat, const MsmTune &tune) {
   MsmPlan p;
   p.n = n; p.batch = batch; p.c = c; p.W = 256 / c + 1; p.M = 1 << (c - 1);
   p.flat = flat; p.Wc = flat ? 1 : p.W;
@@ -579,7 +578,7 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
     while (p.M / p.Lw > 64 * 64) p.Lw <<= 1;     // cap at 4096 lanes per window
     if (p.M / p.Lw >= 1024 && p.Lw < 4) p.Lw = std::min(4, p.M / 1024);  // amortise the wave scan
     if (p.Lw < 1) p.Lw = 1;
-    if (const char *e = getenv("BPPP_LW")) { int v = atoi(e); if (v >= 1 && (v & (v - 1)) == 0 && p.M / v >= 64 && p.M / v <= 4096) p.Lw = v; }
+    if (tune.lw) { const int v = tune.lw; if (v >= 1 && (v & (v - 1)) == 0 && p.M / v >= 64 && p.M / v <= 4096) p.Lw = v; }
     p.WPW = p.M / p.Lw / 64;
     if (p.WPW < 1) p.WPW = 1;
   }
@@ -591,9 +590,9 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
     const int cap = std::min(8, p.M);
     p.RG = std::max(1, std::min(cap, p.M / 16));
     while (p.RG < cap && p.NS * (uint64_t)p.RG < 131072) p.RG <<= 1;
-    if (const char *e = getenv("BPPP_RG")) { int v = atoi(e); if (v >= 1 && v <= cap && (v & (v - 1)) == 0) p.RG = v; }
+    if (tune.rg) { const int v = tune.rg; if (v >= 1 && v <= cap && (v & (v - 1)) == 0) p.RG = v; }
   }
-  p.marg = !p.RG && p.M >= 256 && p.NS <= 65535 && !getenv("BPPP_REDUCE_OLD");
+  p.marg = !p.RG && p.M >= 256 && p.NS <= 65535 && !tune.reduce_old;
   memset(&p.mg, 0, sizeof p.mg);
   if (p.marg) {
     MargGeom &g = p.mg;
@@ -601,7 +600,7 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
     // serial length S per lane: about one wavefront per SIMD over the whole launch (2 * FB bucket reads over ~64K lanes)
     int S = 1;
     while (S < 16 && (2.0 * (double)p.FB) / S > 98304.0) S <<= 1;
-    if (const char *e = getenv("BPPP_MARG_S")) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = v; }
+    if (tune.marg_s) { const int v = tune.marg_s; if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = v; }
     g.SR = std::min(S, g.LO); g.SC = std::min(S, g.HI);
     g.PR = g.LO / g.SR; g.PC = g.HI / g.SC;
     while (g.PR > 64) { g.PR >>= 1; g.SR <<= 1; }                        // the segmented tree lives inside one wavefront
@@ -622,7 +621,7 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat) {
   // serial merge path) while the launch still has two wavefronts per SIMD
   // (L = 256 leaves one wavefront per SIMD and the gathers are no longer hidden: 1.39 ms against 1.15 ms at 2^20)
   if (flat) while (p.L < 128 && (double)p.total_max / (double)p.FB > 4.0 * p.L && p.total_max / (uint64_t)(2 * p.L) >= 65536) p.L <<= 1;
-  if (const char *e = getenv("BPPP_LACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) p.L = v; }
+  if (tune.lacc >= 1 && tune.lacc <= 4096) p.L = tune.lacc;
   p.G = (p.total_max + p.L - 1) / p.L; if (!p.G) p.G = 1;
   p.ntiles = (int)((p.FB + SCAN_TILE - 1) / SCAN_TILE);
   return p;
@@ -653,13 +652,13 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
   if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
   if (!d_scalars || !d_points) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
   if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "msm: n must be < 2^31");
-  int c = window_bits ? window_bits : choose_window(n, batch);
-  if (!window_bits) if (const char *e = getenv("BPPP_WINDOW_BATCHED")) { int v = atoi(e); if (batch > 4 && v >= 2 && v <= 16) c = v; }   // tuning sweeps
+  int c = window_bits ? window_bits : choose_window(n, batch, ctx->tune);
+  if (!window_bits && ctx->tune.window_batched) { const int v = ctx->tune.window_batched; if (batch > 4 && v >= 2 && v <= 16) c = v; }   // tuning sweeps
   if (c < 2 || c > 16) return fail(ctx, BPPP_ERR_ARG, "msm: window_bits must be in [2,16]");
   const bool flat = table_stride != 0;
   if (flat && (!window_bits || shared_points != 1 || n > table_stride || (uint64_t)(256 / c + 1) * table_stride >= (1ull << 31)))
     return fail(ctx, BPPP_ERR_ARG, "msm: bad precomputed-table arguments");
-  MsmPlan p = make_plan(n, batch, c, flat);
+  MsmPlan p = make_plan(n, batch, c, flat, ctx->tune);
   if (p.FB >= (1ull << 32) - 1 || p.total_max >= (1ull << 32) - 1)
     return fail(ctx, BPPP_ERR_ARG, "msm: batch*windows*buckets or batch*n*windows exceeds 2^32; split the batch");
 

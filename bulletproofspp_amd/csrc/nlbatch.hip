@@ -197,6 +197,25 @@ __global__ void __launch_bounds__(256) k_vb_sum_gs(const uint32_t *__restrict__ 
   if (t == 0) { fe x; for (int i = 0; i < 8; i++) x.v[i] = lds[i]; fe_store(out, x); }
 }
 
+// the MSM's point list [G | H | g | per proof: init points, responses] in one pass (16 bytes per lane) instead of five strided copies
+__global__ void __launch_bounds__(256) k_vb_gather_points(const uint4 *__restrict__ G, uint32_t nlen, const uint4 *__restrict__ H, uint32_t llen,
+                                                          const uint4 *__restrict__ g, const uint4 *__restrict__ init_pts, uint32_t ninit,
+                                                          const uint4 *__restrict__ resp, uint32_t nresp, uint64_t T, uint4 *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * T) return;
+  const uint64_t t = i >> 2; const uint32_t part = (uint32_t)(i & 3u);
+  const uint32_t shared = nlen + llen + 1, per = ninit + nresp;
+  const uint4 *src;
+  if (t < nlen) src = G + t * 4;
+  else if (t < nlen + llen) src = H + (t - nlen) * 4;
+  else if (t < shared) src = g;
+  else {
+    const uint64_t u = t - shared, b = u / per; const uint32_t m = (uint32_t)(u % per);
+    src = m < ninit ? init_pts + (b * ninit + m) * 4 : resp + (b * nresp + (m - ninit)) * 4;
+  }
+  out[i] = src[part];
+}
+
 // Validation of the untrusted per-proof arrays: every scalar canonical (< n), rho non-zero, every point the infinity encoding
 // or on y^2 = x^3 + 7 with canonical coordinates.  flags[0] |= 1 (scalar) / 2 (point) / 4 (rho = 0).
 __global__ void __launch_bounds__(256) k_vb_validate_scalars(const uint32_t *__restrict__ s, uint64_t n, int nonzero, uint32_t *__restrict__ flags) {
@@ -342,11 +361,14 @@ __global__ void __launch_bounds__(256) k_ipvb_proof(const uint32_t *__restrict__
 
 using namespace bppp;
 
-extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
-                                           const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q,
-                                           const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
-                                           const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
-                                           const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]) {
+// `validate` = false: the caller made every input itself on the device (csrc/rp.hip: decoded points are on the curve or infinity and
+// decoded / derived scalars canonical by construction), so the fifteen validation launches are skipped
+namespace bppp {
+int nl_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                        const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q,
+                        const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                        const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                        const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8], bool validate) {
   if (!ctx || !out_xy) return BPPP_ERR_ARG;
   if (!batch) { memset(out_xy, 0, 64); return BPPP_OK; }
   if (!d_g_xy || !d_rho || !d_q || !d_sp || (nlen && (!d_norm_g_xy || !d_pub_norm)) || (llen && (!d_lin_h_xy || !d_pub_lin_c || !d_pub_lin_x)) ||
@@ -368,17 +390,19 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
   int rc = BPPP_OK;
   do {
     // untrusted inputs first (asynchronous; the flag word is read after the MSM has synchronised the stream)
-    if (hipMemsetAsync(flags, 0, 4, st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: memset"); break; }
+    if (validate && hipMemsetAsync(flags, 0, 4, st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: memset"); break; }
     auto vs = [&](const void *p, uint64_t n, int nz) {
       if (n) k_vb_validate_scalars<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, nz, flags);
     };
     auto vp = [&](const void *p, uint64_t n) {
       if (n) k_vb_validate_points<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, flags);
     };
-    vs(d_rho, batch, 1); vs(d_q, batch, 0); vs(d_sp, batch, 0); vs(d_pub_norm, batch * nlen, 0); vs(d_pub_lin_c, batch * llen, 0);
-    vs(d_pub_lin_x, batch * llen, 0); vs(d_es, batch * k, 0); vs(d_wit_norm, batch * fn, 0); vs(d_wit_lin, batch * fl, 0);
-    vs(d_init_scalars, batch * ninit, 0);
-    vp(d_g_xy, 1); vp(d_norm_g_xy, nlen); vp(d_lin_h_xy, llen); vp(d_init_points_xy, batch * ninit); vp(d_responses_xy, batch * 2 * k);
+    if (validate) {
+      vs(d_rho, batch, 1); vs(d_q, batch, 0); vs(d_sp, batch, 0); vs(d_pub_norm, batch * nlen, 0); vs(d_pub_lin_c, batch * llen, 0);
+      vs(d_pub_lin_x, batch * llen, 0); vs(d_es, batch * k, 0); vs(d_wit_norm, batch * fn, 0); vs(d_wit_lin, batch * fl, 0);
+      vs(d_init_scalars, batch * ninit, 0);
+      vp(d_g_xy, 1); vp(d_norm_g_xy, nlen); vp(d_lin_h_xy, llen); vp(d_init_points_xy, batch * ninit); vp(d_responses_xy, batch * 2 * k);
+    }
     k_vb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_q, (const uint32_t *)d_es, (uint32_t)batch, (int)k, fac, qf2);
     if (nlen) {
       if (k >= 2) k_vb_shared4<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
@@ -399,17 +423,12 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
                                                             (const uint32_t *)d_init_scalars, (uint32_t)ninit, (const uint32_t *)d_es, gs, sc + shared * 8);
     k_vb_sum_gs<<<dim3(1), dim3(256), 0, st>>>(gs, (uint32_t)batch, sc + (nlen + llen) * 8);
     // points: [G | H | g | per proof: init points, responses]
-    hipError_t he = hipSuccess;
-    if (nlen) he = hipMemcpyAsync(pts, d_norm_g_xy, nlen * 64, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess && llen) he = hipMemcpyAsync(pts + nlen * 16, d_lin_h_xy, llen * 64, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess) he = hipMemcpyAsync(pts + (nlen + llen) * 16, d_g_xy, 64, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess && ninit)
-      he = hipMemcpy2DAsync(pts + shared * 16, per * 64, d_init_points_xy, ninit * 64, ninit * 64, batch, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess && k)
-      he = hipMemcpy2DAsync(pts + (shared + ninit) * 16, per * 64, d_responses_xy, 2 * k * 64, 2 * k * 64, batch, hipMemcpyDeviceToDevice, st);
-    if (he != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: assembling the MSM failed"); break; }
+    k_vb_gather_points<<<dim3((unsigned)((4 * T + 255) / 256)), dim3(256), 0, st>>>((const uint4 *)d_norm_g_xy, (uint32_t)nlen, (const uint4 *)d_lin_h_xy, (uint32_t)llen,
+                                                                                   (const uint4 *)d_g_xy, (const uint4 *)d_init_points_xy, (uint32_t)ninit,
+                                                                                   (const uint4 *)d_responses_xy, (uint32_t)(2 * k), (uint64_t)T, (uint4 *)pts);
+    if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: assembling the MSM failed"); break; }
     rc = msm_run(ctx, sc, pts, T, 1, 1, 0, out_xy);
-    if (rc) break;
+    if (rc || !validate) break;                 // (msm_run returns with the stream drained; nothing was flagged without the validation pass)
     uint32_t hflags = 0;
     if (hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
       rc = fail(ctx, BPPP_ERR_HIP, "nl_verify_batch: reading the validation flags failed"); break;
@@ -421,15 +440,26 @@ extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
   hipStreamSynchronize(st);
   return rc;
 }
+}  // namespace bppp
+
+extern "C" int bppp_nl_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                                           const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_q,
+                                           const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                                           const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                                           const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]) {
+  return bppp::nl_verify_batch_run(ctx, batch, nlen, llen, k, fn, fl, ninit, d_g_xy, d_norm_g_xy, d_lin_h_xy, d_rho, d_q, d_sp, d_pub_norm, d_pub_lin_c, d_pub_lin_x, d_es,
+                                   d_wit_norm, d_wit_lin, d_init_scalars, d_init_points_xy, d_responses_xy, out_xy, true);
+}
 
 // verifyBPM for B arguments of the inner-product flavour (src/Bulletproof/InnerProductArgument.hs; verifyBPM src/Bulletproof.hs:370-378):
 // same layout and result contract as bppp_nl_verify_batch_device; d_r holds the per-proof argument of makeNorm (the range proofs'
 // challenge q, src/RangeProof/TypedReciprocal.hs:356), fn counts SCALARS of the final norm witness (even).
-extern "C" int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
-                                           const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_r,
-                                           const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
-                                           const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
-                                           const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]) {
+namespace bppp {
+int ip_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                        const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_r,
+                        const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                        const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                        const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8], bool validate) {
   if (!ctx || !out_xy) return BPPP_ERR_ARG;
   if (!batch) { memset(out_xy, 0, 64); return BPPP_OK; }
   if (!d_g_xy || !d_rho || !d_r || !d_sp || (nlen && (!d_norm_g_xy || !d_pub_norm)) || (llen && (!d_lin_h_xy || !d_pub_lin_c || !d_pub_lin_x)) ||
@@ -457,10 +487,12 @@ extern "C" int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
     auto vp = [&](const void *p, uint64_t n) {
       if (n) k_vb_validate_points<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)p, n, flags);
     };
-    vs(d_rho, batch, 1); vs(d_r, batch, 0); vs(d_sp, batch, 0); vs(d_pub_norm, batch * nlen, 0); vs(d_pub_lin_c, batch * llen, 0);
-    vs(d_pub_lin_x, batch * llen, 0); vs(d_es, batch * k, 0); vs(d_wit_norm, batch * fn, 0); vs(d_wit_lin, batch * fl, 0);
-    vs(d_init_scalars, batch * ninit, 0);
-    vp(d_g_xy, 1); vp(d_norm_g_xy, nlen); vp(d_lin_h_xy, llen); vp(d_init_points_xy, batch * ninit); vp(d_responses_xy, batch * 2 * k);
+    if (validate) {
+      vs(d_rho, batch, 1); vs(d_r, batch, 0); vs(d_sp, batch, 0); vs(d_pub_norm, batch * nlen, 0); vs(d_pub_lin_c, batch * llen, 0);
+      vs(d_pub_lin_x, batch * llen, 0); vs(d_es, batch * k, 0); vs(d_wit_norm, batch * fn, 0); vs(d_wit_lin, batch * fl, 0);
+      vs(d_init_scalars, batch * ninit, 0);
+      vp(d_g_xy, 1); vp(d_norm_g_xy, nlen); vp(d_lin_h_xy, llen); vp(d_init_points_xy, batch * ninit); vp(d_responses_xy, batch * 2 * k);
+    }
     k_ipvb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_r, (const uint32_t *)d_es, (const uint32_t *)d_wit_norm, (uint32_t)batch,
                                                                             (int)k, (uint32_t)fm, facx, facy, qf, v, flags);
     const uint32_t sper = (ntiles + SUM_GROUPS - 1) / SUM_GROUPS, groups = (ntiles + sper - 1) / sper;
@@ -481,15 +513,10 @@ extern "C" int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
                                                               (const uint32_t *)d_pub_lin_c, (uint32_t)llen, facx, (int)k, (const uint32_t *)d_init_scalars, (uint32_t)ninit,
                                                               (const uint32_t *)d_es, gs, sc + shared * 8);
     k_vb_sum_gs<<<dim3(1), dim3(256), 0, st>>>(gs, (uint32_t)batch, sc + (nlen + llen) * 8);
-    hipError_t he = hipSuccess;
-    if (nlen) he = hipMemcpyAsync(pts, d_norm_g_xy, nlen * 64, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess && llen) he = hipMemcpyAsync(pts + nlen * 16, d_lin_h_xy, llen * 64, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess) he = hipMemcpyAsync(pts + (nlen + llen) * 16, d_g_xy, 64, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess && ninit)
-      he = hipMemcpy2DAsync(pts + shared * 16, per * 64, d_init_points_xy, ninit * 64, ninit * 64, batch, hipMemcpyDeviceToDevice, st);
-    if (he == hipSuccess && k)
-      he = hipMemcpy2DAsync(pts + (shared + ninit) * 16, per * 64, d_responses_xy, 2 * k * 64, 2 * k * 64, batch, hipMemcpyDeviceToDevice, st);
-    if (he != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "ip_verify_batch: assembling the MSM failed"); break; }
+    k_vb_gather_points<<<dim3((unsigned)((4 * T + 255) / 256)), dim3(256), 0, st>>>((const uint4 *)d_norm_g_xy, (uint32_t)nlen, (const uint4 *)d_lin_h_xy, (uint32_t)llen,
+                                                                                   (const uint4 *)d_g_xy, (const uint4 *)d_init_points_xy, (uint32_t)ninit,
+                                                                                   (const uint4 *)d_responses_xy, (uint32_t)(2 * k), (uint64_t)T, (uint4 *)pts);
+    if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "ip_verify_batch: assembling the MSM failed"); break; }
     rc = msm_run(ctx, sc, pts, T, 1, 1, 0, out_xy);
     if (rc) break;
     uint32_t hflags = 0;
@@ -503,4 +530,14 @@ extern "C" int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t n
   } while (0);
   hipStreamSynchronize(st);
   return rc;
+}
+}  // namespace bppp
+
+extern "C" int bppp_ip_verify_batch_device(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, size_t k, size_t fn, size_t fl, size_t ninit,
+                                           const void *d_g_xy, const void *d_norm_g_xy, const void *d_lin_h_xy, const void *d_rho, const void *d_r,
+                                           const void *d_sp, const void *d_pub_norm, const void *d_pub_lin_c, const void *d_pub_lin_x,
+                                           const void *d_es, const void *d_wit_norm, const void *d_wit_lin, const void *d_init_scalars,
+                                           const void *d_init_points_xy, const void *d_responses_xy, uint64_t out_xy[8]) {
+  return bppp::ip_verify_batch_run(ctx, batch, nlen, llen, k, fn, fl, ninit, d_g_xy, d_norm_g_xy, d_lin_h_xy, d_rho, d_r, d_sp, d_pub_norm, d_pub_lin_c, d_pub_lin_x, d_es,
+                                   d_wit_norm, d_wit_lin, d_init_scalars, d_init_points_xy, d_responses_xy, out_xy, true);
 }

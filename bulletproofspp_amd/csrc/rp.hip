@@ -59,7 +59,7 @@ template <int MOD> BPPP_DI fe load_field_be(const uint8_t *p) {
 //   else              the input commitments                         = the commitments file
 // Output: responses to resp[b][t], the rest to init[b][...] in the order blCom : rCom : dmCom : mCom : nComs.
 __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batch, const uint8_t *__restrict__ coms, const uint8_t *__restrict__ proofs,
-                                                         uint32_t *__restrict__ init_pts, uint32_t *__restrict__ resp_pts, uint32_t *__restrict__ bad) {
+                                                         uint32_t *__restrict__ init_pts, uint32_t *__restrict__ resp_pts, uint32_t *__restrict__ bad) {   // bad[batch] per proof, bad[batch] any
   const uint32_t npts = rp_npts(D);
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (uint64_t)batch * npts) return;
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batc
   fe d;
   const bool y_big = raw_sub(d, yn, ye) != 0;                  // -y < y
   aff r; r.x = x; r.y = (y_big != want_big) ? fq_from_fe(yn) : y;
-  if (!ok) { r = aff_inf(); atomicOr(bad + b, 1u); }
+  if (!ok) { r = aff_inf(); atomicOr(bad + b, 1u); atomicOr(bad + batch, 1u); }
   uint32_t *out = t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16
                               : init_pts + ((size_t)b * (4 + D.nr) + (t - 2 * D.k)) * 16;
   aff_store(out, r);
@@ -315,6 +315,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->d_plan) hipFree(rp->d_plan);
   if (rp->work) hipFree(rp->work);
   if (rp->stage) hipFree(rp->stage);
+  if (rp->hflag) hipHostFree(rp->hflag);
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
@@ -365,6 +366,7 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
     rp->c_points.assign(points_xy, points_xy + 8 * (2 + st.llen + st.nlen)); rp->c_has_types = has_types;
     hipSetDevice(ctx->device);
     BPPP_HIP(ctx, hipMalloc(&rp->d_basis, (1 + st.nlen + st.llen) * 64));
+    BPPP_HIP(ctx, hipHostMalloc((void **)&rp->hflag, 64, hipHostMallocDefault));
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis, rp->h_g.data(), 64, hipMemcpyHostToDevice));
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16, rp->h_H.data(), st.llen * 64, hipMemcpyHostToDevice));
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16 * (1 + st.llen), rp->h_G.data(), st.nlen * 64, hipMemcpyHostToDevice));
@@ -529,7 +531,8 @@ U256 host_digest_to_fr(const uint32_t h[8]) {
   return bppp_rps::u_mod_n(r);
 }
 // init [4 + nr][8], resp [2k][8] (u64 limbs as downloaded); ch_out [7][4], es_out [k][4]  (the weight rho_b is k_rp_rho's on both routes)
-void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, uint64_t *ch_out, uint64_t *es_out) {
+// part 0: the seven challenges of verifyTRRPM; part 1: the k round challenges of verifyBPM
+void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, uint64_t *ch_out, uint64_t *es_out, int part) {
   const uint32_t k = rp->D.k, nr = rp->D.nr, npts = 2 * k + 4 + nr;
   std::vector<std::string> txt(npts);
   for (uint32_t t = 0; t < npts; t++) {
@@ -545,10 +548,13 @@ void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_
     h.finish(d);
     host_digest_to_fr(d).store(out);
   };
-  for (uint32_t n = 1; n <= 3; n++) one(n, 2 + nr, 2 * k + 2, ch_out + 4 * (n - 1));          // e, x, r0        (the order of rp_build_plan)
-  for (uint32_t n = 1; n <= 3; n++) one(n, 3 + nr, 2 * k + 1, ch_out + 4 * (3 + n - 1));      // q, x', r1
-  one(1, 4 + nr, 2 * k, ch_out + 4 * 6);                                                      // t
-  for (uint32_t j = 1; j <= k; j++) one(1, 4 + nr + 2 * j, 2 * (k - j), es_out + 4 * (k - j));   // round j: es is LAST round first
+  if (part == 0) {
+    for (uint32_t n = 1; n <= 3; n++) one(n, 2 + nr, 2 * k + 2, ch_out + 4 * (n - 1));          // e, x, r0        (the order of rp_build_plan)
+    for (uint32_t n = 1; n <= 3; n++) one(n, 3 + nr, 2 * k + 1, ch_out + 4 * (3 + n - 1));      // q, x', r1
+    one(1, 4 + nr, 2 * k, ch_out + 4 * 6);                                                      // t
+  } else {
+    for (uint32_t j = 1; j <= k; j++) one(1, 4 + nr + 2 * j, 2 * (k - j), es_out + 4 * (k - j));   // round j: es is LAST round first
+  }
 }
 }  // namespace
 extern "C" {
@@ -583,17 +589,18 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     text = cv.take<uint8_t>(B * (size_t)D.text_stride + 64); text_off = cv.take<uint32_t>(B * (npts + 1));
     ch = cv.take<uint32_t>(B * 7 * 8); es = cv.take<uint32_t>(B * k * 8 + 8); rho = cv.take<uint32_t>(B * 8);
     q = cv.take<uint32_t>(B * 8); sp = cv.take<uint32_t>(B * 8); pub_norm = cv.take<uint32_t>(B * nlen * 8); pub_lin_c = cv.take<uint32_t>(B * llen * 8);
-    pub_lin_x = cv.take<uint32_t>(B * llen * 8); init_sc = cv.take<uint32_t>(B * ninit * 8); bad = cv.take<uint32_t>(B);
+    pub_lin_x = cv.take<uint32_t>(B * llen * 8); init_sc = cv.take<uint32_t>(B * ninit * 8); bad = cv.take<uint32_t>(B + 1);
     d_seed = cv.take<uint8_t>(32);
     if (!pass) { need = cv.off; int rc = rp_ensure_work(rp, need); if (rc) return rc; }
   }
-  BPPP_HIP(ctx, hipMemsetAsync(bad, 0, B * 4, st));
+  BPPP_HIP(ctx, hipMemsetAsync(bad, 0, (B + 1) * 4, st));
   BPPP_HIP(ctx, hipMemsetAsync(pub_lin_x, 0, B * llen * 32, st));       // the public linear vector of these proofs is zero (TypedReciprocal.hs:466)
   BPPP_HIP(ctx, hipMemcpyAsync(d_seed, seed, 32, hipMemcpyHostToDevice, st));
   const uint64_t np = (uint64_t)B * npts, ns = (uint64_t)B * (D.fn + D.fl);
   k_rp_decode_points<<<dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_coms_files, (const uint8_t *)d_proof_files, init_pts,
                                                                            resp_pts, bad);
   if (ns) k_rp_decode_scalars<<<dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_proof_files, wit_norm, wit_lin);
+  BPPP_HIP(ctx, hipMemcpyAsync(rp->hflag, bad + B, 4, hipMemcpyDeviceToHost, st));     // pinned; read after the MSM has drained the stream
   const size_t host_oracle_max = rp->opt.host_oracle_verify;
   // async copies below target host vectors: whatever path leaves this function, the stream is drained before they are destroyed
   struct StreamDrain { hipStream_t s; ~StreamDrain() { hipStreamSynchronize(s); } };
@@ -603,44 +610,67 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     BPPP_HIP(ctx, hipMemcpyAsync(hi.data(), init_pts, B * ninit * 64, hipMemcpyDeviceToHost, st));
     if (k) BPPP_HIP(ctx, hipMemcpyAsync(hr.data(), resp_pts, B * 2 * k * 64, hipMemcpyDeviceToHost, st));
     BPPP_HIP(ctx, hipStreamSynchronize(st));
-    auto work = [&](size_t lo, size_t hi_) {
-      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, &hi[b * ninit * 8], &hr[b * 2 * k * 8], &hch[b * 28], &hes[b * k * 4]);
+    // the seven challenges of verifyTRRPM first: k_trrp_public needs only those and runs while the host hashes the argument's rounds
+    auto work = [&](size_t lo, size_t hi_, int part) {
+      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, &hi[b * ninit * 8], &hr[b * 2 * k * 8], &hch[b * 28], &hes[b * k * 4], part);
     };
-    if (B == 1) work(0, 1);                            // ~0.2 ms per proof (168 decimal conversions, 16 hashes of ~11 KB): one thread per proof
-    else {
+    auto all = [&](int part) {
+      if (B == 1) { work(0, 1, part); return; }        // ~0.2 ms per proof (168 decimal conversions, 16 hashes of ~11 KB): one thread per proof
       std::vector<std::thread> th;
-      for (size_t b = 0; b < B; b++) th.emplace_back(work, b, b + 1);
+      for (size_t b = 0; b < B; b++) th.emplace_back(work, b, b + 1, part);
       for (auto &x : th) x.join();
-    }
+    };
+    all(0);
     BPPP_HIP(ctx, hipMemcpyAsync(ch, hch.data(), B * 7 * 32, hipMemcpyHostToDevice, st));
+    int rc0 = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
+    if (rc0) return rc0;
+    all(1);
     if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes.data(), B * k * 32, hipMemcpyHostToDevice, st));
     BPPP_HIP(ctx, hipStreamSynchronize(st));          // the staging vectors go out of scope
   } else {
+    // transcript text, then the hashing in two halves: the seven challenges of verifyTRRPM on the call's stream, followed there by
+    // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it — the hashing is
+    // latency-bound (one wavefront per SIMD at 4096 proofs), the scalar kernel is multiplier-bound: they share the SIMDs
     k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
-    const uint64_t nh = (uint64_t)B * rp->nhash;
-    k_rp_hash<<<dim3((unsigned)((nh + 63) / 64)), dim3(128), 0, st>>>(D, (uint32_t)B, rp->nhash, rp->d_plan, text, text_off, ch, es);
+    const uint32_t nch = 7, nes = rp->nhash - 7;
+    hipStream_t aux = st;
+    if (nes) {
+      int rca = ctx_aux(ctx); if (rca) return rca;
+      aux = ctx->aux_stream;
+      BPPP_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
+      BPPP_HIP(ctx, hipStreamWaitEvent(aux, ctx->aux_fork, 0));
+    }
+    k_rp_hash<<<dim3((unsigned)(((uint64_t)B * nch + 63) / 64)), dim3(128), 0, st>>>(D, (uint32_t)B, nch, rp->d_plan, text, text_off, ch, es);
+    if (nes) {
+      k_rp_hash<<<dim3((unsigned)(((uint64_t)B * nes + 63) / 64)), dim3(128), 0, aux>>>(D, (uint32_t)B, nes, rp->d_plan + nch, text, text_off, ch, es);
+      BPPP_HIP(ctx, hipEventRecord(ctx->aux_join, aux));
+    }
+    BPPP_HIP(ctx, hipGetLastError());
+    int rc0 = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
+    if (nes) BPPP_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));      // (joined even when the launch above failed: the second stream must not outlive the call's buffers)
+    if (rc0) { hipStreamSynchronize(st); return rc0; }
   }
   k_rp_rho<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, index_offset, d_seed, ch, es, wit_norm, wit_lin, rho);
   BPPP_HIP(ctx, hipGetLastError());
-  int rc = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
-  if (rc) return rc;
+  int rc = BPPP_OK;
   uint64_t out_xy[8];
   // verifyBPM of the setup's argument flavour (q is makeNorm's r for the inner-product one)
-  auto verify_bp = S.flavour ? bppp_ip_verify_batch_device : bppp_nl_verify_batch_device;
+  // (every input below was made on the device by this call: canonical scalars, points on the curve or infinity — no validation pass)
+  auto verify_bp = S.flavour ? bppp::ip_verify_batch_run : bppp::nl_verify_batch_run;
   rc = verify_bp(ctx, B, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho, q, sp, pub_norm,
-                 pub_lin_c, pub_lin_x, es, wit_norm, wit_lin, init_sc, init_pts, resp_pts, out_xy);
+                 pub_lin_c, pub_lin_x, es, wit_norm, wit_lin, init_sc, init_pts, resp_pts, out_xy, false);
   if (rc) return rc;
-  // decode failures (an x with no point on the curve): Nothing in the reference (decodeCommitments, Encoding.hs:119-128)
-  std::vector<uint32_t> hbad(B);
+  // decode failures (an x with no point on the curve): Nothing in the reference (decodeCommitments, Encoding.hs:119-128).  The batch-wide
+  // flag reached pinned memory long before the MSM drained the stream; the per-proof words are fetched only when somebody needs them
+  const bool any_bad = rp->hflag[0] != 0;
+  std::vector<uint32_t> hbad(proof_status ? B : 0);
   StreamDrain drain{st};
-  BPPP_HIP(ctx, hipMemcpyAsync(hbad.data(), bad, B * 4, hipMemcpyDeviceToHost, st));
+  if (proof_status) BPPP_HIP(ctx, hipMemcpyAsync(hbad.data(), bad, B * 4, hipMemcpyDeviceToHost, st));
   if (challenges_out) {
     BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out, (7 + k) * 32, ch, 7 * 32, 7 * 32, B, hipMemcpyDeviceToHost, st));
     if (k) BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out + 28, (7 + k) * 32, es, k * 32, k * 32, B, hipMemcpyDeviceToHost, st));
   }
-  BPPP_HIP(ctx, hipStreamSynchronize(st));
-  bool any_bad = false;
-  for (size_t b = 0; b < B; b++) any_bad |= hbad[b] != 0;
+  if (proof_status || challenges_out) BPPP_HIP(ctx, hipStreamSynchronize(st));
   auto is_inf = [](const uint64_t *p) { uint64_t o = 0; for (int i = 0; i < 8; i++) o |= p[i]; return o == 0; };
   const bool whole = is_inf(out_xy);
   if (combined_xy) memcpy(combined_xy, out_xy, 64);
@@ -661,7 +691,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
       const size_t o = r.lo, n = r.hi - r.lo;
       rc = verify_bp(ctx, n, nlen, llen, k, D.fn, D.fl, ninit, rp->d_g(), rp->d_G(), rp->d_H(), rho + o * 8, q + o * 8,
                                        sp + o * 8, pub_norm + o * nlen * 8, pub_lin_c + o * llen * 8, pub_lin_x + o * llen * 8, es + o * k * 8, wit_norm + o * D.fn * 8,
-                                       wit_lin + o * D.fl * 8, init_sc + o * ninit * 8, init_pts + o * ninit * 16, resp_pts + o * 2 * k * 16, out_xy);
+                                       wit_lin + o * D.fl * 8, init_sc + o * ninit * 8, init_pts + o * ninit * 16, resp_pts + o * 2 * k * 16, out_xy, false);
       if (rc) return rc;
       ok = is_inf(out_xy);
     }

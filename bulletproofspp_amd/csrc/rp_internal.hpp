@@ -41,6 +41,11 @@ template <class F> static void rp_parallel(size_t n, F f) {
 }
 
 int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
+// bppp_{nl,ip}_verify_batch_device with the validation of untrusted inputs optional (csrc/nlbatch.hip)
+int nl_verify_batch_run(bppp_ctx *, size_t, size_t, size_t, size_t, size_t, size_t, size_t, const void *, const void *, const void *, const void *, const void *, const void *,
+                        const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, uint64_t *, bool);
+int ip_verify_batch_run(bppp_ctx *, size_t, size_t, size_t, size_t, size_t, size_t, size_t, const void *, const void *, const void *, const void *, const void *, const void *,
+                        const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, uint64_t *, bool);
 
 }  // namespace bppp
 
@@ -101,6 +106,7 @@ struct bppp_rp {
   bppp::CombTable *comb = nullptr; bool comb_owned = false, comb_failed = false; size_t proved_total = 0;
   uint32_t *d_comb_out = nullptr; size_t comb_out_rows = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
+  uint32_t *hflag = nullptr;                     // pinned: the verifier's "some proof did not decode" word, copied out while the batch is still in flight
   void *work = nullptr; size_t work_bytes = 0;
   void *stage = nullptr; size_t stage_bytes = 0;
 };

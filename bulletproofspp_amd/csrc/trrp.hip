@@ -259,9 +259,11 @@ int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges
   if (!batch) return BPPP_OK;
   if (!d_challenges || !d_q || !d_sp || !d_pub_norm || !d_pub_lin_c || !d_init_scalars || batch >= (1u << 24)) return fail(ctx, BPPP_ERR_ARG, "trrp_public: bad arguments");
   hipSetDevice(ctx->device);
-  // lanes per proof: 32 (two proofs per wavefront) unless the LDS of the proofs of a wavefront would not fit a workgroup
-  int G = 32;
-  if (const char *e = getenv("BPPP_TRRP_G")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) G = v; }
+  // lanes per proof: 32 (two proofs per wavefront) unless the LDS of the proofs of a wavefront would not fit a workgroup; a batch that
+  // cannot give every SIMD a wavefront anyway (<= 1024 proofs) takes a whole wavefront per proof: the kernel is then one proof's
+  // dependency chain, which 64 lanes walk in fewer steps
+  static const int forced_g = [] { const char *e = getenv("BPPP_TRRP_G"); const int v = e ? atoi(e) : 0; return (v == 16 || v == 32 || v == 64) ? v : 0; }();
+  int G = forced_g ? forced_g : (batch <= 1024 ? 64 : 32);
   auto words = [&](int g) { return ((size_t)(2 + o->D.nsyms) + 2 * (size_t)g + o->D.nr + 3 * TRRP_MAX_SLOTS) * 8; };
   while (G < 64 && words(G) * 4 * (64 / G) > 64 * 1024) G <<= 1;
   const size_t wpp = words(G), lds = wpp * 4 * (64 / G);
