@@ -629,25 +629,28 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     BPPP_HIP(ctx, hipStreamSynchronize(st));          // the staging vectors go out of scope
   } else {
     // transcript text, then the hashing in two halves: the seven challenges of verifyTRRPM on the call's stream, followed there by
-    // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it — the hashing is
-    // latency-bound (one wavefront per SIMD at 4096 proofs), the scalar kernel is multiplier-bound: they share the SIMDs
+    // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it.  Only while the
+    // batch leaves SIMDs idle (<= 1024 proofs: 256 proofs 1.65 -> 1.38 ms of kernels); at 4096 proofs the three kernels already
+    // fill the VALU and running them side by side only stretches each (hash 0.65 -> 0.55 + 0.87, scalars 0.84 -> 1.04 ms: measured, not kept)
     k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
     const uint32_t nch = 7, nes = rp->nhash - 7;
     hipStream_t aux = st;
-    if (nes) {
+    const bool fork = nes && B <= 1024;
+    if (fork) {
       int rca = ctx_aux(ctx); if (rca) return rca;
       aux = ctx->aux_stream;
       BPPP_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
       BPPP_HIP(ctx, hipStreamWaitEvent(aux, ctx->aux_fork, 0));
     }
-    k_rp_hash<<<dim3((unsigned)(((uint64_t)B * nch + 63) / 64)), dim3(128), 0, st>>>(D, (uint32_t)B, nch, rp->d_plan, text, text_off, ch, es);
-    if (nes) {
+    const uint32_t nfirst = fork ? nch : rp->nhash;            // one launch over every hash unless the halves run side by side
+    k_rp_hash<<<dim3((unsigned)(((uint64_t)B * nfirst + 63) / 64)), dim3(128), 0, st>>>(D, (uint32_t)B, nfirst, rp->d_plan, text, text_off, ch, es);
+    if (fork) {
       k_rp_hash<<<dim3((unsigned)(((uint64_t)B * nes + 63) / 64)), dim3(128), 0, aux>>>(D, (uint32_t)B, nes, rp->d_plan + nch, text, text_off, ch, es);
       BPPP_HIP(ctx, hipEventRecord(ctx->aux_join, aux));
     }
     BPPP_HIP(ctx, hipGetLastError());
     int rc0 = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
-    if (nes) BPPP_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));      // (joined even when the launch above failed: the second stream must not outlive the call's buffers)
+    if (fork) BPPP_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));      // (joined even when the launch above failed: the second stream must not outlive the call's buffers)
     if (rc0) { hipStreamSynchronize(st); return rc0; }
   }
   k_rp_rho<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, index_offset, d_seed, ch, es, wit_norm, wit_lin, rho);
