@@ -29,7 +29,7 @@ SYMBOLS = [
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
     "bppp_basis_create", "bppp_basis_create_device", "bppp_basis_destroy", "bppp_basis_info", "bppp_msm_basis", "bppp_basis_enable_comb",
-    "bppp_rp_create", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_set_option", "bppp_rp_shape_of", "bppp_rp_digits", "bppp_hash_to_scalar", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_verify_shard_device", "bppp_rp_prove_batch",
+    "bppp_rp_create", "bppp_rp_create_binary", "bppp_rp_destroy", "bppp_rp_info", "bppp_rp_set_option", "bppp_rp_shape_of", "bppp_rp_digits", "bppp_hash_to_scalar", "bppp_rp_verify_batch", "bppp_rp_verify_batch_device", "bppp_rp_verify_shard_device", "bppp_rp_prove_batch",
 ]
 
 
@@ -118,6 +118,7 @@ def load_library() -> C.CDLL:
     lib.bppp_msm_basis.argtypes = [vp, vp, sz, sz, vp]
     lib.bppp_basis_enable_comb.argtypes = [vp, C.c_int, sz, vp, vp]
     lib.bppp_rp_create.argtypes = [vp, i, i, vp, sz, vp, sz, vp, sz, C.c_char_p, C.POINTER(vp)]
+    lib.bppp_rp_create_binary.argtypes = [vp, i, i, vp, sz, vp, vp, sz, C.c_char_p, C.POINTER(vp)]
     lib.bppp_rp_destroy.argtypes = [vp]
     lib.bppp_rp_destroy.restype = None
     lib.bppp_rp_info.argtypes = [vp, vp]

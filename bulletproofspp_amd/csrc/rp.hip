@@ -55,7 +55,7 @@ template <int MOD> BPPP_DI fe load_field_be(const uint8_t *p) {
 
 // Point t of a proof IN TRANSCRIPT ORDER (newest first, the order shaOracle's final call sees, src/ZKP.hs:98):
 //   t < 2k            the argument's responses, last round first  = bpComs of the proof file (RangeProof.hs:60-66)
-//   2k <= t < 2k + 4  blCom, rCom, dmCom, mCom                      = rpComs of the proof file
+//   2k <= t < 2k + 4  blCom, rCom, dmCom, mCom  (Binary: blCom, dCom) = rpComs of the proof file
 //   else              the input commitments                         = the commitments file
 // Output: responses to resp[b][t], the rest to init[b][...] in the order blCom : rCom : dmCom : mCom : nComs.
 __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batch, const uint8_t *__restrict__ coms, const uint8_t *__restrict__ proofs,
@@ -66,15 +66,15 @@ __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batc
   const uint32_t b = (uint32_t)(g / npts), t = (uint32_t)(g % npts);
   const uint8_t *signs, *xs;
   uint32_t idx;
-  const uint32_t nproof_pts = 4 + 2 * D.k;
-  if (t < 2 * D.k + 4) {
+  const uint32_t nproof_pts = D.nrp + 2 * D.k;
+  if (t < 2 * D.k + D.nrp) {
     const uint8_t *pf = proofs + (size_t)b * D.proof_bytes + (size_t)(D.fn + D.fl) * 32;
     signs = pf; xs = pf + (nproof_pts + 7) / 8;
-    idx = t < 2 * D.k ? 4 + t : t - 2 * D.k;
+    idx = t < 2 * D.k ? D.nrp + t : t - 2 * D.k;
   } else {
     const uint8_t *cf = coms + (size_t)b * D.coms_bytes;
     signs = cf; xs = cf + (D.nr + 7) / 8;
-    idx = t - 2 * D.k - 4;
+    idx = t - 2 * D.k - D.nrp;
   }
   const bool want_big = (signs[idx >> 3] >> (idx & 7)) & 1;
   const fe xe = load_field_be<0>(xs + (size_t)idx * 32);
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batc
   aff r; r.x = x; r.y = (y_big != want_big) ? fq_from_fe(yn) : y;
   if (!ok) { r = aff_inf(); atomicOr(bad + b, 1u); atomicOr(bad + batch, 1u); }
   uint32_t *out = t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16
-                              : init_pts + ((size_t)b * (4 + D.nr) + (t - 2 * D.k)) * 16;
+                              : init_pts + ((size_t)b * (D.nrp + D.nr) + (t - 2 * D.k)) * 16;
   aff_store(out, r);
 }
 
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64) k_rp_decode_scalars(RpDims D, uint32_t bat
 
 // ------------------------------------------------------------------------------------------------ transcript text (helpers: rphash.hip.h)
 BPPP_DI const uint32_t *rp_point_ptr(const RpDims &D, const uint32_t *init_pts, const uint32_t *resp_pts, uint32_t b, uint32_t t) {
-  return t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16 : init_pts + ((size_t)b * (4 + D.nr) + (t - 2 * D.k)) * 16;
+  return t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16 : init_pts + ((size_t)b * (D.nrp + D.nr) + (t - 2 * D.k)) * 16;
 }
 
 // One workgroup per proof.  Pass 1: the text length of every point (x digits + y digits); exclusive scan; pass 2: the digits
@@ -219,9 +219,95 @@ __global__ void __launch_bounds__(128) k_rp_hash(RpDims D, uint32_t batch, uint3
   const uint32_t t0 = off[pl->start_pt], t1 = off[npts];
   const fe v = rp_hash_to_fr_pc(active, pl->hdr_be, pl->hlen, text + (size_t)b * D.text_stride + t0, t1 - t0, lds);   // the suffix of the proof's text this call hashes
   if (!active || threadIdx.x < 64) return;                  // the consumer wavefront holds the digests
-  const uint32_t slot = pl->out_slot;
+  const uint32_t slot = pl->out_slot;                      // < 7: a challenge of the range-proof layer (ch rows are 7 wide for both kinds), else 7 + round slot
   if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
   else fe_store(es + ((size_t)b * D.k + (slot - 7)) * 8, v);
+}
+
+
+// ------------------------------------------------------------------------------------------------ RangeProof.Binary: public scalars
+// The scalar work of verifyBRPM (src/RangeProof/Binary.hs:206-222) for a batch, one wavefront per proof, from the proof's challenges
+// (q, x, r, t) = ch slots 0, 1, 2, 6:
+//   makePublicConsts (:73-98): bss_i = x^(2(j+1)) b_i over the positions of the ranges that are not assumed; p_i = bss_i q0^-(i+1) - 1/2;
+//                              sc = -2 (net' + sum_j min_j x^(2(j+1))) + sum_i q0^(i+1) p_i^2,  net' = -x netPublic when conserving
+//   the argument's public opening (:215-219): scalar t^2 sc, norm vector t p_i (zero beyond the live positions), linear weights
+//   [0, r t] (setupBRP's psv, :151-152), and the initCom scalars of TranscriptBRP (:107-110) in commitment order blCom : dCom : nComs =
+//   1, t, 2 t^2 inputCoeffs (:127-129).  q0 = q^2 (NL) or -q^2 (IP) as qPowers' has it.
+struct BrpDims { uint32_t nlen, nlive, nr, conserve, flavour; };
+__global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, const uint32_t *__restrict__ pos_range, const uint32_t *__restrict__ pos_coeff,
+                                                   const uint32_t *__restrict__ range_min, const uint32_t *__restrict__ range_flags, const uint32_t *__restrict__ net_public,
+                                                   const uint32_t *__restrict__ ch, uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp,
+                                                   uint32_t *__restrict__ out_norm, uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
+  extern __shared__ uint32_t lds[];               // [nr] x^(2(j+1)), then [64] partial sums
+  uint32_t *x2s = lds, *part = lds + (size_t)D.nr * 8;
+  const uint32_t b = blockIdx.x, l = threadIdx.x;
+  const uint32_t *c = ch + (size_t)b * 56;
+  const fe q = fe_load(c), x = fe_load(c + 8), r = fe_load(c + 16), t = fe_load(c + 48);
+  fe q0 = fe_sqr<1>(q);
+  if (D.flavour) q0 = fe_neg<1>(q0);
+  const fe q0i = fe_modinv<1>(q0);               // every lane the same division steps: no divergence, one pass
+  const fe xx = fe_sqr<1>(x);
+  auto powu = [](fe base, uint32_t e) { fe acc = fe_one(); while (e) { if (e & 1u) acc = fe_mul<1>(acc, base); base = fe_sqr<1>(base); e >>= 1; } return acc; };
+  {
+    fe xj = powu(xx, l + 1);
+    const fe step = powu(xx, 64);
+    for (uint32_t j = l; j < D.nr; j += 64) { for (int k = 0; k < 8; k++) x2s[j * 8 + k] = xj.v[k]; xj = fe_mul<1>(xj, step); }
+  }
+  __syncthreads();
+  auto x2 = [&](uint32_t j) { fe v; for (int k = 0; k < 8; k++) v.v[k] = x2s[j * 8 + k]; return v; };
+  fe half = fe_zero();                            // (n + 1) / 2
+  { const fe n = fr_modulus(); uint32_t carry = 1; fe tt;
+    for (int i = 0; i < 8; i++) { const uint64_t s_ = (uint64_t)n.v[i] + carry; tt.v[i] = (uint32_t)s_; carry = (uint32_t)(s_ >> 32); }
+    for (int i = 0; i < 8; i++) half.v[i] = (tt.v[i] >> 1) | (i < 7 ? tt.v[i + 1] << 31 : carry << 31); }
+  fe acc = fe_zero();
+  {
+    fe qp = powu(q0, l + 1), qi = powu(q0i, l + 1);
+    const fe qs = powu(q0, 64), qis = powu(q0i, 64);
+    for (uint32_t i = l; i < D.nlen; i += 64) {
+      fe p = fe_zero();
+      if (i < D.nlive) {
+        p = fe_sub<1>(fe_mul<1>(fe_mul<1>(x2(pos_range[i]), fe_load(pos_coeff + (size_t)i * 8)), qi), half);
+        acc = fe_add<1>(acc, fe_mul<1>(qp, fe_sqr<1>(p)));
+        p = fe_mul<1>(t, p);
+      }
+      fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
+      qp = fe_mul<1>(qp, qs); qi = fe_mul<1>(qi, qis);
+    }
+  }
+  // z = -2 (net' + sum_j min_j x^(2(j+1)))  (assumed ranges contribute no minimum, :91)
+  fe z = fe_zero();
+  for (uint32_t j = l; j < D.nr; j += 64)
+    if (!(range_flags[j] & 2u)) z = fe_add<1>(z, fe_mul<1>(fe_load(range_min + (size_t)j * 8), x2(j)));
+  if (l == 0 && D.conserve) z = fe_sub<1>(z, fe_mul<1>(x, fe_load(net_public)));
+  acc = fe_sub<1>(acc, fe_dbl<1>(z));
+  for (int k = 0; k < 8; k++) part[l * 8 + k] = acc.v[k];
+  __syncthreads();
+  for (int d = 32; d >= 1; d >>= 1) {
+    if ((int)l < d) {
+      fe a, o;
+      for (int k = 0; k < 8; k++) { a.v[k] = part[l * 8 + k]; o.v[k] = part[(l + d) * 8 + k]; }
+      a = fe_add<1>(a, o);
+      for (int k = 0; k < 8; k++) part[l * 8 + k] = a.v[k];
+    }
+    __syncthreads();
+  }
+  const fe t2 = fe_sqr<1>(t);
+  if (l == 0) {
+    fe sc; for (int k = 0; k < 8; k++) sc.v[k] = part[k];
+    fe_store(out_sp + (size_t)b * 8, fe_mul<1>(t2, sc));
+    fe_store(out_q + (size_t)b * 8, q);
+    fe_store(out_cs + (size_t)b * 16, fe_zero());
+    fe_store(out_cs + (size_t)b * 16 + 8, fe_mul<1>(r, t));
+    fe_store(out_init + (size_t)b * (2 + D.nr) * 8, fe_one());
+    fe_store(out_init + ((size_t)b * (2 + D.nr) + 1) * 8, t);
+  }
+  const fe two_t2 = fe_dbl<1>(t2);
+  for (uint32_t j = l; j < D.nr; j += 64) {
+    const uint32_t fl = range_flags[j];            // bit 0: output, bit 1: assumed
+    fe ic = (fl & 2u) ? fe_zero() : x2(j);
+    if (D.conserve) ic = (fl & 1u) ? fe_sub<1>(ic, x) : fe_add<1>(ic, x);
+    fe_store(out_init + ((size_t)b * (2 + D.nr) + 2 + j) * 8, fe_mul<1>(two_t2, ic));
+  }
 }
 
 }  // namespace bppp
@@ -277,10 +363,15 @@ int rp_build_plan(bppp_rp *rp) {
     return true;
   };
   bool ok = true;
-  for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 2 + nr, 2 * k + 2, n - 1);          // e, x, r0
-  for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 3 + nr, 2 * k + 1, 3 + n - 1);      // q, x', r1
-  ok &= add(1, 4 + nr, 2 * k, 6);                                                    // t
-  for (uint32_t j = 1; j <= k; j++) ok &= add(1, 4 + nr + 2 * j, 2 * (k - j), 7 + (k - j));   // round j: es is LAST round first
+  if (rp->st.kind == 0) {
+    for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 2 + nr, 2 * k + 2, n - 1);          // e, x, r0
+    for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 3 + nr, 2 * k + 1, 3 + n - 1);      // q, x', r1
+    ok &= add(1, 4 + nr, 2 * k, 6);                                                    // t
+  } else {                                     // RangeProof.Binary: oracle' (dCom : nComs) (Binary.hs:179, :209), then oracle [blCom] (:189, :213)
+    for (uint32_t n = 1; n <= 3; n++) ok &= add(n, 1 + nr, 2 * k + 1, n - 1);          // q, x, r  -> ch slots 0, 1, 2
+    ok &= add(1, 2 + nr, 2 * k, 6);                                                    // t        -> ch slot 6 (where k_rp_rho reads it)
+  }
+  for (uint32_t j = 1; j <= k; j++) ok &= add(1, rp->D.nrp + nr + 2 * j, 2 * (k - j), 7 + (k - j));   // round j: es is LAST round first
   if (!ok) return fail(rp->ctx, BPPP_ERR_ARG, "rp_create: oracle tag too long");
   rp->nhash = (uint32_t)plan.size();
   BPPP_HIP(rp->ctx, hipMalloc(&rp->d_plan, plan.size() * sizeof(HashPlan)));
@@ -291,6 +382,53 @@ int rp_build_plan(bppp_rp *rp) {
 }  // namespace
 
 extern "C" void bppp_basis_destroy(bppp_basis *basis);
+
+// device tables of a RangeProof.Binary setup (k_brp_public)
+struct bppp_brp_tabs {
+  uint32_t *pos_range = nullptr, *pos_coeff = nullptr, *range_min = nullptr, *range_flags = nullptr, *net_public = nullptr;
+  BrpDims D{};
+};
+static void brp_tabs_destroy(bppp_brp_tabs *t) {
+  if (!t) return;
+  for (uint32_t *p : {t->pos_range, t->pos_coeff, t->range_min, t->range_flags, t->net_public}) if (p) hipFree(p);
+  delete t;
+}
+static int brp_build_tables(bppp_rp *rp) {
+  const bppp_rps::Setup &st = rp->st;
+  bppp_ctx *ctx = rp->ctx;
+  bppp_brp_tabs *t = new bppp_brp_tabs();
+  rp->btabs = t;
+  t->D = BrpDims{(uint32_t)st.nlen, (uint32_t)st.nlive, (uint32_t)st.rds.size(), st.conserve ? 1u : 0u, st.flavour ? 1u : 0u};
+  std::vector<uint32_t> pr, fl;
+  std::vector<uint64_t> pc, mins;
+  for (const bppp_rps::Pos &p : st.pos) { pr.push_back(p.range); for (int i = 0; i < 4; i++) pc.push_back(p.coeff.w[i]); }
+  for (const bppp_rps::RangeData &rd : st.rds) {
+    fl.push_back((rd.output ? 1u : 0u) | (rd.assumed ? 2u : 0u));
+    const U256 m = bppp_rps::s_mod_n(rd.lo);
+    for (int i = 0; i < 4; i++) mins.push_back(m.w[i]);
+  }
+  if (pr.empty()) { pr.push_back(0); pc.assign(4, 0); }
+  auto up = [&](uint32_t **dst, const void *src, size_t bytes) -> int {
+    BPPP_HIP(ctx, hipMalloc(dst, bytes));
+    BPPP_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return BPPP_OK;
+  };
+  int rc;
+  if ((rc = up(&t->pos_range, pr.data(), pr.size() * 4)) || (rc = up(&t->pos_coeff, pc.data(), pc.size() * 8)) || (rc = up(&t->range_min, mins.data(), mins.size() * 8)) ||
+      (rc = up(&t->range_flags, fl.data(), fl.size() * 4)) || (rc = up(&t->net_public, st.net_public.w, 32)))
+    return rc;
+  return BPPP_OK;
+}
+static int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint32_t *q, uint32_t *sp, uint32_t *pub_norm, uint32_t *pub_lin_c, uint32_t *init_sc) {
+  bppp_ctx *ctx = rp->ctx;
+  const bppp_brp_tabs *t = rp->btabs;
+  const size_t lds = ((size_t)t->D.nr + 64) * 32;
+  if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_brp_public, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_brp_public<<<dim3((unsigned)batch), dim3(64), lds, ctx->stream>>>(t->D, (uint32_t)batch, t->pos_range, t->pos_coeff, t->range_min, t->range_flags, t->net_public, ch, q, sp,
+                                                                     pub_norm, pub_lin_c, init_sc);
+  BPPP_HIP(ctx, hipGetLastError());
+  return BPPP_OK;
+}
 
 void RpOptions::from_env() {
   auto num = [](const char *name, size_t &dst) { if (const char *e = getenv(name)) dst = (size_t)atol(e); };
@@ -311,6 +449,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (rp->tabs) bppp_trrp_destroy(rp->tabs);
+  brp_tabs_destroy(rp->btabs);
   if (rp->d_basis) hipFree(rp->d_basis);
   if (rp->d_plan) hipFree(rp->d_plan);
   if (rp->work) hipFree(rp->work);
@@ -371,7 +510,7 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16, rp->h_H.data(), st.llen * 64, hipMemcpyHostToDevice));
     BPPP_HIP(ctx, hipMemcpy(rp->d_basis + 16 * (1 + st.llen), rp->h_G.data(), st.nlen * 64, hipMemcpyHostToDevice));
     RpDims &D = rp->D;
-    D.nr = (uint32_t)st.rds.size(); D.k = (uint32_t)st.rounds; D.fn = (uint32_t)st.fn; D.fl = (uint32_t)st.fl;
+    D.nr = (uint32_t)st.rds.size(); D.k = (uint32_t)st.rounds; D.fn = (uint32_t)st.fn; D.fl = (uint32_t)st.fl; D.nrp = 4; D.nch = 7;
     D.coms_bytes = (D.nr + 7) / 8 + 32 * D.nr;
     const uint32_t npp = 4 + 2 * D.k;
     D.proof_bytes = 32 * (D.fn + D.fl) + (npp + 7) / 8 + 32 * npp;
@@ -463,7 +602,53 @@ int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out) {
   const bppp_rps::Setup &st = rp->st;
   out->nranges = st.rds.size(); out->norm_len = st.nlen; out->lin_len = st.llen; out->rounds = st.rounds;
   out->final_norm = st.fn; out->final_lin = st.fl; out->coms_bytes = rp->D.coms_bytes; out->proof_bytes = rp->D.proof_bytes;
-  out->challenges_per_proof = 7 + st.rounds;
+  out->challenges_per_proof = rp->D.nch + st.rounds;
+  return BPPP_OK;
+}
+
+// RangeProof.Binary behind the same handle: setupBRP (src/RangeProof/Binary.hs:143-156).  points = [h, g, h0, h1] ++ gs (:147-148)
+int bppp_rp_create_binary(bppp_ctx *ctx, int flavour, int conserve, const bppp_rp_range *ranges, size_t nranges, const uint64_t net_public[4],
+                          const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out) {
+  if (!ctx || !out || ctx_closed(ctx)) return BPPP_ERR_ARG;
+  *out = nullptr;
+  if (!ranges || !nranges || !net_public || !points_xy) return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: null argument");
+  if (flavour != 0 && flavour != 1) return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: flavour must be 0 (norm-linear argument) or 1 (inner-product argument)");
+  if (nranges > 1024) return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: at most 1024 ranges");
+  std::vector<bppp_rps::RangeData> rds(nranges);
+  std::string err;
+  for (size_t i = 0; i < nranges; i++) {
+    const bppp_rp_range &r = ranges[i];
+    if (r.base != 2 || (r.flags & BPPP_RP_SHARED)) return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: range " + std::to_string(i) + ": base must be 2 and digits are not shared (app/Parse.hs:141-146)");
+    if (!bppp_rps::make_range_data_binary(U256::load(r.min), U256::load(r.max), (r.flags & BPPP_RP_OUTPUT) != 0, (r.flags & BPPP_RP_ASSUMED) != 0, rds[i], err))
+      return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: range " + std::to_string(i) + ": " + err);
+  }
+  bppp_rp *rp = new bppp_rp();
+  rp->ctx = ctx; ctx_retain(ctx);
+  rp->opt.from_env();
+  auto fill = [&]() -> int {
+    if (!bppp_rps::make_setup_binary(conserve != 0, rds, bppp_rps::s_mod_n(U256::load(net_public)), flavour, rp->st, err)) return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: " + err);
+    const bppp_rps::Setup &st = rp->st;
+    if (npoints < 4 + st.nlen) return fail(ctx, BPPP_ERR_ARG, "rp_create_binary: not enough basis points (need 4 + nrmLen)");
+    if (!bppp_host::points_on_curve(points_xy, 4 + st.nlen)) return fail(ctx, BPPP_ERR_POINT, "rp_create_binary: a basis point is not on the curve");
+    rp->h_g.assign(points_xy + 8, points_xy + 16);
+    rp->h_H.assign(points_xy + 16, points_xy + 32);
+    rp->h_G.assign(points_xy + 32, points_xy + 32 + 8 * st.nlen);
+    rp->tag = oracle_tag ? oracle_tag : "";
+    hipSetDevice(ctx->device);
+    BPPP_HIP(ctx, hipMalloc(&rp->d_basis, (3 + st.nlen) * 64));
+    BPPP_HIP(ctx, hipHostMalloc((void **)&rp->hflag, 64, hipHostMallocDefault));
+    BPPP_HIP(ctx, hipMemcpy(rp->d_basis, points_xy + 8, (3 + st.nlen) * 64, hipMemcpyHostToDevice));      // [g | h0 h1 | G]: commitRPW's term order
+    RpDims &D = rp->D;
+    D.nr = (uint32_t)st.rds.size(); D.k = (uint32_t)st.rounds; D.fn = (uint32_t)st.fn; D.fl = (uint32_t)st.fl; D.nrp = 2; D.nch = 4;
+    D.coms_bytes = (D.nr + 7) / 8 + 32 * D.nr;
+    const uint32_t npp = 2 + 2 * D.k;
+    D.proof_bytes = 32 * (D.fn + D.fl) + (npp + 7) / 8 + 32 * npp;
+    D.text_stride = ((rp_npts(D) * 2 * 78 + 15) & ~15u) + 16;
+    int rc = brp_build_tables(rp); if (rc) return rc;
+    return rp_build_plan(rp);
+  };
+  if (int rc = fill()) { bppp_rp_destroy(rp); return rc; }
+  *out = rp;
   return BPPP_OK;
 }
 
@@ -533,7 +718,7 @@ U256 host_digest_to_fr(const uint32_t h[8]) {
 // init [4 + nr][8], resp [2k][8] (u64 limbs as downloaded); ch_out [7][4], es_out [k][4]  (the weight rho_b is k_rp_rho's on both routes)
 // part 0: the seven challenges of verifyTRRPM; part 1: the k round challenges of verifyBPM
 void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, uint64_t *ch_out, uint64_t *es_out, int part) {
-  const uint32_t k = rp->D.k, nr = rp->D.nr, npts = 2 * k + 4 + nr;
+  const uint32_t k = rp->D.k, nr = rp->D.nr, nrp = rp->D.nrp, npts = 2 * k + nrp + nr;
   std::vector<std::string> txt(npts);
   for (uint32_t t = 0; t < npts; t++) {
     const uint64_t *p = t < 2 * k ? resp + (size_t)t * 8 : init + (size_t)(t - 2 * k) * 8;
@@ -548,12 +733,15 @@ void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_
     h.finish(d);
     host_digest_to_fr(d).store(out);
   };
-  if (part == 0) {
+  if (part == 0 && rp->st.kind == 0) {
     for (uint32_t n = 1; n <= 3; n++) one(n, 2 + nr, 2 * k + 2, ch_out + 4 * (n - 1));          // e, x, r0        (the order of rp_build_plan)
     for (uint32_t n = 1; n <= 3; n++) one(n, 3 + nr, 2 * k + 1, ch_out + 4 * (3 + n - 1));      // q, x', r1
     one(1, 4 + nr, 2 * k, ch_out + 4 * 6);                                                      // t
+  } else if (part == 0) {
+    for (uint32_t n = 1; n <= 3; n++) one(n, 1 + nr, 2 * k + 1, ch_out + 4 * (n - 1));          // Binary: q, x, r
+    one(1, 2 + nr, 2 * k, ch_out + 4 * 6);                                                      // t
   } else {
-    for (uint32_t j = 1; j <= k; j++) one(1, 4 + nr + 2 * j, 2 * (k - j), es_out + 4 * (k - j));   // round j: es is LAST round first
+    for (uint32_t j = 1; j <= k; j++) one(1, nrp + nr + 2 * j, 2 * (k - j), es_out + 4 * (k - j));   // round j: es is LAST round first
   }
 }
 }  // namespace
@@ -577,7 +765,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
   hipStream_t st = ctx->stream;
   const bppp_rps::Setup &S = rp->st;
   const RpDims D = rp->D;
-  const size_t B = batch, nlen = S.nlen, llen = S.llen, k = S.rounds, ninit = 4 + D.nr, npts = rp_npts(D);
+  const size_t B = batch, nlen = S.nlen, llen = S.llen, k = S.rounds, ninit = D.nrp + D.nr, npts = rp_npts(D);
   size_t need = 0;
   uint32_t *init_pts = nullptr, *resp_pts = nullptr, *wit_norm = nullptr, *wit_lin = nullptr, *text_off = nullptr, *ch = nullptr, *es = nullptr, *rho = nullptr,
            *q = nullptr, *sp = nullptr, *pub_norm = nullptr, *pub_lin_c = nullptr, *pub_lin_x = nullptr, *init_sc = nullptr, *bad = nullptr;
@@ -622,7 +810,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     };
     all(0);
     BPPP_HIP(ctx, hipMemcpyAsync(ch, hch.data(), B * 7 * 32, hipMemcpyHostToDevice, st));
-    int rc0 = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
+    int rc0 = S.kind ? brp_public_device(rp, B, ch, q, sp, pub_norm, pub_lin_c, init_sc) : bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
     if (rc0) return rc0;
     all(1);
     if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes.data(), B * k * 32, hipMemcpyHostToDevice, st));
@@ -633,7 +821,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     // batch leaves SIMDs idle (<= 1024 proofs: 256 proofs 1.65 -> 1.38 ms of kernels); at 4096 proofs the three kernels already
     // fill the VALU and running them side by side only stretches each (hash 0.65 -> 0.55 + 0.87, scalars 0.84 -> 1.04 ms: measured, not kept)
     k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
-    const uint32_t nch = 7, nes = rp->nhash - 7;
+    const uint32_t nch = D.nch, nes = rp->nhash - D.nch;
     hipStream_t aux = st;
     const bool fork = nes && B <= 1024;
     if (fork) {
@@ -649,7 +837,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
       BPPP_HIP(ctx, hipEventRecord(ctx->aux_join, aux));
     }
     BPPP_HIP(ctx, hipGetLastError());
-    int rc0 = bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
+    int rc0 = S.kind ? brp_public_device(rp, B, ch, q, sp, pub_norm, pub_lin_c, init_sc) : bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
     if (fork) BPPP_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));      // (joined even when the launch above failed: the second stream must not outlive the call's buffers)
     if (rc0) { hipStreamSynchronize(st); return rc0; }
   }
@@ -669,9 +857,14 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
   std::vector<uint32_t> hbad(proof_status ? B : 0);
   StreamDrain drain{st};
   if (proof_status) BPPP_HIP(ctx, hipMemcpyAsync(hbad.data(), bad, B * 4, hipMemcpyDeviceToHost, st));
-  if (challenges_out) {
-    BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out, (7 + k) * 32, ch, 7 * 32, 7 * 32, B, hipMemcpyDeviceToHost, st));
-    if (k) BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out + 28, (7 + k) * 32, es, k * 32, k * 32, B, hipMemcpyDeviceToHost, st));
+  if (challenges_out) {                        // [batch][nch + k]: the range-proof layer's challenges (Binary: q, x, r from slots 0-2, t from slot 6), then the rounds'
+    const size_t nch = D.nch, row = (nch + k) * 32;
+    if (S.kind == 0) BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out, row, ch, 7 * 32, 7 * 32, B, hipMemcpyDeviceToHost, st));
+    else {
+      BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out, row, ch, 7 * 32, 3 * 32, B, hipMemcpyDeviceToHost, st));
+      BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out + 12, row, ch + 6 * 8, 7 * 32, 32, B, hipMemcpyDeviceToHost, st));
+    }
+    if (k) BPPP_HIP(ctx, hipMemcpy2DAsync(challenges_out + 4 * nch, row, es, k * 32, k * 32, B, hipMemcpyDeviceToHost, st));
   }
   if (proof_status || challenges_out) BPPP_HIP(ctx, hipStreamSynchronize(st));
   auto is_inf = [](const uint64_t *p) { uint64_t o = 0; for (int i = 0; i < 8; i++) o |= p[i]; return o == 0; };

@@ -16,10 +16,12 @@ namespace bppp {
 
 struct RpDims {
   uint32_t nr, k, fn, fl;            // ranges (input commitments), rounds, final witness lengths
+  uint32_t nrp, nch;                 // range-proof commitments ahead of the inputs (4: blCom rCom dmCom mCom; Binary 2: blCom dCom) and
+                                     // oracle outputs before the argument's rounds (7: e x r0 q x' r1 t; Binary 4: q x r t)
   uint32_t coms_bytes, proof_bytes;  // per-proof file sizes
   uint32_t text_stride;              // bytes reserved per proof for the transcript text (multiple of 16)
 };
-__host__ __device__ inline uint32_t rp_npts(const RpDims &D) { return 4 + D.nr + 2 * D.k; }
+__host__ __device__ inline uint32_t rp_npts(const RpDims &D) { return D.nrp + D.nr + 2 * D.k; }
 
 static constexpr int RP_HDR_MAX = 64;
 struct HashPlan { uint32_t hdr_be[RP_HDR_MAX / 4]; uint32_t hlen, start_pt, out_slot; };   // header as big-endian words, zero-padded
@@ -76,9 +78,11 @@ struct RpOptions {
   bool timing = false;                // BPPP_RP_TIMING: phase times on stderr
   void from_env();
 };
+struct bppp_brp_tabs;      // csrc/rp.hip: device tables of a RangeProof.Binary setup
 struct bppp_rp {
   bppp_ctx *ctx = nullptr;
   RpOptions opt;
+  bppp_brp_tabs *btabs = nullptr;
   bppp_rps::Setup st;
   bppp_trrp *tabs = nullptr;
   std::string tag;

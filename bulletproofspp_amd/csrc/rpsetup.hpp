@@ -182,6 +182,10 @@ struct PublicVT { bool is_output; U256 type, amount; };   // (isOutput, type, am
 
 struct Setup {
   int flavour = 0;                      // 0 = Bulletproof.NormArgument (NL), 1 = Bulletproof.InnerProductArgument (IP)
+  int kind = 0;                         // 0 = RangeProof.TypedReciprocal, 1 = RangeProof.Binary (make_setup_binary below)
+  bool conserve = false;                // Binary: the amounts (and the net public amount) must balance (Binary.hs:137)
+  U256 net_public;                      // Binary: netPublic as an element of the scalar field
+  size_t nlive = 0;                     // Binary: norm positions of the ranges that are not assumed (the rest of nlen stays zero)
   bool has_types = false;
   std::vector<RangeData> rds;
   std::vector<PublicVT> pubs;
@@ -247,6 +251,58 @@ inline bool make_setup(bool has_types, const std::vector<RangeData> &rds, const 
   if (st.pos.size() != st.nlen) { err = "an inline range has more reciprocal symbols than digits (base - 1 > number of digits): unsupported layout"; return false; }
   for (const Pos &p : st.pos)
     if ((p.kind & 0xFFu) != POS_TYPING && st.slot_of(p.radix) < 0) { err = "internal: digit base missing from the base map"; return false; }
+  return true;
+}
+
+// ---- RangeProof.Binary (src/RangeProof/Binary.hs)
+// makeRangeData (:48-54): coefficients b_n : 2^(n1-1) ... 1 with n1 = integerLog 2 (max - min - 1), b_n = (max - min) - 2^n1
+inline bool make_range_data_binary(const U256 &lo, const U256 &hi, bool output, bool assumed, RangeData &out, std::string &err) {
+  if (!s_lt(lo, hi)) { err = "invalid range (need max > min)"; return false; }
+  const U256 w = u_sub(hi, lo);
+  if (bppp_host::cmp(w, bppp_host::FR().m) >= 0) { err = "range wider than the scalar field"; return false; }
+  const int n1 = integer_log(2, u_sub(w, U256::one()));
+  U256 p2 = U256::one();
+  for (int i = 0; i < n1; i++) p2 = u_add(p2, p2);                    // 2^n1 <= w - 1
+  out = RangeData();
+  out.base = 2; out.lo = lo; out.hi = hi; out.output = output; out.assumed = assumed;
+  out.coeffs.push_back(u_sub(w, p2));
+  for (int i = 1; i <= n1; i++) { U256 c = U256::one(); for (int k = 0; k < n1 - i; k++) c = u_add(c, c); out.coeffs.push_back(c); }
+  return true;
+}
+// makeDigits (:56-69): the top digit takes b_n, the rest are the n1 bits of what is left.  The reference takes the top coefficient only
+// when nAdj > b_n; for a power-of-two width (b_n = 2^n1) and nAdj = b_n its low part would need n1 + 1 bits — that one value takes the
+// top digit here (the deviation bulletproofspp_amd/rangeproof_binary.py documents).  n = the value minus the range minimum.
+inline void digits_binary_into(const RangeData &rd, const U256 &n, std::vector<uint32_t> &out) {
+  out.clear();
+  if (rd.assumed) return;
+  const int n1 = (int)rd.coeffs.size() - 1;
+  const U256 &bn = rd.coeffs[0];
+  bool over = false;                                                   // n >> n1 != 0
+  for (int b = n1; b < 256; b++) over |= n.bit(b);
+  const bool top = u_lt(bn, n) || over;
+  const U256 rest = top ? u_sub(n, bn) : n;
+  out.push_back(top ? 1u : 0u);
+  for (int i = 0; i < n1; i++) out.push_back(rest.bit(n1 - 1 - i) ? 1u : 0u);
+}
+
+// setupBRP (:143-156): nrmLen = sum of ALL ranges' coefficient counts (assumed ones included: their positions stay zero), linLen = 2
+// (the blinding generators h0, h1), rounds = optimalWitnessSize nrmLen 2 on both sides (the reference's prover uses integerLog 2 nrmLen - 1,
+// which agrees wherever its own proofs verify: SURVEY.md App. D-1).  `pos` holds one record per LIVE position, in order.
+inline bool make_setup_binary(bool conserve, const std::vector<RangeData> &rds, const U256 &net_public_mod_n, int flavour, Setup &st, std::string &err) {
+  st = Setup();
+  st.kind = 1; st.flavour = flavour; st.conserve = conserve; st.net_public = net_public_mod_n; st.rds = rds;
+  st.nlen = 0; st.llen = 2;
+  st.first_pos.assign(rds.size(), 0);
+  for (size_t i = 0; i < rds.size(); i++) {
+    st.nlen += rds[i].coeffs.size();
+    st.first_pos[i] = st.pos.size();
+    if (rds[i].assumed) continue;
+    for (size_t j = 0; j < rds[i].coeffs.size(); j++) st.pos.push_back(Pos{POS_SHARED, (uint32_t)i, 2u, (uint32_t)j, u_mod_n(rds[i].coeffs[j]), 0});
+  }
+  st.nlive = st.pos.size();
+  if (!st.nlen) { err = "empty norm vector"; return false; }
+  if (flavour) optimal_witness_size_ip(st.nlen, st.llen, st.rounds, st.fn, st.fl);
+  else optimal_witness_size_nl(st.nlen, st.llen, st.rounds, st.fn, st.fl);
   return true;
 }
 

@@ -951,7 +951,8 @@ class NativeRangeProofs:
         chs = None
         if want_challenges:
             flat = array_to_scalars(chal)
-            chs = [(flat[b * nch:b * nch + 7], flat[b * nch + 7:(b + 1) * nch]) for b in range(B)]
+            lead = nch - self.shape["rounds"]               # 7 range-proof challenges (typed reciprocal) or 4 (binary), then one per round
+            chs = [(flat[b * nch:b * nch + lead], flat[b * nch + lead:(b + 1) * nch]) for b in range(B)]
         return bool(acc.value), ([int(v) for v in status[:B]] if want_status else None), chs
 
 

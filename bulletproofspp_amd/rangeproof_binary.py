@@ -21,7 +21,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
-from .rangeproof import (N, RPW, Backend, OracleN, Point, RandFn, RangeProof, SetupBP, Transcript, integer_log, inv, optimal_witness_size, powers1)
+from .rangeproof import (N, RPW, Backend, NativeRangeProofs, OracleN, Point, RandFn, RangeProof, SetupBP, Transcript, integer_log, inv, optimal_witness_size,
+                         powers1)
 
 
 @dataclass
@@ -187,6 +188,57 @@ def verify(st: SetupBRP, proof: RangeProof, oracle: OracleN) -> bool:
     pad = lambda xs, n: list(xs) + [0] * (n - len(xs))
     return st.backend.verify_bp(st.flavour, sbp.q, sbp.pub.sc, st.g, pad(sbp.pub.nrm, st.nrm_len), st.gs, sbp.cs, [0, 0], st.hs, es, list(proof.responses),
                                 list(proof.wit_nrm), list(proof.wit_lin), sbp.init_terms)
+
+
+def verifier_challenges(st: SetupBRP, proof: RangeProof, oracle: OracleN) -> Optional[Tuple[List[int], List[int]]]:
+    """the oracle calls of verifyBRPM (Binary.hs:209, :213) and of verifyBPM (Bulletproof.hs:374): ((q, x, r, t), [e_k ... e_1])"""
+    if len(proof.responses) != st.rounds or (len(proof.wit_nrm), len(proof.wit_lin)) != st.final_lens or len(proof.coms) != 2 + len(st.rds):
+        return None
+    tr = Transcript(oracle)
+    q, x, r = tr.oracle([proof.coms[1]] + list(proof.coms[2:]), 3)
+    t = tr.oracle([proof.coms[0]], 1)[0]
+    es: List[int] = []
+    for a, b in reversed(proof.responses):
+        es.insert(0, tr.oracle([a, b], 1)[0])
+    return [q, x, r, t], es
+
+
+class NativeBinaryRangeProofs(NativeRangeProofs):
+    """One RangeProof.Binary setup registered with the library (bppp_rp_create_binary): the same handle type and entry points as the typed
+    reciprocal proofs — verify_batch* decode the reference's files, hash every transcript and decide the batch with one MSM
+    (verifyBRPM + verifyBPM); prove_batch is proveBRPM + proveBPM in lockstep (norm-linear argument)."""
+
+    def __init__(self, gpu, st: SetupBRP, oracle_tag: bytes = b"", h: Point = None):
+        import ctypes as C
+        from .capi import RP_ASSUMED, RP_OUTPUT, RpRange, RpShape, int_to_limbs, points_to_array
+        self.gpu, self.st, self.h = gpu, st, None
+        rng = (RpRange * len(st.rds))()
+        for r, rd in zip(rng, st.rds):
+            r.base = 2
+            r.flags = (RP_OUTPUT if rd.is_output else 0) | (RP_ASSUMED if rd.is_assumed else 0)
+            r.min[:] = [int(v) for v in int_to_limbs(rd.lo % 2**256)]
+            r.max[:] = [int(v) for v in int_to_limbs(rd.hi % 2**256)]
+        pts = points_to_array([h if h is not None else st.g, st.g] + list(st.hs) + list(st.gs))
+        net = int_to_limbs(st.net_public % 2**256)
+        hnd = C.c_void_p()
+        rc = gpu.lib.bppp_rp_create_binary(gpu.h, 0 if st.flavour == "NL" else 1, int(st.conserve), C.cast(rng, C.c_void_p), len(st.rds), C.c_void_p(net.ctypes.data),
+                                           C.c_void_p(pts.ctypes.data), pts.shape[0], oracle_tag if oracle_tag else None, C.byref(hnd))
+        gpu._check(rc, "bppp_rp_create_binary")
+        self.h = hnd
+        gpu._adopt(self)
+        shp = RpShape()
+        gpu._check(gpu.lib.bppp_rp_info(self.h, C.byref(shp)), "bppp_rp_info")
+        self.shape = {n: int(getattr(shp, n)) for n, _ in RpShape._fields_}
+        if (self.shape["norm_len"], self.shape["lin_len"], self.shape["rounds"], (self.shape["final_norm"], self.shape["final_lin"])) != \
+                (st.nrm_len, 2, st.rounds, tuple(st.final_lens)):
+            raise RuntimeError("native binary setup disagrees with the host setup: %r" % (self.shape,))
+
+    def prove_batch(self, inputs: Sequence[Sequence[Tuple[int, int]]], rand_prefixes: Sequence[bytes]) -> List[Tuple[bytes, bytes]]:
+        """bppp_rp_prove_batch on a binary setup: inputs[b] = [(amount, blinding) per range]"""
+        return super().prove_batch([[(v, 0, bl) for v, bl in row] for row in inputs], rand_prefixes)
+
+    def split_challenges(self, flat: Sequence[int]):
+        return list(flat[:4]), list(flat[4:])
 
 
 def setup_from_schema(backend: Backend, schema: dict, points: Optional[Sequence[Point]] = None) -> SetupBRP:

@@ -351,6 +351,17 @@ typedef struct bppp_rp_shape {
 typedef struct bppp_rp bppp_rp;
 int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_range *ranges, size_t nranges, const bppp_rp_public *pubs, size_t npub,
                    const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out);
+/* RangeProof.Binary (src/RangeProof/Binary.hs) behind the same handle: setupBRP (:143-156).  `ranges`: base must be 2 and SHARED must not
+ * be set (app/Parse.hs:141-146 refuses both); `conserve` = the schema's "conserved" (inputs, outputs and `net_public` — the net public
+ * amount, inputs minus outputs, a plain integer in two's complement — must balance: witnessBRP :158-166 yields a witness only then);
+ * `points_xy` = [h, g, h0, h1] ++ gs, at least 4 + nrmLen points (:147-148).  Every entry point that takes a bppp_rp then serves the
+ * binary protocol: bppp_rp_info (lin_len = 2; proof file = final witness scalars, then blCom, dCom and the responses;
+ * challenges_per_proof = 4 + rounds: q, x, r, t), bppp_rp_verify_batch* / _shard_device (verifyBRPM :206-222 with its two oracle
+ * calls, then verifyBPM) and bppp_rp_prove_batch (proveBRPM :169-204 + proveBPM in lockstep; `types` is ignored, a binary proof is
+ * untyped).  Both sides take the round count from optimalWitnessSize (the reference's prover uses integerLog 2 nrmLen - 1, which
+ * agrees wherever its own proofs verify — SURVEY.md App. D-1). */
+int bppp_rp_create_binary(bppp_ctx *ctx, int flavour, int conserve, const bppp_rp_range *ranges, size_t nranges, const uint64_t net_public[4],
+                          const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out);
 void bppp_rp_destroy(bppp_rp *rp);
 int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out);
 /* Tuning knobs of one handle.  Every knob has a measured default; the BPPP_RP_* environment variables of the
