@@ -330,6 +330,11 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
               "scope": "verifyM of RangeProof END TO END (src/RangeProof.hs:99-105) from the encoded files resident in HBM: decodeProof (square roots, "
                        "signs), every SHA-256 transcript hash of verifyTRRPM / verifyBPM (shaOracle, app/Main.hs:64-80), public scalars, challenge "
                        "expansion, shared-basis merge, ONE combined MSM — all on the GPU, all timed (bppp_rp_verify_batch_device)",
+              "roofline": {"bound": "hbm", "kernel": "whole call (decode, text, SHA-256, public scalars, expansion, combined MSM: profiles/r03_bench_default_kernel_stats.csv)",
+                           "achieved": world * batch * steps * bytes_per_proof / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                           "frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                           "note": "algorithmic %d B per proof (SURVEY.md 8d) x proofs / call time; every stage is VALU- or latency-bound (256-bit field "
+                                   "arithmetic, SHA-256), none HBM-bound" % bytes_per_proof},
               "concurrent": concurrent,
               "host_buffer_call": {"entry": "bppp_rp_verify_batch (files in pageable host memory, %d B per proof over PCIe)" % file_bytes,
                                    "ms_per_batch": hdt * 1e3, "value": batch / hdt, "unit": "verifies/s"}}
@@ -737,8 +742,28 @@ def main():
         dtb = timed(lambda: gpu._check(gpu.lib.bppp_msm_basis(basb.h, vpp(dscb.data_ptr()), nb, inst, vpp(outs_b[2].ctypes.data)), "bppp_msm_basis"))
         assert np.array_equal(outs_b[2], outs_b[0])
         legs["registered_basis_comb"] = {"ms": dtb * 1e3, "pairs_per_s": nb * inst / dtb, "window_bits": cwb, "table_bytes": ctb, "table_build_ms": comb_build * 1e3}
+        # the prover's dominant kernel (k_comb_msm: 63 of 78 kernel-ms per 4096 proofs) on the prover's shape, timed live above (wall clock around
+        # the call: the kernel plus the 256-KB copy of the results).  Algorithmic bytes: per term its 32-B scalar and one 64-B table row per window
+        # (ceil(257 / c) rows: the fixed-base method trades these reads for the additions it saves); HBM traffic from the PMC passes over the
+        # prove command (profiles/traffic.json, static)
+        wcomb = -(-257 // cwb)
+        comb_bytes = inst * nb * (32 + 64 * wcomb)
+        comb_traffic = None
+        try:
+            pk = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["prover_4096_proofs_64by64"]["by_kernel"]
+            ck = next(v for k_, v in pk.items() if "k_comb_msm" in k_)
+            comb_traffic = ck["fetch_bytes_per_launch_x2"] + ck["write_bytes_per_launch"]
+        except Exception:
+            pass
+        comb_roofline = {"bound": "hbm", "kernel": "k_comb_msm", "achieved": comb_bytes / dtb / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": comb_bytes / dtb / 1e9 / HBM_PEAK_GBS, "traffic": comb_traffic,
+                         "traffic_source": "static: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE over benchmarks/prove_timing.py 4096, mean over "
+                                           "the 22 k_comb_msm launches of a batch (16 round launches of 8192 x 774 terms, 6 commitment launches)",
+                         "note": "%d instances x %d terms x (32-B scalar + %d windows x 64-B table row) per launch / live duration; the kernel is VALU-bound "
+                                 "(2.4 k instructions per mixed addition; profiles/r03_pmc_prover_per_kernel.csv: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = 0.36, "
+                                 "SQ_WAIT_ANY 0.06)" % (inst, nb, wcomb)}
         basb.close()
-        fixed_batch = {"workload": f"{inst} MSMs of {nb} terms over one basis (the prover's commitments), results on the host", "routes": legs}
+        fixed_batch = {"workload": f"{inst} MSMs of {nb} terms over one basis (the prover's commitments), results on the host", "routes": legs, "roofline": comb_roofline}
         del dscb
 
     # throughput with several MSMs in flight (one context = one stream + one host thread each): the latency-bound stages of one
@@ -879,6 +904,8 @@ def main():
         if verify is not None:
             out["verify"] = verify
         if prove is not None:
+            if fixed_batch is not None:
+                prove["roofline"] = fixed_batch["roofline"]       # the prover's dominant kernel, timed live on the prover's shape in that leg
             out["prove"] = prove
         if verify_ip is not None:
             out["verify_ip"] = verify_ip

@@ -73,8 +73,10 @@ def reduced(d):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        for r in csv.DictReader(f):
-            out[r["kernel"]][r["counter"]] = (float(r["mean_per_launch"]), int(r["launches"]))
+        next(f)
+        for line in f:                                    # kernel names may hold commas (template arguments): split from the right
+            k, c, n, v = line.rstrip("\n").rsplit(",", 3)
+            out[k][c] = (float(v), int(n))
     return out
 
 
@@ -96,7 +98,7 @@ def round3(tag):
                         f.write(f"{k},{cs[counter][1]},{cs[counter][0]:.3f}\n")
         name = "bppp::k_acc_points"
         fk, wk = fe[name]["FETCH_SIZE"][0], wr[name]["WRITE_SIZE"][0]
-        per_kernel = {k: fe[k]["FETCH_SIZE"][0] * 1024 * 2 + wr[k]["WRITE_SIZE"][0] * 1024 for k in fe if k.startswith("bppp::") and k in wr}
+        per_kernel = {k: fe[k]["FETCH_SIZE"][0] * 1024 * 2 + wr[k]["WRITE_SIZE"][0] * 1024 for k in fe if "bppp::" in k and k in wr}
         traffic = {
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --headline-only, 2^20 pairs, auto window (c = 16); " + tag,
             "k_acc_points_FETCH_SIZE_KB_raw": fk, "k_acc_points_WRITE_SIZE_KB": wk,
@@ -108,7 +110,7 @@ def round3(tag):
         if pf and pw:
             prover = {}
             for k in pf:
-                if k.startswith("bppp::") and k in pw:
+                if "bppp::" in k and k in pw:
                     prover[k] = {"launches": pf[k]["FETCH_SIZE"][1], "fetch_bytes_per_launch_x2": pf[k]["FETCH_SIZE"][0] * 1024 * 2,
                                  "fetch_bytes_per_launch_raw": pf[k]["FETCH_SIZE"][0] * 1024, "write_bytes_per_launch": pw[k]["WRITE_SIZE"][0] * 1024}
                     if ps and k in ps:
