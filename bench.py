@@ -468,6 +468,33 @@ def prove_cpu_baseline(shape: str, reps: int = 2):
                       "thread; the range-proof phases before the argument (4 + #values more commits) are NOT included, which favours the baseline"}
 
 
+def launcher_selftest(args):
+    """What a rank does under --launcher-selftest: gloo rendezvous from the launcher's environment, one all-gather of (rank, shard of a
+    4096-proof job), one line from rank 0.  Exercises launch_ranks and the job-sharding arithmetic of the strong-scaling legs without a GPU."""
+    import torch
+    import torch.distributed as dist
+    from bulletproofspp_amd.dist import shard_range
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BPPP_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                                         # the launcher must report this and end the other ranks
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(4096, rank, world)
+    mine = torch.tensor([[rank, lo, hi]], dtype=torch.int64)
+    out = torch.zeros((world, 3), dtype=torch.int64)
+    if world > 1:
+        dist.all_gather_into_tensor(out, mine)
+        dist.barrier()
+    else:
+        out = mine
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "ranks": [int(v) for v in out[:, 0]], "shards": [[int(a), int(b_)] for a, b_ in out[:, 1:]]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def gpu_device(dev) -> int:
     return dev.index if getattr(dev, "index", None) is not None else 0
 
@@ -538,10 +565,15 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="only the 2^log2n MSM leg (profiling passes: one launch shape per kernel)")
     ap.add_argument("--check-combined", action="store_true", help="N > 1: rank 0 also computes the whole sharded MSM alone (all ranks' inputs regenerated "
                                                                   "from their seeds) and asserts the combined point equals it")
+    ap.add_argument("--launcher-selftest", action="store_true", help="no GPU: the ranks only rendezvous over gloo, all-gather their rank numbers and shard ranges, "
+                                                                    "and rank 0 prints them (the CPU-tier test of the plain `--gpus N` start)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))          # plain start: become the launcher BEFORE torch / HIP are touched
+
+    if args.launcher_selftest:
+        return launcher_selftest(args)
 
     import torch
     import bulletproofspp_amd as b

@@ -71,3 +71,20 @@ def test_shard_ranges_partition():
             assert rs[0][0] == 0 and rs[-1][1] == n
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def test_bench_plain_start_launches_its_own_ranks():
+    """`python bench.py --gpus N` started plainly is its own launcher (bench.py launch_ranks): N child processes with RANK / WORLD_SIZE /
+    MASTER_* set rendezvous over gloo; rank 0's JSON line is relayed; a failing rank makes the launcher exit non-zero and ends the others.
+    (--launcher-selftest keeps the ranks off the GPU; the GPU tier runs the real legs this way, tests/test_gpu_two_ranks.py.)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BPPP_SELFTEST_FAIL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launcher-selftest"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 3 and out["ranks"] == [0, 1, 2]
+    assert out["shards"][0][0] == 0 and out["shards"][-1][1] == 4096 and all(out["shards"][i][1] == out["shards"][i + 1][0] for i in range(2))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, BPPP_SELFTEST_FAIL_RANK="1"), cwd=ROOT)
+    assert p.returncode != 0 and "rank 1 exited with 3" in p.stderr
