@@ -826,7 +826,8 @@ class NativeRangeProofs:
     """One setup registered with the library (bppp_rp_create): ranges, layout and basis live on the device; batches of ENCODED
     proofs (the reference's commitments / proof files, bulletproofspp_amd.encoding) are verified end to end there — decoding,
     all SHA-256 transcript hashing (the CLI's shaOracle), verifyTRRPM's scalars, challenge expansion and one combined MSM.
-    Both argument flavours verify; prove_batch (the lockstep prover) serves the norm-linear one."""
+    Both argument flavours verify and prove (bppp_rp_prove_batch: the norm-linear argument through csrc/nlb.hip, the inner-product one
+    through csrc/rpprove.hip's ip_argument_lockstep)."""
 
     def __init__(self, gpu, st: SetupTRRP, oracle_tag: bytes = b"", h: Point = None):
         import ctypes as C
@@ -880,8 +881,6 @@ class NativeRangeProofs:
         import numpy as np
         from .capi import scalars_to_array
         B, nr = len(inputs), len(self.st.rds)
-        if self.st.flavour != "NL":
-            raise ValueError("the lockstep batch prover exists for the norm-linear argument flavour")
         if B == 0:
             return []
         if len(rand_prefixes) != B or len({len(p_) for p_ in rand_prefixes}) != 1 or any(len(row) != nr for row in inputs):

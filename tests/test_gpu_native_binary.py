@@ -102,6 +102,7 @@ def test_native_binary_on_the_reference_example(gpu):
     nat_ip = BRP.NativeBinaryRangeProofs(gpu, st_ip)
     c_ip, f_ip = E.encode_proof(2, p_ip)
     assert nat_ip.verify_batch([c_ip], [f_ip])
+    assert nat_ip.prove_batch([row], [b"bin ip"])[0] == (c_ip, f_ip)                 # the binary prover over the lockstep inner-product argument
     t_ip = bytearray(f_ip); t_ip[40] ^= 1
     assert not nat_ip.verify_batch([c_ip], [bytes(t_ip)])
     nat_ip.close(); nat.close()

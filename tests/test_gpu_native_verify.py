@@ -375,15 +375,13 @@ def test_native_layer_on_a_mixed_schema(gpu):
     forged[3] = (got[2][0], got[3][1])                              # another proof's input commitments
     ok, status, _ = nat.verify_batch([c for c, _ in forged], [p for _, p in forged], seed, want_status=True)
     assert not ok and status == [0, 0, 0, 1, 0]
-    # the same schema under the inner-product argument: the library verifies it (tests/test_gpu_native_verify_ip.py), the lockstep
-    # prover is the norm-linear one
+    # the same schema under the inner-product argument (tests/test_gpu_native_verify_ip.py)
     st_ip = RP.setup(RP.GpuBackend(gpu), pts, True, pub, rds, "IP")
     nat_ip = RP.NativeRangeProofs(gpu, st_ip)
     p_ip = RP.prove(st_ip, RP.witness(st_ip, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0]))
     c_ip, f_ip = E.encode_proof(4, p_ip)
     t_ip = bytearray(f_ip); t_ip[5] ^= 2
     assert nat_ip.verify_batch([c_ip], [f_ip]) and not nat_ip.verify_batch([c_ip], [bytes(t_ip)])
-    with pytest.raises(ValueError):
-        nat_ip.prove_batch(inputs[:1], prefixes[:1])
+    assert nat_ip.prove_batch(inputs[:1], prefixes[:1])[0] == (c_ip, f_ip)          # its lockstep prover: the same bytes
     nat_ip.close()
     nat.close()

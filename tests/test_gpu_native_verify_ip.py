@@ -124,8 +124,48 @@ def test_native_ip_setups_verify_from_files(gpu, name):
     ok, status, _ = nat.verify_batch([c for c, _ in sw], [p for _, p in sw], seed, want_status=True)
     if files[1][0] != files[3][0]:
         assert not ok and status[1] == 1 and sum(status) == 1
-    with pytest.raises(ValueError):
-        nat.prove_batch([[(1, 0, 1)] * len(st.rds)], [b"x"])
+    nat.close()
+
+
+@pytest.mark.parametrize("name", ["64bit", "32bit", "rec_test"])
+def test_native_ip_lockstep_prover_equals_host_protocol_bytes(gpu, oracle_lib, name):
+    """bppp_rp_prove_batch on an inner-product setup (csrc/rpprove.hip ip_argument_lockstep: every commitment an MSM over the ORIGINAL
+    basis — makeNorm's basis change and every point fold carried in the scalars) against rangeproof.prove over the per-proof device
+    argument (bppp_ip_*: basis change by scalar multiplications, folds by the reference's rationalReduceScalar pairs) and over the
+    ORACLE backend: the same files byte for byte."""
+    schema = json.load(open(os.path.join(EXAMPLES, name, "schema.json")))
+    st = RP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    st_o = RP.setup_from_schema(OracleBackend(oracle_lib), schema)
+    wit_json = json.load(open(os.path.join(EXAMPLES, name, "witness.json")))
+    B = 9
+    inputs = [RP.inputs_from_witness(wit_json, b"ip lockstep %d" % j) for j in range(B)]
+    prefixes = [b"ip lockstep rand %02d" % j for j in range(B)]
+    nat = RP.NativeRangeProofs(gpu, st)
+    got = nat.prove_batch(inputs, prefixes)
+    for b in range(B):
+        proof = RP.prove(st, RP.witness(st, inputs[b]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[b]))
+        assert got[b] == E.encode_proof(4, proof), "proof %d differs from the host protocol code's" % b
+    p_o = RP.prove(st_o, RP.witness(st_o, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0]))
+    assert got[0] == E.encode_proof(4, p_o) and RP.verify(st_o, p_o, RP.sha256_oracle())
+    assert nat.verify_batch([c for c, _ in got], [p for _, p in got])
+    nat.close()
+
+
+def test_native_ip_lockstep_prover_on_a_long_vector(gpu):
+    """the 64by64 schema under the inner-product argument (nrmLen 512 -> 256 pairs, linLen 261, 8 rounds, odd lengths on the way down):
+    lockstep prover == per-proof device argument, and the batch verifies"""
+    schema = dict(json.load(open(os.path.join(EXAMPLES, "64by64", "schema.json"))), argument="IP")
+    st = RP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    assert st.flavour == "IP" and st.nrm_len == 512
+    rnd = random.Random(64)
+    B = 3
+    inputs = [[(rnd.randrange(2**64), 0, rnd.randrange(RP.N)) for _ in range(64)] for _ in range(B)]
+    prefixes = [b"ip long %d" % j for j in range(B)]
+    nat = RP.NativeRangeProofs(gpu, st)
+    got = nat.prove_batch(inputs, prefixes)
+    proof = RP.prove(st, RP.witness(st, inputs[1]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[1]))
+    assert got[1] == E.encode_proof(4, proof)
+    assert nat.verify_batch([c for c, _ in got], [p for _, p in got])
     nat.close()
 
 
