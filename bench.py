@@ -371,14 +371,14 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     return verify, prove
 
 
-def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, distinct: int = 128, cpu_baseline_leg: bool = True):
-    """The inner-product flavour at batch scale (the CLI's DEFAULT argument, app/Parse.hs:100): `batch` encoded proofs
-    of the examples/64bit shape — ONE 64-bit value, base 16 inline, nrmLen 16, linLen 6, 3 rounds, the paper's 416-byte proof
-    (README.md:169-172) — verified end to end from their files in HBM by bppp_rp_verify_batch_device over a flavour-1 setup: decode,
-    all SHA-256 transcript hashing, verifyTRRPM's scalars, expandChallenges of InnerProductArgument.hs:103-124 / :172-181 with makeNorm's
-    basis change folded into the shared-basis scalars, ONE combined MSM of 23 + batch * 11 terms.  The library has no lockstep prover
-    for this flavour, so `distinct` proofs (random 64-bit values, own blindings and prover randomness; made one at a time by the host
-    protocol code over bppp_ip_*) are tiled to the batch — position-dependent weights make every slot its own term of the combination."""
+def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, cpu_baseline_leg: bool = True):
+    """The inner-product flavour at batch scale (the CLI's DEFAULT argument, app/Parse.hs:100): `batch` DISTINCT encoded
+    proofs of the examples/64bit shape — ONE 64-bit value, base 16 inline, nrmLen 16, linLen 6, 3 rounds, the paper's 416-byte proof
+    (README.md:169-172) — made in this run by the library's lockstep prover (bppp_rp_prove_batch over a flavour-1 setup: range-proof phases,
+    then csrc/rpprove.hip's ip_argument_lockstep — every commitment an MSM over the original basis, no basis change, no point fold) and
+    verified end to end from their files in HBM by bppp_rp_verify_batch_device: decode, all SHA-256 transcript hashing, verifyTRRPM's
+    scalars, expandChallenges of InnerProductArgument.hs:103-124 / :172-181 with makeNorm's basis change folded into the shared-basis
+    scalars, ONE combined MSM of 23 + batch * 11 terms."""
     import ctypes as C
     from bulletproofspp_amd import encoding as E
     from bulletproofspp_amd import rangeproof as RP
@@ -387,20 +387,32 @@ def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, distinct: int = 128
     assert (st.flavour, st.nrm_len, st.lin_len, st.rounds, tuple(st.final_lens)) == ("IP", 16, 6, 3, (2, 1))
     nat = RP.NativeRangeProofs(gpu, st)
     rng = np.random.default_rng(0x1664)
+    vals = rng.integers(0, 2**64, size=batch, dtype=np.uint64)
+    amt = np.zeros((batch, 1, 4), dtype=np.uint64); amt[:, 0, 0] = vals
+    typ = np.zeros((batch, 1, 4), dtype=np.uint64)
+    bld = rng.integers(0, 2**64, size=(batch, 1, 4), dtype=np.uint64); bld[:, :, 3] >>= np.uint64(1)
+    plen = 20
+    pre = np.frombuffer(b"".join(b"bench ip %010d " % b_ for b_ in range(batch)), dtype=np.uint8)
+    assert pre.size == batch * plen
+    cf = np.zeros(batch * nat.shape["coms_bytes"], dtype=np.uint8)
+    pf = np.zeros(batch * nat.shape["proof_bytes"], dtype=np.uint8)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+
+    def prove_once():
+        gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bld), vp(pre), plen, vp(cf), vp(pf)), "bppp_rp_prove_batch")
+    prove_once()
     tp0 = time.perf_counter()
-    files, kept = [], []
-    for j in range(distinct):
-        v, bl = int(rng.integers(0, 2**64, dtype=np.uint64)), int(rng.integers(1, 2**63, dtype=np.uint64)) << 64 | int(rng.integers(0, 2**63, dtype=np.uint64))
-        proof = RP.prove(st, RP.witness(st, [(v, 0, bl)]), RP.sha256_oracle(), RP.hash_to_scalar(b"bench ip %06d" % j))
-        files.append(E.encode_proof(4, proof))
-        if j < 3:
-            kept.append(proof)
+    prove_once()
     prove_s = time.perf_counter() - tp0
-    assert len(files[0][1]) == 418 and len({p for _, p in files}) == distinct
-    reps = (batch + distinct - 1) // distinct
-    cf = np.frombuffer((b"".join(c for c, _ in files) * reps)[:batch * nat.shape["coms_bytes"]], dtype=np.uint8)
-    pf = np.frombuffer((b"".join(p for _, p in files) * reps)[:batch * nat.shape["proof_bytes"]], dtype=np.uint8)
-    d_c, d_p = torch.from_numpy(cf.copy()).to(dev), torch.from_numpy(pf.copy()).to(dev)
+    pb = nat.shape["proof_bytes"]
+    assert pb == 418 and len({pf[b_ * pb:(b_ + 1) * pb].tobytes() for b_ in range(min(batch, 512))}) == min(batch, 512), "proofs are not distinct"
+    # one proof of the batch against the host protocol code over the per-proof device argument (bppp_ip_*): the same bytes
+    p0 = RP.prove(st, RP.witness(st, [(int(vals[0]), 0, int(bld[0, 0, 0]) | int(bld[0, 0, 1]) << 64 | int(bld[0, 0, 2]) << 128 | int(bld[0, 0, 3]) << 192)]),
+                  RP.sha256_oracle(), RP.hash_to_scalar(b"bench ip %010d " % 0))
+    c0, f0 = E.encode_proof(4, p0)
+    assert cf[:len(c0)].tobytes() == c0 and pf[:pb].tobytes() == f0, "lockstep inner-product prover differs from the host protocol code"
+    kept = [p0]
+    d_c, d_p = torch.from_numpy(cf).to(dev), torch.from_numpy(pf).to(dev)
     seed = os.urandom(32)
     ok, _ = nat.verify_batch_device_point(batch, d_c.data_ptr(), d_p.data_ptr(), seed)
     assert ok, "batch of valid inner-product proofs did not verify"
@@ -420,11 +432,15 @@ def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, distinct: int = 128
     nlen, llen, k, ninit = st.nrm_len, st.lin_len, st.rounds, 4 + len(st.rds)
     bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
     out = {"metric": "single_64bit_range_proof_verifies_per_sec (inner-product argument)", "value": batch / dt, "unit": "verifies/s", "ms_per_batch": dt * 1e3,
-           "batch": batch, "distinct_proofs": distinct, "combined_msm_terms": nlen + llen + 1 + batch * (ninit + 2 * k),
+           "batch": batch, "distinct_proofs": batch, "combined_msm_terms": nlen + llen + 1 + batch * (ninit + 2 * k),
            "algorithmic_bytes_per_proof": bytes_per_proof, "encoded_bytes_per_proof": nat.shape["coms_bytes"] + nat.shape["proof_bytes"],
            "achieved_GBps": batch * bytes_per_proof / dt / 1e9, "hbm_frac": batch * bytes_per_proof / dt / 1e9 / HBM_PEAK_GBS,
            "shape": "examples/64bit: 1 x 64-bit value, base 16 inline, IP argument, nrmLen 16, linLen 6, 3 rounds, 34-term verifier MSM per proof, 418-byte proof file",
-           "proofs": f"{distinct} distinct real proofs (host protocol code over bppp_ip_*, {prove_s / distinct * 1e3:.0f} ms each) tiled to {batch}; all verify; one corrupted member is rejected",
+           "proofs": f"{batch} DISTINCT real proofs made by the lockstep inner-product prover in this run (one checked byte for byte against the host "
+                     "protocol code); all verify; one corrupted member is rejected",
+           "prove": {"metric": "single_64bit_range_proofs_proved_per_sec (inner-product argument)", "value": batch / prove_s, "unit": "proofs/s", "ms_per_batch": prove_s * 1e3,
+                     "scope": "bppp_rp_prove_batch, flavour 1: range-proof phases and the argument's field algebra on the host cores, every commitment an MSM over "
+                              "the registered original basis on the GPU (csrc/rpprove.hip ip_argument_lockstep)"},
            "scope": "verifyM of RangeProof end to end from the encoded files in HBM, inner-product flavour (bppp_rp_verify_batch_device, flavour 1)"}
     if cpu_baseline_leg:
         # the reference's verifier for ONE such proof: makeNorm's basis change (one 256-row scalar multiplication per basis pair,
@@ -434,7 +450,7 @@ def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, distinct: int = 128
         import pyoracle
         from rp_backends import OracleBackend
         ob = OracleBackend(pyoracle.CEC())
-        sample = [RP.verify_inputs(st, p_, RP.sha256_oracle()) for p_ in kept]
+        sample = [RP.verify_inputs(st, p_, RP.sha256_oracle()) for p_ in kept] * 3
         tc0 = time.perf_counter()
         for v in sample:
             assert ob.verify_bp("IP", v["q"], v["sp"], st.g, v["pub_norm"], st.gs, v["pub_lin_c"], v["pub_lin_x"], st.hs, v["es"], v["responses"], v["wit_norm"],
