@@ -800,13 +800,14 @@ def main():
         try:
             pk = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["prover_4096_proofs_64by64"]["by_kernel"]
             ck = next(v for k_, v in pk.items() if "k_comb_msm" in k_)
-            comb_traffic = ck["fetch_bytes_per_launch_x2"] + ck["write_bytes_per_launch"]
+            # the profile's launches average SQ_WAVES instances (one wavefront per instance): scale to this launch's `inst` instances
+            comb_traffic = (ck["fetch_bytes_per_launch_x2"] + ck["write_bytes_per_launch"]) / ck["sq_per_launch"]["SQ_WAVES"] * inst
         except Exception:
             pass
         comb_roofline = {"bound": "hbm", "kernel": "k_comb_msm", "achieved": comb_bytes / dtb / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": comb_bytes / dtb / 1e9 / HBM_PEAK_GBS, "traffic": comb_traffic,
-                         "traffic_source": "static: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE over benchmarks/prove_timing.py 4096, mean over "
-                                           "the 22 k_comb_msm launches of a batch (16 round launches of 8192 x 774 terms, 6 commitment launches)",
+                         "traffic_source": "static: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE over benchmarks/prove_timing.py 4096: bytes per "
+                                           "instance (mean over the 22 k_comb_msm launches of two batches, 7447 instances of 774 terms each on average) x this launch's instances",
                          "note": "%d instances x %d terms x (32-B scalar + %d windows x 64-B table row) per launch / live duration; the kernel is VALU-bound "
                                  "(2.4 k instructions per mixed addition; profiles/r03_pmc_prover_per_kernel.csv: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = 0.36, "
                                  "SQ_WAIT_ANY 0.06)" % (inst, nb, wcomb)}
