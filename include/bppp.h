@@ -324,8 +324,9 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
  * with their digit coefficients (makeRangeData :103-120), the Phase1 layout (:133-169), the round count (optimalWitnessSize,
  * src/Bulletproof/NormArgument.hs:165-178) and the REGISTERED BASIS g, G, H — uploaded once, referenced by every later call
  * (G, H are fixed per setup, TypedReciprocal.hs:348-359).  Argument flavour: 0 = norm-linear (Bulletproof.NormArgument), 1 = inner product
- * (Bulletproof.InnerProductArgument, the CLI's default, app/Parse.hs:100).  Both have the batch VERIFIER; the lockstep batch PROVER
- * (bppp_rp_prove_batch) exists for flavour 0 — inner-product proofs are made one at a time through bppp_ip_*.
+ * (Bulletproof.InnerProductArgument, the CLI's default, app/Parse.hs:100).  Both have the batch verifier and the lockstep batch prover
+ * (bppp_rp_prove_batch; flavour 1 proves with its field algebra on the host cores and every commitment as an MSM over the registered
+ * original basis — makeNorm's basis change and every point fold are carried in the scalars, same bytes as the folding route).
  *
  * bppp_rp_create: `ranges` as the schema gives them (app/Parse.hs:125-172): base, min, max (plain INTEGERS in 256-bit two's complement — a minimum may be negative, examples/rec_test — max exclusive
  * as in makeRangeData), flags.  `pubs`: the public (isOutput, type, amount) triples.  `points_xy` = h : g : hs ++ gs, the stream the
