@@ -8,12 +8,14 @@
 // batch of fresh proofs goes from challenges to the combined MSM without its O(nrmLen + linLen) scalars crossing PCIe.
 //
 // A group of lanes per proof (16: four proofs per wavefront).  All field inversions of a proof — e, q0 and every (e + symbol) of the reciprocal argument — are ONE
-// inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 8x32 limbs (fe.hip.h).
+// inversion: block-wide Montgomery trick (prefix and suffix product scans in LDS).  Fr arithmetic in 10 x 26-bit lazy limbs (fr26.hip.h:
+// 413 instructions per multiplication against 785 for the 8 x 32 form), canonical 8 x 32 values in memory.
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
 #include "fe.hip.h"
+#include "fr26.hip.h"
 #include "modinv.hip.h"
 #include "trrp.hpp"
 #include "../../include/bppp.h"
@@ -22,16 +24,16 @@ namespace bppp {
 
 // Fr multiply / square as real functions: ~80 call sites would otherwise inline to 37 k instructions (220 KB of code, several
 // times the instruction cache) for a kernel whose wavefronts all sit in different phases
-__device__ __noinline__ fe frm(fe a, fe b) { return fe_mul<1>(a, b); }
-__device__ __noinline__ fe frs(fe a) { return fe_sqr<1>(a); }
+__device__ __noinline__ fr frm(fr a, fr b) { return fr_mul(a, b); }
+__device__ __noinline__ fr frs(fr a) { return fr_sqr(a); }
 
-BPPP_DI fe fr_pow_u32(fe base, uint32_t e) {
-  fe acc = fe_one();
+BPPP_DI fr fr_pow_u32(fr base, uint32_t e) {
+  fr acc = fr_one();
   while (e) { if (e & 1u) acc = frm(acc, base); base = frs(base); e >>= 1; }
   return acc;
 }
-BPPP_DI fe lds_get(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8; k++) r.v[k] = p[i * 8 + k]; return r; }
-BPPP_DI void lds_put(uint32_t *p, uint32_t i, const fe &a) { for (int k = 0; k < 8; k++) p[i * 8 + k] = a.v[k]; }
+BPPP_DI fr lds_get(const uint32_t *p, uint32_t i) { fr r; for (int k = 0; k < 10; k++) r.n[k] = p[i * 10 + k]; return r; }
+BPPP_DI void lds_put(uint32_t *p, uint32_t i, const fr &a) { for (int k = 0; k < 10; k++) p[i * 10 + k] = a.n[k]; }
 
 
 // G lanes per proof (G | 64), 64 / G proofs per wavefront: lane t of a group owns the contiguous chunks [t*C, (t+1)*C) of every list, so
@@ -59,60 +61,60 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, uint32_t batch, 
   const uint32_t b = live ? b_raw : batch - 1;
   uint32_t *lds = lds_all + (size_t)grp * lds_words_per_proof;
   uint32_t *inv = lds;                         // [m] the inverted list: e, q0, e + sym_k (holds the lanes' running products first)
-  uint32_t *sa = inv + (size_t)m * 8;          // [G] scan scratch A
-  uint32_t *sb = sa + G * 8;                   // [G] scan scratch B
-  uint32_t *x2 = sb + G * 8;                   // [nr]  x^(2(j+1))
-  uint32_t *sl = x2 + (size_t)D.nr * 8;        // [3][TRRP_MAX_SLOTS] per base slot: t^2 v, 2 t^5 v / e, 2 t^3 v   (v = x^(3+2 slot))
+  uint32_t *sa = inv + (size_t)m * 10;          // [G] scan scratch A
+  uint32_t *sb = sa + G * 10;                   // [G] scan scratch B
+  uint32_t *x2 = sb + G * 10;                   // [nr]  x^(2(j+1))
+  uint32_t *sl = x2 + (size_t)D.nr * 10;        // [3][TRRP_MAX_SLOTS] per base slot: t^2 v, 2 t^5 v / e, 2 t^3 v   (v = x^(3+2 slot))
   const uint32_t *c = ch + (size_t)b * 56;
-  const fe e = fe_load(c), x = fe_load(c + 8), r0 = fe_load(c + 16), q = fe_load(c + 24), xp = fe_load(c + 32), r1 = fe_load(c + 40), tt = fe_load(c + 48);
-  fe q0 = frs(q);                         // qPowers' : q^2 (NL, NormArgument.hs:148) or -q^2 (IP, InnerProductArgument.hs:231)
-  if (D.flavour) q0 = fe_neg<1>(q0);
+  const fr e = fr_load(c), x = fr_load(c + 8), r0 = fr_load(c + 16), q = fr_load(c + 24), xp = fr_load(c + 32), r1 = fr_load(c + 40), tt = fr_load(c + 48);
+  fr q0 = frs(q);                         // qPowers' : q^2 (NL, NormArgument.hs:148) or -q^2 (IP, InnerProductArgument.hs:231)
+  if (D.flavour) q0 = fr_negr(q0);
 
   // ---- one inversion for the whole proof (batchInverse semantics: 0 -> 0)
   const uint32_t K = (m + G - 1) / G, lo = min(m, t * K), hi = min(m, lo + K);
-  fe local = fe_one();
+  fr local = fr_one();
   for (uint32_t i = lo; i < hi; i++) {
-    fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));
+    fr a = i == 0 ? e : i == 1 ? q0 : fr_addr(e, fr_load(syms + (size_t)(i - 2) * 8));
     lds_put(inv, i, local);                      // product of this lane's elements before element i
-    if (!fe_is_zero(a)) local = frm(local, a);
+    if (!fr_is_zero(a)) local = frm(local, a);
   }
   lds_put(sa, t, local); lds_put(sb, t, local);
   __syncthreads();
   for (int d = 1; d < G; d <<= 1) {            // inclusive prefix (sa) and suffix (sb) products over the lanes of the group
-    fe pa = lds_get(sa, t), pb = lds_get(sb, t);
-    fe oa = (int)t - d >= 0 ? lds_get(sa, t - d) : fe_one();
-    fe ob = t + d < (uint32_t)G ? lds_get(sb, t + d) : fe_one();
+    fr pa = lds_get(sa, t), pb = lds_get(sb, t);
+    fr oa = (int)t - d >= 0 ? lds_get(sa, t - d) : fr_one();
+    fr ob = t + d < (uint32_t)G ? lds_get(sb, t + d) : fr_one();
     __syncthreads();
     lds_put(sa, t, frm(pa, oa)); lds_put(sb, t, frm(pb, ob));
     __syncthreads();
   }
-  fe others = frm(t ? lds_get(sa, t - 1) : fe_one(), t + 1 < (uint32_t)G ? lds_get(sb, t + 1) : fe_one());
-  fe total = lds_get(sa, G - 1);
+  fr others = frm(t ? lds_get(sa, t - 1) : fr_one(), t + 1 < (uint32_t)G ? lds_get(sb, t + 1) : fr_one());
+  fr total = lds_get(sa, G - 1);
   __syncthreads();
-  if (t == 0) lds_put(sa, 0, fe_modinv<1>(total));        // one active lane per group: division steps (~14 k instructions), all groups in one pass
+  if (t == 0) lds_put(sa, 0, fr_from_fe(fe_modinv<1>(fr_to_fe(total))));        // one active lane per group: division steps (~14 k instructions), all groups in one pass
   __syncthreads();
   {
-    fe suf = frm(lds_get(sa, 0), others);  // 1 / (product of this lane's own elements), then times the ones already passed
+    fr suf = frm(lds_get(sa, 0), others);  // 1 / (product of this lane's own elements), then times the ones already passed
     for (uint32_t i = hi; i-- > lo;) {
-      fe a = i == 0 ? e : i == 1 ? q0 : fe_add<1>(e, fe_load(syms + (size_t)(i - 2) * 8));   // recomputed: one LDS array instead of two
-      if (fe_is_zero(a)) { lds_put(inv, i, fe_zero()); continue; }
+      fr a = i == 0 ? e : i == 1 ? q0 : fr_addr(e, fr_load(syms + (size_t)(i - 2) * 8));   // recomputed: one LDS array instead of two
+      if (fr_is_zero(a)) { lds_put(inv, i, fr_zero()); continue; }
       lds_put(inv, i, frm(suf, lds_get(inv, i)));
       suf = frm(suf, a);
     }
   }
   // ---- per-range and per-base-slot tables
-  const fe xx = frs(x), x3 = frm(xx, x);
-  const fe t2 = frs(tt), t3 = frm(t2, tt), t4 = frs(t2), t5 = frm(t4, tt), t6 = frs(t3);
-  const fe two_t5 = fe_dbl<1>(t5), two_t3 = fe_dbl<1>(t3);
+  const fr xx = frs(x), x3 = frm(xx, x);
+  const fr t2 = frs(tt), t3 = frm(t2, tt), t4 = frs(t2), t5 = frm(t4, tt), t6 = frs(t3);
+  const fr two_t5 = fr_dblr(t5), two_t3 = fr_dblr(t3);
   {                                                           // x^(2(j+1)) for this lane's ranges j = t, t + G, ...: one power, then steps of x^(2G)
-    fe xj = fr_pow_u32(xx, t + 1);
-    const fe xg = fr_pow_u32(xx, G);
+    fr xj = fr_pow_u32(xx, t + 1);
+    const fr xg = fr_pow_u32(xx, G);
     for (uint32_t j = t; j < D.nr; j += G) { lds_put(x2, j, xj); xj = frm(xj, xg); }
   }
   __syncthreads();
-  const fe e_inv = lds_get(inv, 0), q0_inv = lds_get(inv, 1);
+  const fr e_inv = lds_get(inv, 0), q0_inv = lds_get(inv, 1);
   for (uint32_t s_ = t; s_ < (uint32_t)TRRP_MAX_SLOTS; s_ += G) {
-    fe v = frm(x3, fr_pow_u32(xx, s_));                      // makeBaseMap: x^3, x^5, ... (:349)
+    fr v = frm(x3, fr_pow_u32(xx, s_));                      // makeBaseMap: x^3, x^5, ... (:349)
     lds_put(sl, s_, frm(t2, v));
     lds_put(sl, TRRP_MAX_SLOTS + s_, frm(frm(two_t5, e_inv), v));
     lds_put(sl, 2 * TRRP_MAX_SLOTS + s_, frm(two_t3, v));
@@ -122,77 +124,77 @@ __global__ void __launch_bounds__(64) k_trrp_public(TrrpDims D, uint32_t batch, 
   // ---- norm positions: publicTerms (TypedReciprocal.hs:262-274) with u, v, c of makePhase2s (:193-205), regrouped:
   //   digit:  p = t^2 e + q^-2i (t^2 v + t^3 u + t^4 c),        ts0 = q^2i (p^2 + 2 t^5) + 2 t^5 v / e
   //   type:   p = t^2 e + t^3 x' + q^-2i (t^2 v + t^3 x' u),     ts0 = q^2i p^2
-  fe acc = fe_zero();
+  fr acc = fr_zero();
   {
     const uint32_t C = (D.nlen + G - 1) / G, plo = min(D.nlen, t * C), phi = min(D.nlen, plo + C);
-    fe q2 = fr_pow_u32(q0, plo + 1), qi2 = fr_pow_u32(q0_inv, plo + 1);
-    const fe t2e = frm(t2, e), t3xp = frm(t3, xp), t2e_t = fe_add<1>(t2e, t3xp);
+    fr q2 = fr_pow_u32(q0, plo + 1), qi2 = fr_pow_u32(q0_inv, plo + 1);
+    const fr t2e = frm(t2, e), t3xp = frm(t3, xp), t2e_t = fr_addr(t2e, t3xp);
     for (uint32_t i = plo; i < phi; i++) {
       const uint32_t kf = pos_kind[i], kind = kf & 0xFFu;
-      const fe xr = lds_get(x2, pos_range[i]);
-      fe p, ts0;
+      const fr xr = lds_get(x2, pos_range[i]);
+      fr p, ts0;
       if (kind == K_TYPING) {
-        fe A = frm(t2, (kf & F_IO) ? fe_neg<1>(x) : x);
-        if (!(kf & F_IA)) A = fe_add<1>(A, frm(t3xp, xr));
-        p = fe_add<1>(t2e_t, frm(qi2, A));
+        fr A = frm(t2, (kf & F_IO) ? fr_negr(x) : x);
+        if (!(kf & F_IA)) A = fr_addr(A, frm(t3xp, xr));
+        p = fr_addr(t2e_t, frm(qi2, A));
         ts0 = frm(q2, frs(p));
       } else {
         const uint32_t slot = pos_slot[i], sy = pos_sym[i];
-        fe A = fe_add<1>(lds_get(sl, slot), frm(t3, frm(xr, fe_load(pos_coeff + (size_t)i * 8))));
+        fr A = fr_addr(lds_get(sl, slot), frm(t3, frm(xr, fr_load(pos_coeff + (size_t)i * 8))));
         if (kind == K_INLINE && sy != NO_SYM) {
-          const fe si = lds_get(inv, 2 + sy);                      // "if s == 0 then 0" is tested on the INVERTED value (:205): e + s = 0 gives c = 0
-          if (!fe_is_zero(si)) A = fe_add<1>(A, frm(frm(t2, lds_get(sl, slot)), fe_sub<1>(e_inv, si)));      // t^4 v = t^2 (t^2 v): the slot table has t^2 v
+          const fr si = lds_get(inv, 2 + sy);                      // "if s == 0 then 0" is tested on the INVERTED value (:205): e + s = 0 gives c = 0
+          if (!fr_is_zero(si)) A = fr_addr(A, frm(frm(t2, lds_get(sl, slot)), fr_subr(e_inv, si)));      // t^4 v = t^2 (t^2 v): the slot table has t^2 v
         }
-        p = fe_add<1>(t2e, frm(qi2, A));
-        ts0 = fe_add<1>(frm(q2, fe_add<1>(frs(p), two_t5)), lds_get(sl, TRRP_MAX_SLOTS + slot));
+        p = fr_addr(t2e, frm(qi2, A));
+        ts0 = fr_addr(frm(q2, fr_addr(frs(p), two_t5)), lds_get(sl, TRRP_MAX_SLOTS + slot));
       }
-      if (live) fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
-      acc = fe_add<1>(acc, ts0);
+      if (live) fr_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
+      acc = fr_addr(acc, ts0);
       q2 = frm(q2, q0); qi2 = frm(qi2, q0_inv);
     }
   }
   // z (:254): -2 t^5 sum_j min_j x^(2(j+1))  -  [typed] 2 t^5 x pubSum
   for (uint32_t j = t; j < D.nr; j += G)
-    if (!range_assumed[j]) acc = fe_sub<1>(acc, frm(two_t5, frm(fe_load(range_min + (size_t)j * 8), lds_get(x2, j))));
+    if (!range_assumed[j]) acc = fr_subr(acc, frm(two_t5, frm(fr_load(range_min + (size_t)j * 8), lds_get(x2, j))));
   if (D.has_types)
     for (uint32_t j = t; j < D.npub; j += G) {
-      fe term = frm(frm(two_t5, x), frm(fe_load(pub_amount + (size_t)j * 8), lds_get(inv, 2 + pub_sym[j])));
-      acc = pub_is_out[j] ? fe_add<1>(acc, term) : fe_sub<1>(acc, term);
+      fr term = frm(frm(two_t5, x), frm(fr_load(pub_amount + (size_t)j * 8), lds_get(inv, 2 + pub_sym[j])));
+      acc = pub_is_out[j] ? fr_addr(acc, term) : fr_subr(acc, term);
     }
   __syncthreads();
   lds_put(sa, t, acc);
   __syncthreads();
   for (int d = G / 2; d >= 1; d >>= 1) {
-    if ((int)t < d) lds_put(sa, t, fe_add<1>(lds_get(sa, t), lds_get(sa, t + d)));
+    if ((int)t < d) lds_put(sa, t, fr_addr(lds_get(sa, t), lds_get(sa, t + d)));
     __syncthreads();
   }
-  if (t == 0 && live) { fe_store(out_sp + (size_t)b * 8, lds_get(sa, 0)); fe_store(out_q + (size_t)b * 8, q); }
+  if (t == 0 && live) { fr_store(out_sp + (size_t)b * 8, lds_get(sa, 0)); fr_store(out_q + (size_t)b * 8, q); }
 
   // ---- linear weights: makeBpCoeffs (:391-396) over makeSharedCoeffs (:213-216)
-  const fe rs = frm(r0, r1);
+  const fr rs = frm(r0, r1);
   if (live)
     for (uint32_t j = t; j < D.llen; j += G) {
-      fe v;
-      if (j == 0) v = D.has_types ? fe_neg<1>(xp) : fe_zero();
+      fr v;
+      if (j == 0) v = D.has_types ? fr_negr(xp) : fr_zero();
       else if (j == 1) v = frm(rs, tt);
       else if (j == 2) v = frm(rs, t2);
       else if (j == 3) v = frm(rs, t3);
       else if (j == 4) v = frm(r0, t4);
       else if (j == 5) v = frm(rs, t6);
-      else v = frm(lds_get(sl, 2 * TRRP_MAX_SLOTS + cs_slot[j - 6]), fe_sub<1>(e_inv, lds_get(inv, 2 + cs_sym[j - 6])));
-      fe_store(out_cs + ((size_t)b * D.llen + j) * 8, v);
+      else v = frm(lds_get(sl, 2 * TRRP_MAX_SLOTS + cs_slot[j - 6]), fr_subr(e_inv, lds_get(inv, 2 + cs_sym[j - 6])));
+      fr_store(out_cs + ((size_t)b * D.llen + j) * 8, v);
     }
   // ---- initCom scalars in commitment order blCom : rCom : dmCom : mCom : nComs  (openWith of TranscriptTRRP, :293-297)
   const uint32_t ninit = 4 + D.nr;
-  fe qr = D.has_types ? fr_pow_u32(q0, t + 1) : fe_zero();
-  const fe qG = D.has_types ? fr_pow_u32(q0, G) : fe_zero();
+  fr qr = D.has_types ? fr_pow_u32(q0, t + 1) : fr_zero();
+  const fr qG = D.has_types ? fr_pow_u32(q0, G) : fr_zero();
   if (live) {
     for (uint32_t r = t; r < D.nr; r += G) {
-      fe ic = range_assumed[r] ? fe_zero() : lds_get(x2, r);                     // inputCoeffs (:325-328)
-      if (D.has_types) { ic = fe_add<1>(ic, qr); qr = frm(qr, qG); }
-      fe_store(out_init + ((size_t)b * ninit + 4 + r) * 8, frm(two_t5, ic));
+      fr ic = range_assumed[r] ? fr_zero() : lds_get(x2, r);                     // inputCoeffs (:325-328)
+      if (D.has_types) { ic = fr_addr(ic, qr); qr = frm(qr, qG); }
+      fr_store(out_init + ((size_t)b * ninit + 4 + r) * 8, frm(two_t5, ic));
     }
-    if (t < 4) fe_store(out_init + ((size_t)b * ninit + t) * 8, t == 0 ? fe_one() : t == 1 ? t3 : t == 2 ? t2 : tt);
+    if (t < 4) fr_store(out_init + ((size_t)b * ninit + t) * 8, t == 0 ? fr_one() : t == 1 ? t3 : t == 2 ? t2 : tt);
   }
 }
 
@@ -264,7 +266,7 @@ int bppp_trrp_public_device(bppp_trrp *o, size_t batch, const void *d_challenges
   // dependency chain, which 64 lanes walk in fewer steps
   static const int forced_g = [] { const char *e = getenv("BPPP_TRRP_G"); const int v = e ? atoi(e) : 0; return (v == 16 || v == 32 || v == 64) ? v : 0; }();
   int G = forced_g ? forced_g : (batch <= 1024 ? 64 : 32);
-  auto words = [&](int g) { return ((size_t)(2 + o->D.nsyms) + 2 * (size_t)g + o->D.nr + 3 * TRRP_MAX_SLOTS) * 8; };
+  auto words = [&](int g) { return ((size_t)(2 + o->D.nsyms) + 2 * (size_t)g + o->D.nr + 3 * TRRP_MAX_SLOTS) * 10; };      // fr26: ten words per element
   while (G < 64 && words(G) * 4 * (64 / G) > 64 * 1024) G <<= 1;
   const size_t wpp = words(G), lds = wpp * 4 * (64 / G);
   if (lds > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "trrp_public: too many ranges for one workgroup's LDS");
