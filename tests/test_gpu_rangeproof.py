@@ -137,6 +137,31 @@ def test_device_derived_verifier_scalars_equal_the_host_derivation(gpu, pts, nam
     tabs.close()
 
 
+@pytest.mark.parametrize("name,flavour", [("typed_with_assumed", "NL"), ("mixed_inline_shared", "NL"), ("typed_conserved", "IP")])
+def test_public_scalars_three_kernel_route_equals_the_single_kernel(gpu, pts, name, flavour):
+    """Above 1024 proofs bppp_trrp_public_device runs as k_trrp_pre / k_trrp_pos / k_trrp_lin (csrc/trrp.hip) instead of the one
+    k_trrp_public: the same challenges through both routes — as one batch of 1100 and as two batches of 550 — give identical
+    outputs, and rows of it equal the host derivation (typing positions, inline symbols, assumed ranges, public amounts: every branch)."""
+    ranges, typed, pub, vals = CASES[name]
+    rds = [RP.make_range_data(*r) for r in ranges]
+    st = RP.setup(RP.GpuBackend(gpu), pts, typed, pub, rds, flavour)
+    tabs = RP.DeviceVerifierTables(gpu, st)
+    rnd = random.Random("split " + name)
+    chs = [[rnd.randrange(RP.N) for _ in range(7)] for _ in range(1100)]
+    chs[7] = [1, 2, 3, 4, 5, 6, 7]; chs[1099] = [RP.N - 1] * 7
+    big = tabs.public(chs)
+    small = tabs.public(chs[:550]) + tabs.public(chs[550:])
+    assert big == small
+    proof = RP.prove(st, RP.witness(st, [(v, ty, rnd.randrange(RP.N)) for v, ty in vals]), RP.sha256_oracle(), RP.hash_to_scalar(b"s"))
+    for i in (0, 7, 600, 1099):
+        e, x, r0, q, xp, r1, t = chs[i]
+        seq = iter([[e, x, r0], [q, xp, r1], [t]])
+        sbp = RP.verify_rp(st, proof.coms, RP.Transcript(lambda cs, n: next(seq)))
+        pad = lambda xs, n: list(xs) + [0] * (n - len(xs))
+        assert big[i]["sp"] == sbp.pub.sc and big[i]["pub_norm"] == pad(sbp.pub.nrm, st.nrm_len) and big[i]["pub_lin_c"] == pad(sbp.cs, st.lin_len)
+    tabs.close()
+
+
 def test_batch_verification_from_challenges_on_the_device(gpu, proofs_64by64):
     """challenges -> (device) public scalars -> (device) combined MSM: the whole verifier's arithmetic on the GPU"""
     import numpy as np
