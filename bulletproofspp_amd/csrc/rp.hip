@@ -150,6 +150,59 @@ __global__ void __launch_bounds__(256) k_rp_text(RpDims D, const uint32_t *__res
   }
 }
 
+// The same text through LDS (round 3): one lane per COORDINATE converts it once (the nine 9-digit chunks wait in LDS across the offset
+// scan), the digits are written as bytes into an LDS image of the proof's text, and the image goes out in 16-byte coalesced stores —
+// the first version converted every coordinate twice on 84 of its 256 lanes and wrote 13 KB per proof as single-byte global stores
+// (0.245 ms per 4096 proofs).  Dynamic LDS: off[npts + 1] | len[2 npts] | chunks[2 npts][9] | image[text_stride]; setups whose image does
+// not fit (thousands of commitments) keep k_rp_text.
+__host__ __device__ inline size_t rp_text_lds_bytes(const RpDims &D) {
+  const size_t npts = rp_npts(D);
+  return (((npts + 1) + 2 * npts + 18 * npts) * 4 + 15) / 16 * 16 + D.text_stride;
+}
+__global__ void __launch_bounds__(256) k_rp_text_lds(RpDims D, const uint32_t *__restrict__ init_pts, const uint32_t *__restrict__ resp_pts,
+                                                     uint8_t *__restrict__ text, uint32_t *__restrict__ text_off) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  __shared__ uint32_t wsum[4];
+  const uint32_t npts = rp_npts(D), nc = 2 * npts, b = blockIdx.x, tid = threadIdx.x;
+  uint32_t *off = sm, *clen = off + (npts + 1), *chunks = clen + nc;
+  uint8_t *image = (uint8_t *)sm + (((npts + 1) + nc + 9 * nc) * 4 + 15) / 16 * 16;
+  for (uint32_t c = tid; c < nc; c += 256) {
+    const uint32_t *p = rp_point_ptr(D, init_pts, resp_pts, b, c >> 1) + (c & 1u) * 8;
+    const Dec d = dec_convert(fe_load(p));
+    clen[c] = d.len | (d.top << 16);
+#pragma unroll
+    for (int k = 0; k < 9; k++) chunks[c * 9 + k] = d.ch[k];
+  }
+  __syncthreads();
+  // exclusive scan of the point lengths: every thread owns a contiguous chunk of points
+  const uint32_t per = (npts + 255) / 256, lo = min(npts, tid * per), hi = min(npts, lo + per);
+  uint32_t s = 0;
+  for (uint32_t t = lo; t < hi; t++) s += (clen[2 * t] & 0xFFFFu) + (clen[2 * t + 1] & 0xFFFFu);
+  uint32_t inc = s;
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if ((int)(tid & 63) >= d) inc += o; }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  uint32_t run = inc - s;
+  for (uint32_t w = 0; w < (tid >> 6); w++) run += wsum[w];
+  for (uint32_t t = lo; t < hi; t++) { off[t] = run; run += (clen[2 * t] & 0xFFFFu) + (clen[2 * t + 1] & 0xFFFFu); }
+  if (tid == 255) off[npts] = run;
+  __syncthreads();
+  for (uint32_t t = tid; t <= npts; t += 256) text_off[(size_t)b * (npts + 1) + t] = off[t];
+  for (uint32_t c = tid; c < nc; c += 256) {
+    Dec d;
+#pragma unroll
+    for (int k = 0; k < 9; k++) d.ch[k] = chunks[c * 9 + k];
+    d.len = clen[c] & 0xFFFFu; d.top = clen[c] >> 16;
+    const uint32_t start = off[c >> 1] + ((c & 1u) ? (clen[c - 1] & 0xFFFFu) : 0u);
+    dec_write_backward(d, image + start + d.len);
+  }
+  __syncthreads();
+  const uint32_t total = off[npts], n16 = (total + 15) / 16;
+  uint4 *dst = (uint4 *)(text + (size_t)b * D.text_stride);
+  const uint4 *src = (const uint4 *)image;
+  for (uint32_t i = tid; i < n16; i += 256) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------ hashing
 // Hash h of a proof (h < 7 + k):  0,1,2 -> e, x, r0   first oracle call  [dmCom, mCom] ++ nComs      (TypedReciprocal.hs:459)
 //                                 3,4,5 -> q, x', r1  second call, rCom prepended                    (:460)
@@ -820,7 +873,8 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it.  Only while the
     // batch leaves SIMDs idle (<= 1024 proofs: 256 proofs 1.65 -> 1.38 ms of kernels); at 4096 proofs the three kernels already
     // fill the VALU and running them side by side only stretches each (hash 0.65 -> 0.55 + 0.87, scalars 0.84 -> 1.04 ms: measured, not kept)
-    k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
+    if (rp_text_lds_bytes(D) <= 64 * 1024) k_rp_text_lds<<<dim3((unsigned)B), dim3(256), rp_text_lds_bytes(D), st>>>(D, init_pts, resp_pts, text, text_off);
+    else k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
     const uint32_t nch = D.nch, nes = rp->nhash - D.nch;
     hipStream_t aux = st;
     const bool fork = nes && B <= 1024;
