@@ -524,6 +524,114 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// 0. ONE small MSM in ONE launch (n <= MSM_SMALL_MAX terms, one instance): the general pipeline is ~16 launches and four dependency
+// chains deep (0.30 ms for the 858-term MSM of a single range-proof verification, whatever the window); here one workgroup per window
+// does all of it — sign fold + digit of its window for every scalar, a counting sort of the entries in LDS, M = 2^(c-1) buckets with
+// 256 / M lanes each (a shuffle tree joins them), and the running-sum reduction sum (m + 1) B_m as a suffix scan + tree over M lanes.
+// c = 6: 43 workgroups, ~17 dependent point operations deep.  The window sums go to the host's Horner combine like the general path's.
+static constexpr uint32_t MSM_SMALL_MAX = 4096;
+__global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ points, uint32_t n, int c, RecodeK K,
+                                                   uint32_t *__restrict__ winsum) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  const int M = 1 << (c - 1);
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  uint32_t *hist = sm, *start = hist + M, *sorted = start + M + 1;
+  uint16_t *key = (uint16_t *)(sorted + n);
+  uint32_t *bsum = sm + (((size_t)(2 * M + 1) + n + (n + 1) / 2 + 3) & ~(size_t)3);    // [M + 4] bucket sums, then the wavefronts' results
+  for (int t = tid; t < M; t += 256) hist[t] = 0;
+  __syncthreads();
+  const uint32_t bit0 = (uint32_t)c * w, mask = (1u << c) - 1u;
+  for (uint32_t j = tid; j < n; j += 256) {
+    const fe s_ = fe_load(scalars + (size_t)j * 8);
+    fe t, tmp;
+    raw_sub(t, fr_modulus(), s_);
+    const bool neg = raw_sub(tmp, t, s_) != 0;                     // s > n - s (reduceScalar, Commitment.hs:279)
+    uint32_t sp[10];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s_.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
+    sp[8] = (uint32_t)cy + K.k[8]; sp[9] = 0;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) if ((bit0 >> 5) == (uint32_t)q) { lo = sp[q]; hi = sp[q + 1]; }
+    const uint32_t sh = bit0 & 31u;
+    const uint32_t d = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
+    const int v = (int)d - M;
+    uint16_t kx = 0xFFFFu;
+    if (v) {
+      const uint32_t mb = (uint32_t)(v < 0 ? -v : v) - 1u;
+      kx = (uint16_t)((mb << 1) | (((v < 0) != neg) ? 1u : 0u));
+      atomicAdd(&hist[mb], 1u);
+    }
+    key[j] = kx;
+  }
+  __syncthreads();
+  if (tid < 64) {                                                   // exclusive prefix of hist[M] (M <= 128): lane owns M / 64 or one bucket
+    const int per = M > 64 ? M / 64 : 1;
+    uint32_t s0 = 0;
+    for (int q = 0; q < per; q++) { const int b = (int)lane * per + q; if (b < M) s0 += hist[b]; }
+    uint32_t inc = s0;
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t o = __shfl_up(inc, dd, 64); if ((int)lane >= dd) inc += o; }
+    uint32_t run = inc - s0;
+    for (int q = 0; q < per; q++) { const int b = (int)lane * per + q; if (b < M) { const uint32_t h = hist[b]; start[b] = run; hist[b] = run; run += h; } }
+    if (lane == 63) start[M] = inc;
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < n; j += 256) {
+    const uint16_t kx = key[j];
+    if (kx != 0xFFFFu) { const uint32_t pos = atomicAdd(&hist[kx >> 1], 1u); sorted[pos] = ((uint32_t)(kx & 1u) << 31) | j; }
+  }
+  __syncthreads();
+  // ---- buckets: LPB = 256 / M lanes per bucket, entries dealt round-robin, then a shuffle tree inside the group
+  const uint32_t LPB = 256u / (uint32_t)M, b = tid / LPB, sub = tid % LPB;
+  xyzz acc = xyzz_inf();
+  {
+    const uint32_t p1 = start[b + 1];
+    for (uint32_t p = start[b] + sub; p < p1; p += LPB) {
+      const uint32_t e = sorted[p];
+      xyzz_madd(acc, aff_cneg(aff_load(points + (size_t)(e & 0x7FFFFFFFu) * 16), (e >> 31) != 0));
+    }
+  }
+  for (uint32_t dd = LPB >> 1; dd >= 1; dd >>= 1) {
+    const xyzz o = xyzz_shfl_down(acc, (int)dd);
+    if (sub + dd < LPB) xyzz_add(acc, o);
+  }
+  if (sub == 0) xyzz_store(bsum + (size_t)b * XYZZ_WORDS, acc);
+  __syncthreads();
+  // ---- sum_m (m + 1) B_m = sum over m of the inclusive suffix sums: suffix scan + tree over the M lanes of each wavefront
+  const uint32_t nw = ((uint32_t)M + 63u) / 64u;
+  if (tid < 64u * nw) {
+    const uint32_t m = tid;
+    xyzz suf = m < (uint32_t)M ? xyzz_load(bsum + (size_t)m * XYZZ_WORDS) : xyzz_inf();
+    const int Mw = M < 64 ? M : 64;                                 // live lanes of a wavefront
+    for (int dd = 1; dd < Mw; dd <<= 1) {
+      const xyzz o = xyzz_shfl_down(suf, dd);
+      if ((int)lane + dd < Mw) xyzz_add(suf, o);
+    }
+    xyzz tot = suf;                                                 // lane 0: the whole wavefront's plain sum
+    xyzz v = suf;
+    for (int dd = Mw >> 1; dd >= 1; dd >>= 1) {
+      const xyzz o = xyzz_shfl_down(v, dd);
+      if ((int)lane + dd < Mw) xyzz_add(v, o);
+    }
+    if (lane == 0) {                                                // results go past the M bucket sums the other wavefront may still be loading
+      xyzz_store(bsum + (size_t)(M + 2 * (tid >> 6)) * XYZZ_WORDS, v);
+      xyzz_store(bsum + (size_t)(M + 2 * (tid >> 6) + 1) * XYZZ_WORDS, tot);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    xyzz r = xyzz_load(bsum + (size_t)M * XYZZ_WORDS);              // A_0
+    for (uint32_t j = 1; j < nw; j++) {                             // + A_j + 64 j T_j
+      xyzz a = xyzz_load(bsum + (size_t)(M + 2 * j) * XYZZ_WORDS), t = xyzz_load(bsum + (size_t)(M + 2 * j + 1) * XYZZ_WORDS);
+      for (int q = 0; q < 6; q++) t = xyzz_dbl(t);                  // 64 T_j (nw <= 2: j = 1)
+      xyzz_add(r, a); xyzz_add(r, t);
+    }
+    xyzz_store(winsum + (size_t)w * XYZZ_WORDS, r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host orchestration
 static int choose_window(size_t n, size_t batch, const MsmTune &tune) {
   // Cost model in units of one mixed addition (~68 ps chip-wide, measured at 2^20; profiles/):
@@ -652,6 +760,38 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
   if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
   if (!d_scalars || !d_points) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
   if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "msm: n must be < 2^31");
+  // ---- one small MSM: the whole of it in one launch (k_msm_small), then the host's Horner combine over the W window sums
+  if (batch == 1 && !table_stride && !window_bits && n <= MSM_SMALL_MAX && !ctx->tune.no_small) {
+    const int c = ctx->tune.small_c >= 5 && ctx->tune.small_c <= 8 ? ctx->tune.small_c : 6, W = 256 / c + 1, M = 1 << (c - 1);
+    Carver cv0(nullptr, 0);
+    cv0.take<uint32_t>((size_t)W * XYZZ_WORDS);
+    int rc = ensure_workspace(ctx, cv0.off); if (rc) return rc;
+    Carver cv(ctx->ws, ctx->ws_bytes);
+    uint32_t *winsum = cv.take<uint32_t>((size_t)W * XYZZ_WORDS);
+    const size_t bytes = (size_t)W * XYZZ_WORDS * 4;
+    rc = ensure_pinned(ctx, bytes); if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    for (int i = 0; i <= 2; i++) prof_mark(ctx, i);
+    if (ctx->pre_acc) { auto f = ctx->pre_acc; ctx->pre_acc = nullptr; int rc_ = f(ctx->pre_acc_arg); if (rc_) return rc_; }
+    const size_t lds = (size_t)(2 * M + 1) * 4 + n * 4 + n * 2 + 16 + (size_t)(M + 4) * XYZZ_WORDS * 4;
+    k_msm_small<<<dim3((unsigned)W), dim3(256), lds, st>>>((const uint32_t *)d_scalars, (const uint32_t *)d_points, (uint32_t)n, c, make_recode_k(c, W), winsum);
+    for (int i = 3; i <= 5; i++) prof_mark(ctx, i);
+    BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
+    prof_mark(ctx, 6);
+    BPPP_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t *ws = (const uint32_t *)ctx->pinned;
+    HJac r = hj_inf();
+    for (int w = W - 1; w >= 0; w--) {
+      const uint32_t *q = ws + (size_t)w * XYZZ_WORDS;
+      for (int k = 0; k < c; k++) r = hj_dbl(r);
+      r = hj_add(r, hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)));
+    }
+    HAff a = hj_to_aff(r);
+    a.x.store(out_xy); a.y.store(out_xy + 4);
+    BPPP_HIP(ctx, hipGetLastError());
+    prof_collect(ctx, 7);
+    return BPPP_OK;
+  }
   int c = window_bits ? window_bits : choose_window(n, batch, ctx->tune);
   if (!window_bits && ctx->tune.window_batched) { const int v = ctx->tune.window_batched; if (batch > 4 && v >= 2 && v <= 16) c = v; }   // tuning sweeps
   if (c < 2 || c > 16) return fail(ctx, BPPP_ERR_ARG, "msm: window_bits must be in [2,16]");

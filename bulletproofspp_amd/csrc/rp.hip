@@ -23,6 +23,7 @@
 // The same file holds the setup handle (`bppp_rp`: ranges, layout, basis resident in HBM) and, further down, the batch prover.
 #include <string.h>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
@@ -508,6 +509,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->work) hipFree(rp->work);
   if (rp->stage) hipFree(rp->stage);
   if (rp->hflag) hipHostFree(rp->hflag);
+  if (rp->hstage) hipHostFree(rp->hstage);
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
@@ -746,21 +748,9 @@ int rp_ensure_twin(bppp_rp *rp) {
 }
 
 // ---- the verifier's oracle on the HOST, for a handful of proofs: one GPU lane walks the ~160 SHA-256 blocks of a 64by64 transcript
-// in ~0.8 ms whatever the batch size; a host core hashes the same 11 KB in ~50 us.  Same inputs and outputs as k_rp_text + k_rp_hash:
-// the decoded points of proof b (an undecodable one reads as "00", like on the device), the 7 + k challenges.
+// in ~0.8 ms whatever the batch size; a host core (SHA extensions) hashes the same 11 KB in ~10 us.  The text itself is the device's
+// (k_rp_text_lds, downloaded: an undecodable point reads as "00"); same 7 + k challenges as k_rp_hash.
 namespace {
-void host_dec_append(std::string &out, U256 v) {
-  char buf[80];
-  int n = 0;
-  if (v.is_zero()) { out.push_back('0'); return; }
-  while (!v.is_zero()) {
-    uint64_t rem = 0;
-    v = bppp_rps::u_div64(v, 10000000000000000000ull, &rem);
-    const bool last = v.is_zero();
-    for (int k = 0; k < 19 && (rem || !last); k++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; }
-  }
-  while (n) out.push_back(buf[--n]);
-}
 U256 host_digest_to_fr(const uint32_t h[8]) {
   uint32_t v[8];
   sha256_digest_to_limbs(h, v);
@@ -768,20 +758,15 @@ U256 host_digest_to_fr(const uint32_t h[8]) {
   for (int i = 0; i < 4; i++) r.w[i] = ((uint64_t)v[2 * i + 1] << 32) | v[2 * i];
   return bppp_rps::u_mod_n(r);
 }
-// init [4 + nr][8], resp [2k][8] (u64 limbs as downloaded); ch_out [7][4], es_out [k][4]  (the weight rho_b is k_rp_rho's on both routes)
-// part 0: the seven challenges of verifyTRRPM; part 1: the k round challenges of verifyBPM
-void host_verifier_oracle(const bppp_rp *rp, const uint64_t *init, const uint64_t *resp, uint64_t *ch_out, uint64_t *es_out, int part) {
+// text / off: the proof's transcript text and the offsets of its points as k_rp_text_lds wrote them (downloaded); ch_out [7][4], es_out [k][4]
+// (the weight rho_b is k_rp_rho's on both routes).  part 0: the seven challenges of verifyTRRPM; part 1: the k round challenges of verifyBPM
+void host_verifier_oracle(const bppp_rp *rp, const uint8_t *text, const uint32_t *off, uint64_t *ch_out, uint64_t *es_out, int part) {
   const uint32_t k = rp->D.k, nr = rp->D.nr, nrp = rp->D.nrp, npts = 2 * k + nrp + nr;
-  std::vector<std::string> txt(npts);
-  for (uint32_t t = 0; t < npts; t++) {
-    const uint64_t *p = t < 2 * k ? resp + (size_t)t * 8 : init + (size_t)(t - 2 * k) * 8;
-    host_dec_append(txt[t], U256::load(p)); host_dec_append(txt[t], U256::load(p + 4));
-  }
   auto one = [&](uint32_t n, uint32_t count, uint32_t start, uint64_t *out) {
     Sha256 h;
     const std::string hdr = rp->tag + std::to_string(n) + std::to_string(count);
     h.update(hdr.data(), hdr.size());
-    for (uint32_t t = start; t < npts; t++) h.update(txt[t].data(), txt[t].size());
+    h.update(text + off[start], off[npts] - off[start]);
     uint32_t d[8];
     h.finish(d);
     host_digest_to_fr(d).store(out);
@@ -846,28 +831,46 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
   // async copies below target host vectors: whatever path leaves this function, the stream is drained before they are destroyed
   struct StreamDrain { hipStream_t s; ~StreamDrain() { hipStreamSynchronize(s); } };
   if (B <= host_oracle_max) {
-    std::vector<uint64_t> hi(B * ninit * 8), hr(B * 2 * k * 8 + 8), hch(B * 28), hes(B * k * 4 + 4);
-    StreamDrain drain{st};
-    BPPP_HIP(ctx, hipMemcpyAsync(hi.data(), init_pts, B * ninit * 64, hipMemcpyDeviceToHost, st));
-    if (k) BPPP_HIP(ctx, hipMemcpyAsync(hr.data(), resp_pts, B * 2 * k * 64, hipMemcpyDeviceToHost, st));
+    // the transcript text comes from the device (k_rp_text_lds: ~10 us against ~0.45 us per coordinate on a host core, 168 of them for 64by64)
+    const size_t tbytes = (B * (size_t)D.text_stride + 63) & ~(size_t)63, obytes = (B * (npts + 1) * 4 + 63) & ~(size_t)63, n_hch = B * 28, n_hes = B * k * 4 + 4;
+    const size_t hbytes = tbytes + obytes + (n_hch + n_hes) * 8;
+    if (hbytes > rp->hstage_bytes) {
+      if (rp->hstage) { BPPP_HIP(ctx, hipStreamSynchronize(st)); hipHostFree(rp->hstage); rp->hstage = nullptr; rp->hstage_bytes = 0; }
+      BPPP_HIP(ctx, hipHostMalloc((void **)&rp->hstage, hbytes, hipHostMallocDefault));
+      rp->hstage_bytes = hbytes;
+    }
+    uint8_t *htext = (uint8_t *)rp->hstage;
+    uint32_t *hoff = (uint32_t *)(htext + tbytes);
+    uint64_t *hch = (uint64_t *)(htext + tbytes + obytes), *hes = hch + n_hch;
+    const bool timing = rp->opt.timing;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = timing ? now() : 0;
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[rp_verify] %-24s %7.1f us\n", what, t - t_last); t_last = t; } };
+    if (rp_text_lds_bytes(D) <= 64 * 1024) k_rp_text_lds<<<dim3((unsigned)B), dim3(256), rp_text_lds_bytes(D), st>>>(D, init_pts, resp_pts, text, text_off);
+    else k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
+    BPPP_HIP(ctx, hipMemcpyAsync(hoff, text_off, B * (npts + 1) * 4, hipMemcpyDeviceToHost, st));
+    BPPP_HIP(ctx, hipMemcpyAsync(htext, text, B * (size_t)D.text_stride, hipMemcpyDeviceToHost, st));
     BPPP_HIP(ctx, hipStreamSynchronize(st));
+    lap("decode + download");
     // the seven challenges of verifyTRRPM first: k_trrp_public needs only those and runs while the host hashes the argument's rounds
     auto work = [&](size_t lo, size_t hi_, int part) {
-      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, &hi[b * ninit * 8], &hr[b * 2 * k * 8], &hch[b * 28], &hes[b * k * 4], part);
+      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, htext + b * (size_t)D.text_stride, hoff + b * (npts + 1), &hch[b * 28], &hes[b * k * 4], part);
     };
     auto all = [&](int part) {
-      if (B == 1) { work(0, 1, part); return; }        // ~0.2 ms per proof (168 decimal conversions, 16 hashes of ~11 KB): one thread per proof
+      if (B == 1) { work(0, 1, part); return; }        // ~0.1 ms per proof (15 hashes of ~11 KB): one thread per proof
       std::vector<std::thread> th;
       for (size_t b = 0; b < B; b++) th.emplace_back(work, b, b + 1, part);
       for (auto &x : th) x.join();
     };
     all(0);
-    BPPP_HIP(ctx, hipMemcpyAsync(ch, hch.data(), B * 7 * 32, hipMemcpyHostToDevice, st));
+    lap("host oracle, part 0");
+    BPPP_HIP(ctx, hipMemcpyAsync(ch, hch, B * 7 * 32, hipMemcpyHostToDevice, st));
     int rc0 = S.kind ? brp_public_device(rp, B, ch, q, sp, pub_norm, pub_lin_c, init_sc) : bppp_trrp_public_device(rp->tabs, B, ch, q, sp, pub_norm, pub_lin_c, init_sc);
     if (rc0) return rc0;
+    lap("launch of the scalars");
     all(1);
-    if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes.data(), B * k * 32, hipMemcpyHostToDevice, st));
-    BPPP_HIP(ctx, hipStreamSynchronize(st));          // the staging vectors go out of scope
+    lap("host oracle, part 1");
+    if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes, B * k * 32, hipMemcpyHostToDevice, st));       // (pinned staging: the next call's downloads are ordered behind this copy on the stream)
   } else {
     // transcript text, then the hashing in two halves: the seven challenges of verifyTRRPM on the call's stream, followed there by
     // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it.  Only while the

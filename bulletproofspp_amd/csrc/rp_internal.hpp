@@ -110,6 +110,7 @@ struct bppp_rp {
   bppp::CombTable *comb = nullptr; bool comb_owned = false, comb_failed = false; size_t proved_total = 0;
   uint32_t *d_comb_out = nullptr; size_t comb_out_rows = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
+  uint64_t *hstage = nullptr; size_t hstage_bytes = 0;   // pinned, grow-only: the host oracle's downloads and uploads (a pageable target makes every async copy a blocking one)
   uint32_t *hflag = nullptr;                     // pinned: the verifier's "some proof did not decode" word, copied out while the batch is still in flight
   void *work = nullptr; size_t work_bytes = 0;
   void *stage = nullptr; size_t stage_bytes = 0;
