@@ -524,14 +524,21 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint32_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// 0. ONE small MSM in ONE launch (n <= MSM_SMALL_MAX terms, one instance): the general pipeline is ~16 launches and four dependency
-// chains deep (0.30 ms for the 858-term MSM of a single range-proof verification, whatever the window); here one workgroup per window
-// does all of it — sign fold + digit of its window for every scalar, a counting sort of the entries in LDS, M = 2^(c-1) buckets with
-// 256 / M lanes each (a shuffle tree joins them), and the running-sum reduction sum (m + 1) B_m as a suffix scan + tree over M lanes.
-// c = 6: 43 workgroups, ~17 dependent point operations deep.  The window sums go to the host's Horner combine like the general path's.
-static constexpr uint32_t MSM_SMALL_MAX = 4096;
-__global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ points, uint32_t n, int c, RecodeK K,
-                                                   uint32_t *__restrict__ winsum) {
+// 0. ONE small MSM (a few thousand terms, one instance) in one or two launches: the general pipeline is ~16 launches and four dependency
+// chains deep (0.28 ms of kernels for the 858-term MSM of a single range-proof verification, whatever the window); here one workgroup per
+// (window, slice of the terms) does all of it — sign fold + digit of its window for every scalar of the slice, a counting sort of the
+// entries in LDS, M = 2^(c-1) buckets with 256 / M lanes each (a shuffle tree joins them), and the running-sum reduction sum (m + 1) B_m
+// as a suffix scan + tree over M lanes.  c = 6: 43 windows, ~17 dependent point operations deep (0.13 ms).  k_msm_small_join adds the
+// slices of a window (one wavefront per window); the window sums go to the host's Horner combine like the general path's.
+static constexpr uint32_t MSM_SMALL_MAX = 4096;            // terms per slice (LDS: 6 bytes each)
+static constexpr size_t MSM_SMALL_DEFAULT_MAX = 8192;      // terms per MSM on this route unless BPPP_MSM_SMALL_MAX says otherwise: every (window, slice) workgroup
+                                                           // pays the ~17-operation reduction chain with most lanes idle, so the general pipeline wins from ~2^14 terms
+                                                           // (benchmarks/sweep_small_msm.py: 858 terms 0.36 -> 0.21 ms, 4096 0.38 -> 0.27, 8192 0.40 -> 0.33, 22016 0.45 -> 0.43, 65536 0.52 -> 0.78)
+__global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ scalars_all, const uint32_t *__restrict__ points_all, uint32_t n_all, uint32_t slice_len,
+                                                   int c, RecodeK K, uint32_t *__restrict__ winsum) {
+  // slice blockIdx.y of the terms: its own bucket set, its own partial window sum (k_msm_small_join adds the slices of a window)
+  const uint32_t j0 = blockIdx.y * slice_len, n = min(slice_len, n_all - j0);
+  const uint32_t *scalars = scalars_all + (size_t)j0 * 8, *points = points_all + (size_t)j0 * 16;
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   const int M = 1 << (c - 1);
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
@@ -627,8 +634,23 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ 
       for (int q = 0; q < 6; q++) t = xyzz_dbl(t);                  // 64 T_j (nw <= 2: j = 1)
       xyzz_add(r, a); xyzz_add(r, t);
     }
-    xyzz_store(winsum + (size_t)w * XYZZ_WORDS, r);
+    xyzz_store(winsum + ((size_t)w * gridDim.y + blockIdx.y) * XYZZ_WORDS, r);
   }
+}
+// window w = the sum of its S slice partials: one wavefront per window
+__global__ void __launch_bounds__(64) k_msm_small_join(const uint32_t *__restrict__ partials, uint32_t S, uint32_t *__restrict__ winsum) {
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  xyzz acc = xyzz_inf();
+  for (uint32_t s_ = lane; s_ < S; s_ += 64) {
+    const xyzz p = xyzz_load(partials + ((size_t)w * S + s_) * XYZZ_WORDS);
+    if (s_ < 64) acc = p; else xyzz_add(acc, p);
+  }
+  uint32_t top = 1; while (top < S && top < 64) top <<= 1;
+  for (uint32_t dd = top >> 1; dd >= 1; dd >>= 1) {
+    const xyzz o = xyzz_shfl_down(acc, (int)dd);
+    if (lane + dd < 64) xyzz_add(acc, o);
+  }
+  if (lane == 0) xyzz_store(winsum + (size_t)w * XYZZ_WORDS, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -760,21 +782,28 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
   if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
   if (!d_scalars || !d_points) return fail(ctx, BPPP_ERR_ARG, "msm: null input");
   if (n >= (1ull << 31)) return fail(ctx, BPPP_ERR_ARG, "msm: n must be < 2^31");
-  // ---- one small MSM: the whole of it in one launch (k_msm_small), then the host's Horner combine over the W window sums
-  if (batch == 1 && !table_stride && !window_bits && n <= MSM_SMALL_MAX && !ctx->tune.no_small) {
+  // ---- one small or mid-size MSM: k_msm_small over (window, slice of <= 4096 terms) workgroups, the slices of a window joined by one
+  // wavefront each, then the host's Horner combine over the W window sums
+  const size_t small_max = ctx->tune.small_max ? (size_t)ctx->tune.small_max : MSM_SMALL_DEFAULT_MAX;
+  if (batch == 1 && !table_stride && !window_bits && n <= small_max && !ctx->tune.no_small) {
     const int c = ctx->tune.small_c >= 5 && ctx->tune.small_c <= 8 ? ctx->tune.small_c : 6, W = 256 / c + 1, M = 1 << (c - 1);
+    size_t len = ctx->tune.small_len >= 64 && ctx->tune.small_len <= (int)MSM_SMALL_MAX ? (size_t)ctx->tune.small_len : (n <= 2048 ? 512 : 1024);
+    if (n <= len + len / 2) len = n;                                  // a second slice has to pay for the join launch
+    const size_t S = (n + len - 1) / len;
     Carver cv0(nullptr, 0);
-    cv0.take<uint32_t>((size_t)W * XYZZ_WORDS);
+    cv0.take<uint32_t>((size_t)W * S * XYZZ_WORDS); cv0.take<uint32_t>((size_t)W * XYZZ_WORDS);
     int rc = ensure_workspace(ctx, cv0.off); if (rc) return rc;
     Carver cv(ctx->ws, ctx->ws_bytes);
-    uint32_t *winsum = cv.take<uint32_t>((size_t)W * XYZZ_WORDS);
+    uint32_t *partials = cv.take<uint32_t>((size_t)W * S * XYZZ_WORDS), *winsum = cv.take<uint32_t>((size_t)W * XYZZ_WORDS);
     const size_t bytes = (size_t)W * XYZZ_WORDS * 4;
     rc = ensure_pinned(ctx, bytes); if (rc) return rc;
     hipStream_t st = ctx->stream;
     for (int i = 0; i <= 2; i++) prof_mark(ctx, i);
     if (ctx->pre_acc) { auto f = ctx->pre_acc; ctx->pre_acc = nullptr; int rc_ = f(ctx->pre_acc_arg); if (rc_) return rc_; }
-    const size_t lds = (size_t)(2 * M + 1) * 4 + n * 4 + n * 2 + 16 + (size_t)(M + 4) * XYZZ_WORDS * 4;
-    k_msm_small<<<dim3((unsigned)W), dim3(256), lds, st>>>((const uint32_t *)d_scalars, (const uint32_t *)d_points, (uint32_t)n, c, make_recode_k(c, W), winsum);
+    const size_t lds = (((size_t)(2 * M + 1) + len + (len + 1) / 2 + 3) & ~(size_t)3) * 4 + (size_t)(M + 4) * XYZZ_WORDS * 4;
+    k_msm_small<<<dim3((unsigned)W, (unsigned)S), dim3(256), lds, st>>>((const uint32_t *)d_scalars, (const uint32_t *)d_points, (uint32_t)n, (uint32_t)len, c,
+                                                                       make_recode_k(c, W), S > 1 ? partials : winsum);
+    if (S > 1) k_msm_small_join<<<dim3((unsigned)W), dim3(64), 0, st>>>(partials, (uint32_t)S, winsum);
     for (int i = 3; i <= 5; i++) prof_mark(ctx, i);
     BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
     prof_mark(ctx, 6);

@@ -486,7 +486,7 @@ static int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint
 
 void RpOptions::from_env() {
   auto num = [](const char *name, size_t &dst) { if (const char *e = getenv(name)) dst = (size_t)atol(e); };
-  num("BPPP_RP_COMB_MIN", comb_min); num("BPPP_RP_SPLIT_MIN", split_min);
+  num("BPPP_RP_COMB_MIN", comb_min); num("BPPP_RP_SPLIT_MIN", split_min); num("BPPP_RP_HASH_FORK_MAX", hash_fork_max);
   if (const char *e = getenv("BPPP_RP_COMB_GB")) comb_budget = (size_t)std::max(1, atoi(e)) << 30;
   if (const char *e = getenv("BPPP_RP_COMB_BITS")) comb_bits = atoi(e);
   if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_verify = host_oracle_prove = (size_t)atol(e);
@@ -510,6 +510,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->stage) hipFree(rp->stage);
   if (rp->hflag) hipHostFree(rp->hflag);
   if (rp->hstage) hipHostFree(rp->hstage);
+  delete rp->pool;
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
@@ -853,14 +854,11 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     BPPP_HIP(ctx, hipStreamSynchronize(st));
     lap("decode + download");
     // the seven challenges of verifyTRRPM first: k_trrp_public needs only those and runs while the host hashes the argument's rounds
-    auto work = [&](size_t lo, size_t hi_, int part) {
-      for (size_t b = lo; b < hi_; b++) host_verifier_oracle(rp, htext + b * (size_t)D.text_stride, hoff + b * (npts + 1), &hch[b * 28], &hes[b * k * 4], part);
-    };
+    // one proof per item: the calling thread alone for one proof, else with the handle's pool (a std::thread per proof costs more than its 36 us of hashing)
+    if (B > 1 && !rp->pool) rp->pool = new bppp::HostPool((unsigned)std::min<size_t>(host_oracle_max, 16) - 1);
     auto all = [&](int part) {
-      if (B == 1) { work(0, 1, part); return; }        // ~0.1 ms per proof (15 hashes of ~11 KB): one thread per proof
-      std::vector<std::thread> th;
-      for (size_t b = 0; b < B; b++) th.emplace_back(work, b, b + 1, part);
-      for (auto &x : th) x.join();
+      const std::function<void(size_t)> f = [&](size_t b) { host_verifier_oracle(rp, htext + b * (size_t)D.text_stride, hoff + b * (npts + 1), &hch[b * 28], &hes[b * k * 4], part); };
+      if (B == 1) f(0); else rp->pool->run(B, f);
     };
     all(0);
     lap("host oracle, part 0");
@@ -880,7 +878,7 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     else k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
     const uint32_t nch = D.nch, nes = rp->nhash - D.nch;
     hipStream_t aux = st;
-    const bool fork = nes && B <= 1024;
+    const bool fork = nes && B <= rp->opt.hash_fork_max;
     if (fork) {
       int rca = ctx_aux(ctx); if (rca) return rca;
       aux = ctx->aux_stream;

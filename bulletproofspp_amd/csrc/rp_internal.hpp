@@ -7,6 +7,7 @@
 #include "ctx.hpp"
 #include "hostmath.hpp"
 #include "rpsetup.hpp"
+#include "hostpool.hpp"
 
 struct bppp_trrp;
 struct bppp_nlb;
@@ -73,6 +74,7 @@ struct RpOptions {
   bool no_split = false;              // BPPP_RP_NO_SPLIT
   size_t host_oracle_verify = 8;      // BPPP_RP_HOST_ORACLE_MAX: largest batch whose transcript hashing runs on the host (verifier)
   size_t host_oracle_prove = 64;      //                          ... (prover)
+  size_t hash_fork_max = 64;          // BPPP_RP_HASH_FORK_MAX: largest batch whose two hashing halves run side by side on two streams (verifier)
   bool fold_points = false;           // BPPP_NLB_FOLD_POINTS: point-folding argument although a table exists
   bool host_algebra = false;          // BPPP_RP_HOST_ALGEBRA: field algebra and hashing of the prover on the host
   bool timing = false;                // BPPP_RP_TIMING: phase times on stderr
@@ -110,6 +112,7 @@ struct bppp_rp {
   bppp::CombTable *comb = nullptr; bool comb_owned = false, comb_failed = false; size_t proved_total = 0;
   uint32_t *d_comb_out = nullptr; size_t comb_out_rows = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
+  bppp::HostPool *pool = nullptr;                // workers of the host oracle (batches of 2 .. host_oracle_verify proofs), made on first use
   uint64_t *hstage = nullptr; size_t hstage_bytes = 0;   // pinned, grow-only: the host oracle's downloads and uploads (a pageable target makes every async copy a blocking one)
   uint32_t *hflag = nullptr;                     // pinned: the verifier's "some proof did not decode" word, copied out while the batch is still in flight
   void *work = nullptr; size_t work_bytes = 0;

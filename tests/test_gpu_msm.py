@@ -214,16 +214,18 @@ def test_new_entry_points_reject_bad_arguments(gpu):
     assert lib.bppp_trrp_public_device(None, 1, None, None, None, None, None, None) != 0
 
 
-@pytest.mark.parametrize("env", [{}, {"BPPP_MSM_SMALL_C": "5"}, {"BPPP_MSM_SMALL_C": "7"}, {"BPPP_MSM_SMALL_C": "8"}, {"BPPP_MSM_NO_SMALL": "1"}])
+@pytest.mark.parametrize("env", [{}, {"BPPP_MSM_SMALL_C": "5"}, {"BPPP_MSM_SMALL_C": "7"}, {"BPPP_MSM_SMALL_C": "8", "BPPP_MSM_SMALL_LEN": "4096"},
+                                 {"BPPP_MSM_SMALL_LEN": "64"}, {"BPPP_MSM_NO_SMALL": "1"}])
 def test_single_launch_small_msm(gpu, oracle_lib, env, monkeypatch):
-    """One instance of <= 4096 terms runs as ONE launch (k_msm_small: a workgroup per window); every window width it takes, its size
-    limit and the general pipeline it replaces must give the oracle's point, on random and on degenerate inputs."""
+    """One instance of <= 8192 terms runs on k_msm_small (a workgroup per window and slice of the terms, joined by k_msm_small_join): every
+    window width and slice length it takes, its size limit and the general pipeline it replaces must give the oracle's point, on random
+    and on degenerate inputs."""
     import bulletproofspp_amd as b
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     ctx = b.Bppp(0)                      # tuning variables are read when a context is made
     try:
-        for n, seed in [(1, 1), (31, 2), (858, 3), (4096, 4), (4097, 5)]:
+        for n, seed in [(1, 1), (31, 2), (767, 6), (769, 7), (858, 3), (4096, 4), (4097, 5), (8192, 8), (8193, 9)]:
             sc, pts = _rand_case(n, 7000 + seed, zero_every=9, inf_every=14)
             assert ctx.msm(scalars_to_array(sc), points_to_array(pts)) == oracle_lib.inner_product(list(zip(sc, pts)))
         G = (O.GX, O.GY)
