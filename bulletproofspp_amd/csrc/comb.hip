@@ -68,11 +68,13 @@ BPPP_DI aff comb_aff(const CombRaw &r, bool neg) {
 // launch dispatches all heavy ones first, so the light ones fill the slots that free up instead of leaving a tail of heavy ones
 template <int WPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_comb_msm(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
-                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, int heavy_first, uint32_t parts, uint32_t *__restrict__ partial,
-                                                 uint32_t *__restrict__ out) {
-  // parts > 1 (few instances): `parts` wavefronts share one instance — wavefront p takes the term groups p, p + parts, ... — and leave
-  // their sums in `partial` for k_comb_join; otherwise one wavefront per instance writes the result
-  const uint32_t lane = threadIdx.x, half = ninst >> 1, blk = blockIdx.x / parts, part = blockIdx.x % parts;
+                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, int heavy_first, uint32_t parts, uint32_t tparts, int wlen,
+                                                 uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
+  // parts > 1 (few instances): `parts` = tparts x (window ranges of wlen windows) wavefronts share one instance — wavefront (tp, wr) takes the
+  // term groups tp, tp + tparts, ... and of each term only the digits of windows [wr wlen, wr wlen + wlen) — and leave their sums in
+  // `partial` for k_comb_join; otherwise one wavefront per instance writes the result
+  const uint32_t lane = threadIdx.x, half = ninst >> 1, blk = blockIdx.x / parts, part = blockIdx.x % parts, tpart = part % tparts;
+  const int w0 = (int)(part / tparts) * wlen, w1 = min(W, w0 + wlen);
   const uint32_t inst = !heavy_first ? blk : blk < half ? 2 * blk : 2 * (blk - half) + 1;
   const uint32_t mask = (1u << c) - 1u;
   const uint32_t *sc = scalars + (size_t)inst * nterms * 8;       // the first nterms <= T registered points
@@ -83,16 +85,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   // zero moves straight on to its next non-zero one instead of idling through the other lanes' 20 digit steps.  With vectors whose
   // zeros follow a power-of-two pattern in the index (the argument's R scalars vanish on every left half) every lane then has the
   // same share, and the wavefront of such an instance takes half the steps.
-  uint32_t k0 = 64u * part, k = part, sp[9];
-  int w = W;                                                   // w == W: this lane needs its next term
+  uint32_t k0 = 64u * tpart, k = tpart, sp[9];
+  int w = w1;                                                  // w == w1: this lane needs its next term
   bool neg = false, live = true;
   const uint32_t *ti = tab;
   while (__any(live)) {
-    if (live && w == W) {
+    if (live && w == w1) {
       live = false;
       while (k0 < nterms) {
         const uint32_t i = k0 + ((lane + 21u * k) & 63u);
-        k0 += 64u * parts; k += parts;
+        k0 += 64u * tparts; k += tparts;
         if (i >= nterms) continue;
         const fe s = fe_load(sc + (size_t)i * 8);
         if (fe_is_zero(s)) continue;
@@ -103,8 +105,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
         for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
         sp[8] = (uint32_t)cy + K.k[8];
+        for (int j = 0; j < w0; j++) {                          // skip the windows of the other ranges
+#pragma unroll
+          for (int q = 0; q < 8; q++) sp[q] = (sp[q] >> c) | (sp[q + 1] << (32 - c));
+          sp[8] >>= c;
+        }
         ti = tab + (size_t)i * D * 16;
-        w = 0; live = true;
+        w = w0; live = true;
         break;
       }
     }
@@ -177,7 +184,8 @@ __global__ void __launch_bounds__(64) k_comb_lanes(const uint32_t *__restrict__ 
 __global__ void __launch_bounds__(64) k_comb_join(const uint32_t *__restrict__ partial, uint32_t parts, uint32_t *__restrict__ out) {
   const uint32_t inst = blockIdx.x, lane = threadIdx.x;
   xyzz acc = lane < parts ? xyzz_load(partial + ((size_t)inst * parts + lane) * XYZZ_WORDS) : xyzz_inf();
-  for (int dd = 32; dd >= 1; dd >>= 1) {
+  int top = 1; while (top < (int)parts) top <<= 1;               // parts <= 64
+  for (int dd = top >> 1; dd >= 1; dd >>= 1) {
     xyzz o = xyzz_shfl_down(acc, dd);
     if ((int)lane + dd < 64) xyzz_add(acc, o);
   }
@@ -241,15 +249,24 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   const int wpe = t->ctx->tune.comb_wpe ? t->ctx->tune.comb_wpe : 2;
   // few instances: several wavefronts per instance (up to one per group of 64 terms), so that a launch is ~1024 wavefronts wide and
   // its depth is a few additions instead of nterms / 64 x W; needs the caller's scratch for the partial sums
-  uint32_t parts = 1;
+  // (a handful of instances — one proof's X and R — also split each term's W digits over window ranges: 17 + 6 chained additions
+  // become 5 + 6, the join one level deeper)
+  uint32_t tparts = 1, wsplit = 1;
   const uint32_t groups = (uint32_t)((nterms + 63) / 64);
   if (d_scratch && ninst < 1024 && groups > 1) {
-    parts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((1024 + ninst - 1) / ninst));
-    while (parts > 1 && (size_t)ninst * parts * XYZZ_WORDS * 4 > scratch_bytes) parts--;
+    tparts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((1024 + ninst - 1) / ninst));
+    while (tparts > 1 && (size_t)ninst * tparts * XYZZ_WORDS * 4 > scratch_bytes) tparts--;
+    if (tparts == groups && !t->ctx->tune.comb_no_wsplit) {
+      wsplit = std::min<uint32_t>(std::min<uint32_t>(64u / tparts, 4u), (uint32_t)(1024 / (ninst * tparts)));
+      while (wsplit > 1 && (size_t)ninst * tparts * wsplit * XYZZ_WORDS * 4 > scratch_bytes) wsplit--;
+      if (wsplit < 1) wsplit = 1;
+    }
   }
+  const uint32_t parts = tparts * wsplit;
+  const int wlen = (t->W + (int)wsplit - 1) / (int)wsplit;
   const dim3 grid((unsigned)(ninst * parts)), block(64);
   const int hf = (heavy_first && !(ninst & 1)) ? 1 : 0;
-#define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, hf, parts, d_scratch, d_out_aff)
+#define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, hf, parts, tparts, wlen, d_scratch, d_out_aff)
   if (wpe <= 2) COMB_LAUNCH(2); else COMB_LAUNCH(3);
 #undef COMB_LAUNCH
   if (parts > 1) k_comb_join<<<dim3((unsigned)ninst), dim3(64), 0, st>>>(d_scratch, parts, d_out_aff);
