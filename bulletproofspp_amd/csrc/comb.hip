@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   // zero moves straight on to its next non-zero one instead of idling through the other lanes' 20 digit steps.  With vectors whose
   // zeros follow a power-of-two pattern in the index (the argument's R scalars vanish on every left half) every lane then has the
   // same share, and the wavefront of such an instance takes half the steps.
-  uint32_t k0 = 64u * tpart, k = tpart, sp[9];
+  uint32_t k0 = w0 < W ? 64u * tpart : nterms, k = tpart, sp[9];      // (an empty window range: nothing to do)
   int w = w1;                                                  // w == w1: this lane needs its next term
   bool neg = false, live = true;
   const uint32_t *ti = tab;

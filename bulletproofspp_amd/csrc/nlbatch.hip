@@ -11,9 +11,11 @@
 // One MSM of (nlen + llen + 1) + B*(ninit + 2k) terms then decides all B proofs: it is infinity iff every
 // proof verifies (up to the 2^-256 soundness slack of the random combination).
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "ctx.hpp"
 #include "fe.hip.h"
+#include "fr26.hip.h"
 #include "modinv.hip.h"
 #include "hostmath.hpp"
 
@@ -71,41 +73,44 @@ __global__ void __launch_bounds__(256) k_vb_shared1(const uint32_t *__restrict__
 __global__ void __launch_bounds__(64) k_vb_shared4(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
                                                    uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
                                                    uint32_t *__restrict__ partial) {
+  // Fr in 10 x 26-bit limbs (fr26.hip.h: 413 instructions per multiplication against 785): values are canonical 8 x 32 in memory,
+  // converted once on load; the accumulators stay lazily reduced (magnitude 3 per proof) until the store
   const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, kt = blockIdx.y;
   if (i0 >= len) return;
-  fe a0 = fe_zero(), a1 = a0, a2 = a0, a3 = a0;          // named scalars, not arrays: arrays of fe end up in scratch here
+  fr a0 = fr_zero(), a1 = a0, a2 = a0, a3 = a0;          // named scalars, not arrays: arrays of field elements end up in scratch here
   uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
   for (uint32_t b = b0; b < b1; b++) {
     const uint32_t *f = fac + (size_t)b * 2 * k * 8;
-    const fe r = fe_load(rho + (size_t)b * 8);
-    fe t0 = fe_zero(), t1 = t0, t2 = t0, t3 = t0;
+    const fr r = fr_load(rho + (size_t)b * 8);
+    fr t0 = fr_zero(), t1 = t0, t2 = t0, t3 = t0;
     const uint32_t *pb = pub + ((size_t)b * len + i0) * 8;
-    const fe p0 = fe_load(pb), p1 = i0 + 1 < len ? fe_load(pb + 8) : fe_zero(), p2 = i0 + 2 < len ? fe_load(pb + 16) : fe_zero(),
-             p3 = i0 + 3 < len ? fe_load(pb + 24) : fe_zero();
+    const fr p0 = fr_load(pb), p1 = i0 + 1 < len ? fr_load(pb + 8) : fr_zero(), p2 = i0 + 2 < len ? fr_load(pb + 16) : fr_zero(),
+             p3 = i0 + 3 < len ? fr_load(pb + 24) : fr_zero();
     uint32_t hi = i0 >> k;
     if (hi < nvs) {                                        // zipWithDef' default 0 beyond the tensor (src/Utils.hs:182-184)
       // every load of this proof is issued before the first multiplication (the factor of round rr is e or q by the bit of i0:
       // the address is computed, not branched on), so the wavefront waits for memory once per proof instead of once per factor
-      const fe w0 = fe_load(wit + ((size_t)b * nvs + hi) * 8);
-      const fe e0 = fe_load(f + (size_t)k * 8), q0 = fe_load(f), e1 = fe_load(f + (size_t)(k + 1) * 8), q1 = fe_load(f + 8);
-      fe base = frm(r, w0);
+      const fr w0 = fr_load(wit + ((size_t)b * nvs + hi) * 8);
+      const fr e0 = fr_load(f + (size_t)k * 8), q0 = fr_load(f), e1 = fr_load(f + (size_t)(k + 1) * 8), q1 = fr_load(f + 8);
+      fr base = fr_mul(r, w0);
       for (int rr = 2; rr < k; rr++) {
         const bool bit = (i0 >> rr) & 1u;
-        if (bit || use_q) base = frm(base, fe_load(f + (size_t)((bit ? k : 0) + rr) * 8));
+        if (bit || use_q) base = fr_mul(base, fr_load(f + (size_t)((bit ? k : 0) + rr) * 8));
       }
       t0 = base;
-      t1 = frm(e0, t0); if (use_q) t0 = frm(q0, t0);
-      t2 = frm(e1, t0); t3 = frm(e1, t1); if (use_q) { t0 = frm(q1, t0); t1 = frm(q1, t1); }
+      t1 = fr_mul(e0, t0); if (use_q) t0 = fr_mul(q0, t0);
+      t2 = fr_mul(e1, t0); t3 = fr_mul(e1, t1); if (use_q) { t0 = fr_mul(q1, t0); t1 = fr_mul(q1, t1); }
     }
-#define VB_ACC(O, A, P, T) if (i0 + (O) < len) A = fe_add<1>(A, fe_sub<1>(frm(r, P), T));
+#define VB_ACC(O, A, P, T) if (i0 + (O) < len) A = fr_add(A, fr_sub<1>(fr_mul(r, P), T));       /* KT = 2 proofs: magnitude <= 6 */
     VB_ACC(0, a0, p0, t0) VB_ACC(1, a1, p1, t1) VB_ACC(2, a2, p2, t2) VB_ACC(3, a3, p3, t3)
 #undef VB_ACC
   }
   uint32_t *po = partial + ((size_t)kt * len + i0) * 8;
-#define VB_ST(O, A) if (i0 + (O) < len) fe_store(po + (O) * 8, A);
+#define VB_ST(O, A) if (i0 + (O) < len) fr_store(po + (O) * 8, A);
   VB_ST(0, a0) VB_ST(1, a1) VB_ST(2, a2) VB_ST(3, a3)
 #undef VB_ST
 }
+static_assert(KT * 3 <= 16, "k_vb_shared4: the accumulators' magnitude must stay within fr_normalize's range");
 
 // column sums of partial[ntiles][len]: block (x, y) adds the tiles [y*per, (y+1)*per) of 64 columns (its 4 wavefronts take
 // every 4th tile) into out[y][len].  Called twice: ntiles -> SUM_GROUPS rows -> 1 row; a single pass over all tiles had only
@@ -128,54 +133,78 @@ __global__ void __launch_bounds__(256) k_vb_sum_partials(const uint32_t *__restr
   }
 }
 
-// per proof: gs[b] = rho_b * (sp_b - sc_b), sc_b = sum_i (qF^2)^(i+1) vs_i^2 + sum_j c_j * tensor_lin[j]
-// (NormArgument.hs:135, :76-78), and the per-proof tail scalars rho_b * [init..., e_r, e_r^2 - 1 ...]
-__global__ void __launch_bounds__(256) k_vb_proof(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ sp, const uint32_t *__restrict__ qf2,
-                                                  const uint32_t *__restrict__ wit_norm, uint32_t fn, const uint32_t *__restrict__ wit_lin, uint32_t fl,
-                                                  const uint32_t *__restrict__ pub_c, uint32_t llen, const uint32_t *__restrict__ fac, int k,
-                                                  const uint32_t *__restrict__ init_sc, uint32_t ninit, const uint32_t *__restrict__ es,
-                                                  uint32_t *__restrict__ gs, uint32_t *__restrict__ tail) {
-  __shared__ uint32_t lds[256 * 8];
-  const uint32_t b = blockIdx.x, t = threadIdx.x;
+// sum_j c_j tensor'(wit_lin, es)[j] of every proof (NormArgument.hs:76-78; tensor': src/Bulletproof.hs:94-95, zero beyond it), first
+// half: lane (b, g) sums the four consecutive positions 4g .. 4g + 3, which share the factors of rounds >= 2 (as k_vb_shared4): llen = 261
+// is 66 lanes x 11 multiplications per proof, packed densely over the batch (a block per proof left three of its four wavefronts idle)
+__global__ void __launch_bounds__(256) k_vb_lin_partial(const uint32_t *__restrict__ wit_lin, uint32_t fl, const uint32_t *__restrict__ pub_c, uint32_t llen,
+                                                        const uint32_t *__restrict__ fac, int k, uint32_t batch, uint32_t G4, uint32_t *__restrict__ partial) {
+  const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (uint64_t)batch * G4) return;
+  const uint32_t b = (uint32_t)(idx / G4), j0 = 4u * (uint32_t)(idx % G4);
   const uint32_t *f = fac + (size_t)b * 2 * k * 8;
-  fe r = fe_load(rho + (size_t)b * 8);
+  fr acc = fr_zero();
+  if (k >= 2) {
+    const uint32_t hi = j0 >> k;
+    if (hi < fl) {
+      const uint32_t *pc = pub_c + ((size_t)b * llen + j0) * 8;
+      fr base = fr_load(wit_lin + ((size_t)b * fl + hi) * 8);
+      const fr e0 = fr_load(f + (size_t)k * 8), e1 = fr_load(f + (size_t)(k + 1) * 8);
+      const fr c0 = fr_load(pc), c1 = j0 + 1 < llen ? fr_load(pc + 8) : fr_zero(), c2 = j0 + 2 < llen ? fr_load(pc + 16) : fr_zero(),
+               c3 = j0 + 3 < llen ? fr_load(pc + 24) : fr_zero();
+      for (int rr = 2; rr < k; rr++) if ((j0 >> rr) & 1u) base = fr_mul(base, fr_load(f + (size_t)(k + rr) * 8));
+      const fr t1 = fr_mul(e0, base), t2 = fr_mul(e1, base), t3 = fr_mul(e1, t1);
+      acc = fr_add(fr_add(fr_mul(c0, base), fr_mul(c1, t1)), fr_add(fr_mul(c2, t2), fr_mul(c3, t3)));       // magnitude 4
+    }
+  } else {
+    for (uint32_t j = j0; j < min(llen, j0 + 4); j++) {     // k < 2: position by position (the tensor index differs inside the group)
+      const uint32_t h2 = j >> k;
+      if (h2 >= fl) continue;
+      fr tl = fr_load(wit_lin + ((size_t)b * fl + h2) * 8);
+      if (k == 1 && (j & 1u)) tl = fr_mul(tl, fr_load(f + (size_t)k * 8));
+      acc = fr_add(acc, fr_mul(fr_load(pub_c + ((size_t)b * llen + j) * 8), tl));
+    }
+  }
+  fr_store(partial + idx * 8, acc);
+}
+BPPP_DI fe fe_shfl_down(const fe &a, int d) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d, 64);
+  return r;
+}
+// second half, one wavefront per proof: gs[b] = rho_b * (sp_b - sc_b), sc_b = sum_i (qF^2)^(i+1) vs_i^2 + the sum above
+// (NormArgument.hs:135, :76-78), and the per-proof tail scalars rho_b * [init..., e_r, e_r^2 - 1 ...]
+__global__ void __launch_bounds__(64) k_vb_proof(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ sp, const uint32_t *__restrict__ qf2,
+                                                 const uint32_t *__restrict__ wit_norm, uint32_t fn, const uint32_t *__restrict__ partial, uint32_t G4, int k,
+                                                 const uint32_t *__restrict__ init_sc, uint32_t ninit, const uint32_t *__restrict__ es,
+                                                 uint32_t *__restrict__ gs, uint32_t *__restrict__ tail) {
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  const fr r26 = fr_load(rho + (size_t)b * 8);
   fe acc = fe_zero();
-  for (uint32_t j = t; j < llen; j += 256) {
-    fe tl = tensor_at(wit_lin + (size_t)b * fl * 8, fl, f, k, j, false);
-    acc = fe_add<1>(acc, fe_mul<1>(fe_load(pub_c + ((size_t)b * llen + j) * 8), tl));
-  }
-  for (int i = 0; i < 8; i++) lds[t * 8 + i] = acc.v[i];
-  __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
-    if ((int)t < d) {
-      fe x, y;
-      for (int i = 0; i < 8; i++) { x.v[i] = lds[t * 8 + i]; y.v[i] = lds[(t + d) * 8 + i]; }
-      x = fe_add<1>(x, y);
-      for (int i = 0; i < 8; i++) lds[t * 8 + i] = x.v[i];
-    }
-    __syncthreads();
-  }
+  for (uint32_t g = t; g < G4; g += 64) acc = fe_add<1>(acc, fe_load(partial + ((size_t)b * G4 + g) * 8));
+  for (int d = 32; d >= 1; d >>= 1) acc = fe_add<1>(acc, fe_shfl_down(acc, d));       // lane 0 ends with the sum of all 64
   if (t == 0) {
-    fe sc; for (int i = 0; i < 8; i++) sc.v[i] = lds[i];
-    fe q2 = fe_load(qf2 + (size_t)b * 8), w = q2;
+    fr sc = fr_from_fe(acc);
+    const fr q2 = fr_load(qf2 + (size_t)b * 8);
+    fr w = q2;
     for (uint32_t i = 0; i < fn; i++) {
-      fe v = fe_load(wit_norm + ((size_t)b * fn + i) * 8);
-      sc = fe_add<1>(sc, fe_mul<1>(w, fe_sqr<1>(v)));
-      w = fe_mul<1>(w, q2);
+      const fr v = fr_load(wit_norm + ((size_t)b * fn + i) * 8);
+      sc = fr_addr(sc, fr_mul(w, fr_sqr(v)));
+      w = fr_mul(w, q2);
     }
-    fe_store(gs + (size_t)b * 8, fe_mul<1>(r, fe_sub<1>(fe_load(sp + (size_t)b * 8), sc)));
+    fr_store(gs + (size_t)b * 8, fr_mul(r26, fr_sub<1>(fr_load(sp + (size_t)b * 8), sc)));
   }
   // tail: ninit init scalars then (e, e^2 - 1) per response, in the order the responses are stored
   uint32_t per = ninit + 2 * (uint32_t)k;
-  for (uint32_t m = t; m < per; m += 256) {
-    fe v;
-    if (m < ninit) v = fe_load(init_sc + ((size_t)b * ninit + m) * 8);
+  for (uint32_t m = t; m < per; m += 64) {
+    fr v;
+    if (m < ninit) v = fr_load(init_sc + ((size_t)b * ninit + m) * 8);
     else {
       uint32_t rr = (m - ninit) >> 1;
-      fe e = fe_load(es + ((size_t)b * k + rr) * 8);
-      v = ((m - ninit) & 1u) ? fe_sub<1>(fe_sqr<1>(e), fe_one()) : e;      // makeEs e = (e, e^2 - 1) (NormArgument.hs:109)
+      const fr e = fr_load(es + ((size_t)b * k + rr) * 8);
+      v = ((m - ninit) & 1u) ? fr_sub<1>(fr_sqr(e), fr_one()) : e;         // makeEs e = (e, e^2 - 1) (NormArgument.hs:109)
     }
-    fe_store(tail + ((size_t)b * per + m) * 8, fe_mul<1>(r, v));
+    fr_store(tail + ((size_t)b * per + m) * 8, fr_mul(r26, v));
   }
 }
 __global__ void __launch_bounds__(256) k_vb_sum_gs(const uint32_t *__restrict__ gs, uint32_t batch, uint32_t *__restrict__ out) {
@@ -381,11 +410,12 @@ int nl_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
   const size_t per = ninit + 2 * k, shared = nlen + llen + 1, T = shared + batch * per;
   const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
   const size_t maxlen = nlen > llen ? nlen : llen;
+  const size_t npartial = std::max((size_t)ntiles * maxlen, batch * ((llen + 3) / 4));      // the tile sums, then k_vb_lin_partial's group sums
   // scratch (separate from the MSM workspace, which msm_run carves from ctx->ws)
-  size_t words = (batch * 2 * (k ? k : 1) + batch + (size_t)ntiles * maxlen + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16 + 64;
+  size_t words = (batch * 2 * (k ? k : 1) + batch + npartial + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16 + 64;
   { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
   uint32_t *buf = (uint32_t *)ctx->ws2;
-  uint32_t *fac = buf, *qf2 = fac + batch * 2 * (k ? k : 1) * 8, *partial = qf2 + batch * 8, *partial2 = partial + (size_t)ntiles * maxlen * 8, *gs = partial2 + (size_t)SUM_GROUPS * maxlen * 8,
+  uint32_t *fac = buf, *qf2 = fac + batch * 2 * (k ? k : 1) * 8, *partial = qf2 + batch * 8, *partial2 = partial + npartial * 8, *gs = partial2 + (size_t)SUM_GROUPS * maxlen * 8,
            *sc = gs + batch * 8, *pts = sc + (T + 32) * 8, *flags = pts + T * 16;
   int rc = BPPP_OK;
   do {
@@ -418,9 +448,11 @@ int nl_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
         k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, per, (uint32_t)llen, partial2);
         k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)llen, sc + nlen * 8); }
     }
-    k_vb_proof<<<dim3((unsigned)batch), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf2, (const uint32_t *)d_wit_norm, (uint32_t)fn,
-                                                            (const uint32_t *)d_wit_lin, (uint32_t)fl, (const uint32_t *)d_pub_lin_c, (uint32_t)llen, fac, (int)k,
-                                                            (const uint32_t *)d_init_scalars, (uint32_t)ninit, (const uint32_t *)d_es, gs, sc + shared * 8);
+    const uint32_t G4 = (uint32_t)((llen + 3) / 4);                 // (the partial-sum buffer is free again: at most llen / 4 of its maxlen / 2 words per proof)
+    if (G4) k_vb_lin_partial<<<dim3((unsigned)(((uint64_t)batch * G4 + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_wit_lin, (uint32_t)fl, (const uint32_t *)d_pub_lin_c,
+                                                                                                      (uint32_t)llen, fac, (int)k, (uint32_t)batch, G4, partial);
+    k_vb_proof<<<dim3((unsigned)batch), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf2, (const uint32_t *)d_wit_norm, (uint32_t)fn, partial, G4, (int)k,
+                                                           (const uint32_t *)d_init_scalars, (uint32_t)ninit, (const uint32_t *)d_es, gs, sc + shared * 8);
     k_vb_sum_gs<<<dim3(1), dim3(256), 0, st>>>(gs, (uint32_t)batch, sc + (nlen + llen) * 8);
     // points: [G | H | g | per proof: init points, responses]
     k_vb_gather_points<<<dim3((unsigned)((4 * T + 255) / 256)), dim3(256), 0, st>>>((const uint4 *)d_norm_g_xy, (uint32_t)nlen, (const uint4 *)d_lin_h_xy, (uint32_t)llen,
