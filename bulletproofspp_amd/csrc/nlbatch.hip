@@ -338,51 +338,46 @@ __global__ void __launch_bounds__(256) k_ipvb_norm(const uint32_t *__restrict__ 
   fe_store(partial + ((size_t)kt * nlen + i) * 8, acc);
 }
 // per proof: gs[b] = rho_b (sp_b - sc_b) and the tail scalars rho_b [init ..., 1 / e_r, e_r ...] in the order the responses are stored
-__global__ void __launch_bounds__(256) k_ipvb_proof(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ sp, const uint32_t *__restrict__ qf,
-                                                    const uint32_t *__restrict__ v, uint32_t fm, const uint32_t *__restrict__ wit_lin, uint32_t fl,
-                                                    const uint32_t *__restrict__ pub_c, uint32_t llen, const uint32_t *__restrict__ facx, int k,
-                                                    const uint32_t *__restrict__ init_sc, uint32_t ninit, const uint32_t *__restrict__ es,
-                                                    uint32_t *__restrict__ gs, uint32_t *__restrict__ tail) {
-  __shared__ uint32_t lds[256 * 8];
+__global__ void __launch_bounds__(64) k_ipvb_proof(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ sp, const uint32_t *__restrict__ qf,
+                                                   const uint32_t *__restrict__ v, uint32_t fm, const uint32_t *__restrict__ wit_lin, uint32_t fl,
+                                                   const uint32_t *__restrict__ pub_c, uint32_t llen, const uint32_t *__restrict__ facx, int k,
+                                                   const uint32_t *__restrict__ init_sc, uint32_t ninit, const uint32_t *__restrict__ es,
+                                                   uint32_t *__restrict__ gs, uint32_t *__restrict__ tail) {
+  // one wavefront per proof (the vectors of a single 64-bit proof are a handful of elements: a 256-thread block with an LDS tree was
+  // eight barriers around four mostly idle wavefronts); Fr in 10 x 26-bit limbs
   const uint32_t b = blockIdx.x, t = threadIdx.x;
   const uint32_t *f = facx + (size_t)b * 2 * k * 8;
-  const fe r = fe_load(rho + (size_t)b * 8);
-  fe acc = fe_zero();
-  for (uint32_t j = t; j < llen; j += 256) {
-    const fe tl = tensor_at(wit_lin + (size_t)b * fl * 8, fl, f, k, j, false);
-    acc = fe_add<1>(acc, fe_mul<1>(fe_load(pub_c + ((size_t)b * llen + j) * 8), tl));
+  const fr r = fr_load(rho + (size_t)b * 8);
+  fr acc26 = fr_zero();
+  for (uint32_t j = t; j < llen; j += 64) {
+    const uint32_t hi = j >> k;                             // tensor'(wit_lin, 1 / es)[j] (src/Bulletproof.hs:94-95), zero beyond it
+    if (hi >= fl) continue;
+    fr tl = fr_load(wit_lin + ((size_t)b * fl + hi) * 8);
+    for (int rr = 0; rr < k; rr++) if ((j >> rr) & 1u) tl = fr_mul(tl, fr_load(f + (size_t)(k + rr) * 8));
+    acc26 = fr_addr(acc26, fr_mul(fr_load(pub_c + ((size_t)b * llen + j) * 8), tl));
   }
-  for (int i = 0; i < 8; i++) lds[t * 8 + i] = acc.v[i];
-  __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
-    if ((int)t < d) {
-      fe x, y;
-      for (int i = 0; i < 8; i++) { x.v[i] = lds[t * 8 + i]; y.v[i] = lds[(t + d) * 8 + i]; }
-      x = fe_add<1>(x, y);
-      for (int i = 0; i < 8; i++) lds[t * 8 + i] = x.v[i];
-    }
-    __syncthreads();
-  }
+  fe acc = fr_to_fe(acc26);
+  for (int d = 32; d >= 1; d >>= 1) acc = fe_add<1>(acc, fe_shfl_down(acc, d));       // lane 0 ends with the sum of all 64
   if (t == 0) {
-    fe sc; for (int i = 0; i < 8; i++) sc.v[i] = lds[i];
-    const fe q = fe_load(qf + (size_t)b * 8);
-    fe w = q, nrm = fe_zero();
+    const fr sc = fr_from_fe(acc);
+    const fr q = fr_load(qf + (size_t)b * 8);
+    fr w = q, nrm = fr_zero();
     for (uint32_t j = 0; j < fm; j++) {
-      nrm = fe_add<1>(nrm, fe_mul<1>(w, fe_mul<1>(fe_load(v + ((size_t)b * 2 * fm + j) * 8), fe_load(v + ((size_t)b * 2 * fm + fm + j) * 8))));
-      w = fe_mul<1>(w, q);
+      nrm = fr_addr(nrm, fr_mul(w, fr_mul(fr_load(v + ((size_t)b * 2 * fm + j) * 8), fr_load(v + ((size_t)b * 2 * fm + fm + j) * 8))));
+      w = fr_mul(w, q);
     }
-    nrm = fe_dbl<1>(fe_dbl<1>(nrm));                                        // s = 4 (makeNorm)
-    fe_store(gs + (size_t)b * 8, fe_mul<1>(r, fe_sub<1>(fe_load(sp + (size_t)b * 8), fe_add<1>(sc, nrm))));
+    nrm = fr_dblr(fr_dblr(nrm));                                            // s = 4 (makeNorm)
+    fr_store(gs + (size_t)b * 8, fr_mul(r, fr_sub<2>(fr_load(sp + (size_t)b * 8), fr_add(sc, nrm))));
   }
   const uint32_t per = ninit + 2 * (uint32_t)k;
-  for (uint32_t m = t; m < per; m += 256) {
-    fe val;
-    if (m < ninit) val = fe_load(init_sc + ((size_t)b * ninit + m) * 8);
+  for (uint32_t m = t; m < per; m += 64) {
+    fr val;
+    if (m < ninit) val = fr_load(init_sc + ((size_t)b * ninit + m) * 8);
     else {
       const uint32_t rr = (m - ninit) >> 1;                                 // stored last round first; facx holds 1 / e first round first
-      val = ((m - ninit) & 1u) ? fe_load(es + ((size_t)b * k + rr) * 8) : fe_load(f + (size_t)(k + (k - 1 - rr)) * 8);
+      val = ((m - ninit) & 1u) ? fr_load(es + ((size_t)b * k + rr) * 8) : fr_load(f + (size_t)(k + (k - 1 - rr)) * 8);
     }
-    fe_store(tail + ((size_t)b * per + m) * 8, fe_mul<1>(r, val));
+    fr_store(tail + ((size_t)b * per + m) * 8, fr_mul(r, val));
   }
 }
 
@@ -541,7 +536,7 @@ int ip_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
       k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, sper, (uint32_t)llen, partial2);
       k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)llen, sc + nlen * 8);
     }
-    k_ipvb_proof<<<dim3((unsigned)batch), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf, v, (uint32_t)fm, (const uint32_t *)d_wit_lin, (uint32_t)fl,
+    k_ipvb_proof<<<dim3((unsigned)batch), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_sp, qf, v, (uint32_t)fm, (const uint32_t *)d_wit_lin, (uint32_t)fl,
                                                               (const uint32_t *)d_pub_lin_c, (uint32_t)llen, facx, (int)k, (const uint32_t *)d_init_scalars, (uint32_t)ninit,
                                                               (const uint32_t *)d_es, gs, sc + shared * 8);
     k_vb_sum_gs<<<dim3(1), dim3(256), 0, st>>>(gs, (uint32_t)batch, sc + (nlen + llen) * 8);
