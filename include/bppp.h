@@ -375,7 +375,8 @@ int bppp_rp_info(const bppp_rp *rp, bppp_rp_shape *out);
  *   COMB_BITS       force the table's window width (4..18; skips the budget), 0 = widest that fits.
  *   SPLIT_MIN       smallest prove batch run as two half-batches in flight on a twin context (default 4096); 0 = never split.
  *   HOST_ORACLE_MAX largest batch whose Fiat-Shamir hashing runs on host cores (defaults: 8 proofs verifying, 64 proving; UINT64_MAX
- *                   restores them).
+ *                   restores them).  Verifying 2 .. HOST_ORACLE_MAX proofs starts, once per handle, a pool of at most 15 worker threads
+ *                   that sleep between calls and end with bppp_rp_destroy.
  *   FOLD_POINTS     1 = the point-folding argument although a table exists;  HOST_ALGEBRA 1 = prover's field algebra on the host;
  *   TIMING          1 = phase times on stderr. */
 #define BPPP_RP_OPT_COMB_MIN 1
