@@ -40,7 +40,7 @@ void MsmTune::from_env() {
   if (const char *e = getenv("BPPP_GCOST")) gcost = atof(e);
   cmin = geti("BPPP_CMIN"); lw = geti("BPPP_LW"); rg = geti("BPPP_RG"); marg_s = geti("BPPP_MARG_S"); lacc = geti("BPPP_LACC");
   window_batched = geti("BPPP_WINDOW_BATCHED"); comb_wpe = geti("BPPP_COMB_WPE"); reduce_old = getenv("BPPP_REDUCE_OLD") != nullptr;
-  small_c = geti("BPPP_MSM_SMALL_C"); small_len = geti("BPPP_MSM_SMALL_LEN"); small_max = geti("BPPP_MSM_SMALL_MAX"); no_small = getenv("BPPP_MSM_NO_SMALL") != nullptr; comb_no_wsplit = getenv("BPPP_COMB_NO_WSPLIT") != nullptr;
+  small_c = geti("BPPP_MSM_SMALL_C"); small_len = geti("BPPP_MSM_SMALL_LEN"); small_max = geti("BPPP_MSM_SMALL_MAX"); hist_ch = geti("BPPP_HIST_CH"); no_small = getenv("BPPP_MSM_NO_SMALL") != nullptr; comb_no_wsplit = getenv("BPPP_COMB_NO_WSPLIT") != nullptr;
 }
 namespace bppp {
 int ctx_aux(bppp_ctx *ctx) {
@@ -112,6 +112,7 @@ int bppp_ctx_create(int device, bppp_ctx **out) {
   bppp_ctx *ctx = new bppp_ctx();
   ctx->device = device;
   ctx->tune.from_env();
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) ctx->tune.num_cus = cus; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return BPPP_ERR_HIP;

@@ -701,6 +701,18 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat, const MsmTune
   p.hist_threads = p.M >= 8192 ? 1024 : 256;
   size_t per_block = (size_t)p.hist_threads * 64;
   p.CH = (int)std::max<size_t>(1, std::min<size_t>(64, (n + per_block - 1) / per_block));
+  // the histogram of a wide window (>= 80 KB of LDS) leaves room for ONE k_hist / k_scatter workgroup per CU: a grid a few workgroups
+  // over a whole number of rounds (17 windows x 16 chunks on 256 CUs) runs a nearly empty extra round — take the chunk count that fills
+  // the rounds instead (15: sort stage 0.301 -> 0.277 ms at 2^20)
+  if ((size_t)p.M * 4 > 80 * 1024 && tune.num_cus > 0) {
+    const double rounds = (double)p.NB * p.CH / tune.num_cus;
+    if (rounds >= 0.75) {
+      const uint64_t r = (uint64_t)(rounds + 0.5) ? (uint64_t)(rounds + 0.5) : 1;
+      const uint64_t ch = r * (uint64_t)tune.num_cus / p.NB;
+      if (ch >= 1 && ch <= 64 && 4 * ch >= 3 * (uint64_t)p.CH) p.CH = (int)ch;
+    }
+  }
+  if (tune.hist_ch >= 1 && tune.hist_ch <= 64) p.CH = tune.hist_ch;
   // bucket reduce geometry: lanes per window T = M / Lw, at most 64 wavefronts per window
   if (p.M <= 64) { p.Lw = 1; p.WPW = 1; }
   else {
