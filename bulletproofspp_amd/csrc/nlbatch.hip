@@ -22,7 +22,9 @@
 namespace bppp {
 int msm_run(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *);
 
-static constexpr int KT = 2;    // proofs per partial sum (more, shorter wavefronts: these kernels are latency-bound)
+static constexpr int KT = 2;    // proofs per partial sum at most (more, shorter wavefronts: these kernels are latency-bound)
+// batches that leave SIMDs idle anyway take ONE proof per partial sum: half the chain per lane, twice the (cheap) partial rows to add
+static inline uint32_t vb_kt(size_t batch) { return batch <= 1024 ? 1u : (uint32_t)KT; }
 BPPP_DI fe frm(const fe &a, const fe &b) { return fe_mul<1>(a, b); }
 
 // factor table per proof: fac[b][r] = q_b^(2^r) (r < k), fac[b][k + r] = e_{b, first-round-first r}, and qF2 = (q^(2^k))^2
@@ -55,11 +57,11 @@ BPPP_DI fe tensor_at(const uint32_t *vs, uint32_t nvs, const uint32_t *fac, int 
 // partial[kt][i] = sum_{b in tile kt} rho_b * (pub[b][i] - tensor_b[i])      (shared-basis scalars), one position per lane
 __global__ void __launch_bounds__(256) k_vb_shared1(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
                                                     uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
-                                                    uint32_t *__restrict__ partial) {
+                                                    uint32_t ktile, uint32_t *__restrict__ partial) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, kt = blockIdx.y;
   if (i >= len) return;
   fe acc = fe_zero();
-  uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
+  uint32_t b0 = kt * ktile, b1 = min(batch, b0 + ktile);
   for (uint32_t b = b0; b < b1; b++) {
     fe t = tensor_at(wit + (size_t)b * nvs * 8, nvs, fac + (size_t)b * 2 * k * 8, k, i, use_q != 0);
     fe d = fe_sub<1>(fe_load(pub + ((size_t)b * len + i) * 8), t);
@@ -72,13 +74,13 @@ __global__ void __launch_bounds__(256) k_vb_shared1(const uint32_t *__restrict__
 // lane halved the multiplications again but left one wavefront per SIMD: 160 us per launch here against 240 us.)
 __global__ void __launch_bounds__(64) k_vb_shared4(const uint32_t *__restrict__ rho, const uint32_t *__restrict__ pub, const uint32_t *__restrict__ wit,
                                                    uint32_t nvs, const uint32_t *__restrict__ fac, uint32_t batch, uint32_t len, int k, int use_q,
-                                                   uint32_t *__restrict__ partial) {
+                                                   uint32_t ktile, uint32_t *__restrict__ partial) {
   // Fr in 10 x 26-bit limbs (fr26.hip.h: 413 instructions per multiplication against 785): values are canonical 8 x 32 in memory,
   // converted once on load; the accumulators stay lazily reduced (magnitude 3 per proof) until the store
   const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, kt = blockIdx.y;
   if (i0 >= len) return;
   fr a0 = fr_zero(), a1 = a0, a2 = a0, a3 = a0;          // named scalars, not arrays: arrays of field elements end up in scratch here
-  uint32_t b0 = kt * KT, b1 = min(batch, b0 + KT);
+  uint32_t b0 = kt * ktile, b1 = min(batch, b0 + ktile);
   for (uint32_t b = b0; b < b1; b++) {
     const uint32_t *f = fac + (size_t)b * 2 * k * 8;
     const fr r = fr_load(rho + (size_t)b * 8);
@@ -403,7 +405,7 @@ int nl_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
   hipSetDevice(ctx->device);
   hipStream_t st = ctx->stream;
   const size_t per = ninit + 2 * k, shared = nlen + llen + 1, T = shared + batch * per;
-  const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
+  const uint32_t ktile = vb_kt(batch), ntiles = (uint32_t)((batch + ktile - 1) / ktile);
   const size_t maxlen = nlen > llen ? nlen : llen;
   const size_t npartial = std::max((size_t)ntiles * maxlen, batch * ((llen + 3) / 4));      // the tile sums, then k_vb_lin_partial's group sums
   // scratch (separate from the MSM workspace, which msm_run carves from ctx->ws)
@@ -430,15 +432,15 @@ int nl_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
     }
     k_vb_factors<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>((const uint32_t *)d_q, (const uint32_t *)d_es, (uint32_t)batch, (int)k, fac, qf2);
     if (nlen) {
-      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
-      else k_vb_shared1<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, partial);
+      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, ktile, partial);
+      else k_vb_shared1<<<dim3((unsigned)((nlen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_norm, (const uint32_t *)d_wit_norm, (uint32_t)fn, fac, (uint32_t)batch, (uint32_t)nlen, (int)k, 1, ktile, partial);
       { const uint32_t per = (ntiles + SUM_GROUPS - 1) / SUM_GROUPS, groups = (ntiles + per - 1) / per;
         k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, per, (uint32_t)nlen, partial2);
         k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)nlen, sc); }
     }
     if (llen) {
-      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
-      else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, ktile, partial);
+      else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, fac, (uint32_t)batch, (uint32_t)llen, (int)k, 0, ktile, partial);
       { const uint32_t per = (ntiles + SUM_GROUPS - 1) / SUM_GROUPS, groups = (ntiles + per - 1) / per;
         k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, per, (uint32_t)llen, partial2);
         k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)llen, sc + nlen * 8); }
@@ -497,7 +499,7 @@ int ip_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
   hipSetDevice(ctx->device);
   hipStream_t st = ctx->stream;
   const size_t per = ninit + 2 * k, shared = nlen + llen + 1, T = shared + batch * per, fm = fn / 2, kk = k ? k : 1;
-  const uint32_t ntiles = (uint32_t)((batch + KT - 1) / KT);
+  const uint32_t ktile = (uint32_t)KT, ntiles = (uint32_t)((batch + KT - 1) / KT);
   const size_t maxlen = nlen > llen ? nlen : llen;
   size_t words = (2 * batch * 2 * kk + batch + batch * (fn ? fn : 2) + (size_t)ntiles * maxlen + (size_t)SUM_GROUPS * maxlen + batch + T + 64) * 8 + T * 16 + 64;
   { int rc0 = ensure_scratch(ctx, words * 4); if (rc0) return rc0; }
@@ -531,8 +533,8 @@ int ip_verify_batch_run(bppp_ctx *ctx, size_t batch, size_t nlen, size_t llen, s
       k_vb_sum_partials<<<dim3((unsigned)((nlen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)nlen, sc);
     }
     if (llen) {
-      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, facx, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
-      else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, facx, (uint32_t)batch, (uint32_t)llen, (int)k, 0, partial);
+      if (k >= 2) k_vb_shared4<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(64), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, facx, (uint32_t)batch, (uint32_t)llen, (int)k, 0, ktile, partial);
+      else k_vb_shared1<<<dim3((unsigned)((llen + 255) / 256), ntiles), dim3(256), 0, st>>>((const uint32_t *)d_rho, (const uint32_t *)d_pub_lin_x, (const uint32_t *)d_wit_lin, (uint32_t)fl, facx, (uint32_t)batch, (uint32_t)llen, (int)k, 0, ktile, partial);
       k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), groups), dim3(256), 0, st>>>(partial, ntiles, sper, (uint32_t)llen, partial2);
       k_vb_sum_partials<<<dim3((unsigned)((llen + 63) / 64), 1), dim3(256), 0, st>>>(partial2, groups, groups, (uint32_t)llen, sc + nlen * 8);
     }
