@@ -60,7 +60,8 @@ template <int MOD> BPPP_DI fe load_field_be(const uint8_t *p) {
 //   else              the input commitments                         = the commitments file
 // Output: responses to resp[b][t], the rest to init[b][...] in the order blCom : rCom : dmCom : mCom : nComs.
 __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batch, const uint8_t *__restrict__ coms, const uint8_t *__restrict__ proofs,
-                                                         uint32_t *__restrict__ init_pts, uint32_t *__restrict__ resp_pts, uint32_t *__restrict__ bad) {   // bad[batch] per proof, bad[batch] any
+                                                         uint32_t *__restrict__ init_pts, uint32_t *__restrict__ resp_pts, uint32_t *__restrict__ bad,
+                                                         uint32_t *__restrict__ any_bad) {   // bad[b] per proof of this launch, *any_bad for the call
   const uint32_t npts = rp_npts(D);
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (uint64_t)batch * npts) return;
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64) k_rp_decode_points(RpDims D, uint32_t batc
   fe d;
   const bool y_big = raw_sub(d, yn, ye) != 0;                  // -y < y
   aff r; r.x = x; r.y = (y_big != want_big) ? fq_from_fe(yn) : y;
-  if (!ok) { r = aff_inf(); atomicOr(bad + b, 1u); atomicOr(bad + batch, 1u); }
+  if (!ok) { r = aff_inf(); atomicOr(bad + b, 1u); atomicOr(any_bad, 1u); }
   uint32_t *out = t < 2 * D.k ? resp_pts + ((size_t)b * 2 * D.k + t) * 16
                               : init_pts + ((size_t)b * (D.nrp + D.nr) + (t - 2 * D.k)) * 16;
   aff_store(out, r);
@@ -510,6 +511,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->stage) hipFree(rp->stage);
   if (rp->hflag) hipHostFree(rp->hflag);
   if (rp->hstage) hipHostFree(rp->hstage);
+  for (auto &e : rp->slice_ev) if (e) hipEventDestroy(e);
   delete rp->pool;
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
@@ -823,10 +825,35 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
   BPPP_HIP(ctx, hipMemsetAsync(bad, 0, (B + 1) * 4, st));
   BPPP_HIP(ctx, hipMemsetAsync(pub_lin_x, 0, B * llen * 32, st));       // the public linear vector of these proofs is zero (TypedReciprocal.hs:466)
   BPPP_HIP(ctx, hipMemcpyAsync(d_seed, seed, 32, hipMemcpyHostToDevice, st));
-  const uint64_t np = (uint64_t)B * npts, ns = (uint64_t)B * (D.fn + D.fl);
-  k_rp_decode_points<<<dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_coms_files, (const uint8_t *)d_proof_files, init_pts,
-                                                                           resp_pts, bad);
-  if (ns) k_rp_decode_scalars<<<dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)B, (const uint8_t *)d_proof_files, wit_norm, wit_lin);
+  // decodeProof.  From host buffers (bppp_rp_verify_batch left them in rp->host_*; the device pointers are then its staging area): the
+  // files go up in four slices, each followed by its decode launches, so the square roots of slice i run under the upload of slice
+  // i + 1 (a pageable copy keeps the HOST busy staging, not the stream)
+  {
+    const uint8_t *hc = rp->host_coms, *hp = rp->host_proofs;
+    rp->host_coms = rp->host_proofs = nullptr;
+    const size_t nslices = (hc && B >= 1024) ? 4 : 1;
+    for (size_t sl = 0; sl < nslices; sl++) {
+      const size_t b0 = B * sl / nslices, b1 = B * (sl + 1) / nslices, nb = b1 - b0;
+      const uint8_t *dc = (const uint8_t *)d_coms_files + b0 * (size_t)D.coms_bytes, *dp = (const uint8_t *)d_proof_files + b0 * (size_t)D.proof_bytes;
+      if (hc) {
+        // the copies go on the context's second stream (a copy on `st` would queue behind the previous slice's kernels), the kernels wait
+        // for their slice's event
+        hipStream_t up = st;
+        if (nslices > 1) {
+          int rca = ctx_aux(ctx); if (rca) return rca;
+          up = ctx->aux_stream;
+          if (!rp->slice_ev[sl]) BPPP_HIP(ctx, hipEventCreateWithFlags(&rp->slice_ev[sl], hipEventDisableTiming));
+          if (sl == 0) { BPPP_HIP(ctx, hipEventRecord(ctx->aux_fork, st)); BPPP_HIP(ctx, hipStreamWaitEvent(up, ctx->aux_fork, 0)); }   // the staging area is free again
+        }
+        BPPP_HIP(ctx, hipMemcpyAsync((void *)dc, hc + b0 * (size_t)D.coms_bytes, nb * (size_t)D.coms_bytes, hipMemcpyHostToDevice, up));
+        BPPP_HIP(ctx, hipMemcpyAsync((void *)dp, hp + b0 * (size_t)D.proof_bytes, nb * (size_t)D.proof_bytes, hipMemcpyHostToDevice, up));
+        if (nslices > 1) { BPPP_HIP(ctx, hipEventRecord(rp->slice_ev[sl], up)); BPPP_HIP(ctx, hipStreamWaitEvent(st, rp->slice_ev[sl], 0)); }
+      }
+      const uint64_t np = (uint64_t)nb * npts, ns = (uint64_t)nb * (D.fn + D.fl);
+      k_rp_decode_points<<<dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)nb, dc, dp, init_pts + b0 * ninit * 16, resp_pts + b0 * 2 * k * 16, bad + b0, bad + B);
+      if (ns) k_rp_decode_scalars<<<dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st>>>(D, (uint32_t)nb, dp, wit_norm + b0 * D.fn * 8, wit_lin + b0 * D.fl * 8);
+    }
+  }
   BPPP_HIP(ctx, hipMemcpyAsync(rp->hflag, bad + B, 4, hipMemcpyDeviceToHost, st));     // pinned; read after the MSM has drained the stream
   const size_t host_oracle_max = rp->opt.host_oracle_verify;
   // async copies below target host vectors: whatever path leaves this function, the stream is drained before they are destroyed
@@ -972,11 +999,9 @@ int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, c
     rp->stage_bytes = cbp + pb + 256;
   }
   void *stage = rp->stage;
-  int rc = BPPP_OK;
-  if (hipMemcpyAsync(stage, coms_files, cb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-      hipMemcpyAsync((char *)stage + cbp, proof_files, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-    rc = fail(ctx, BPPP_ERR_HIP, "rp_verify_batch: upload failed");
-  if (!rc) rc = bppp_rp_verify_batch_device(rp, batch, stage, (char *)stage + cbp, seed, accept, proof_status, challenges_out, combined_xy);
+  rp->host_coms = coms_files; rp->host_proofs = proof_files;          // uploaded in slices by the decode stage of the call below
+  int rc = bppp_rp_verify_batch_device(rp, batch, stage, (char *)stage + cbp, seed, accept, proof_status, challenges_out, combined_xy);
+  rp->host_coms = rp->host_proofs = nullptr;
   hipStreamSynchronize(ctx->stream);
   return rc;
 }

@@ -113,6 +113,8 @@ struct bppp_rp {
   uint32_t *d_comb_out = nullptr; size_t comb_out_rows = 0;   // fixed-base tables of the argument's first round (csrc/nlb.hip)
   // grow-only verifier workspace and the staging buffer of the host-buffer entry point
   bppp::HostPool *pool = nullptr;                // workers of the host oracle (batches of 2 .. host_oracle_verify proofs), made on first use
+  hipEvent_t slice_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // one per upload slice of bppp_rp_verify_batch
+  const uint8_t *host_coms = nullptr, *host_proofs = nullptr;   // set by bppp_rp_verify_batch around its call of the device entry point: files still on the host
   uint64_t *hstage = nullptr; size_t hstage_bytes = 0;   // pinned, grow-only: the host oracle's downloads and uploads (a pageable target makes every async copy a blocking one)
   uint32_t *hflag = nullptr;                     // pinned: the verifier's "some proof did not decode" word, copied out while the batch is still in flight
   void *work = nullptr; size_t work_bytes = 0;
