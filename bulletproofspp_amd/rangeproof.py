@@ -966,9 +966,10 @@ def setup_from_schema(backend: Backend, schema: dict, points: Optional[Sequence[
     """The reciprocal branch of the CLI's schema handling (app/Parse.hs:100-186, app/Main.hs:262-285): defaults argument = IP,
     count = 1, min = 0, max = 2^64, base = approxLogW (max - min), flags False; typed or conserved => hasTypes.  `points`
     defaults to the try-and-increment stream over schema["basisSeed"] (getPoints, app/Main.hs:68-72; even-y root: this build's
-    documented choice).  Binary schemas ("binary": true) are a different protocol (RangeProof.Binary) and are refused."""
+    documented choice).  Binary schemas ("binary": true) are a different protocol (RangeProof.Binary): they go through
+    bulletproofspp_amd.rangeproof_binary.setup_from_schema and are refused here."""
     if schema.get("binary", False):
-        raise ValueError("binary range proofs (RangeProof.Binary) are not built")
+        raise ValueError("a binary schema (RangeProof.Binary): use bulletproofspp_amd.rangeproof_binary.setup_from_schema")
     arg = str(schema.get("argument", "IP")).lower()
     flavour = {"ip": "IP", "innerproduct": "IP", "nl": "NL", "normlinear": "NL"}.get(arg)
     if flavour is None:
