@@ -300,6 +300,17 @@ def test_config5_batch_of_4096_proofs_64by64(gpu):
     pf = bytearray(bad[1234][1]); pf[40] ^= 1; bad[1234] = (bad[1234][0], bytes(pf))
     ok, status, _ = nat.verify_batch([c for c, _ in bad], [p for _, p in bad], seed, want_status=True)
     assert not ok and [i for i, s_ in enumerate(status) if s_] == [1234] and status[1234] == 1
+    # the host-buffer entry point uploads a batch of this size in four slices (decode of one under the upload of the next): a commitment
+    # with no point on the curve in the LAST slice is reported as malformed next to the invalid proof of the second, and the files
+    # already resident in HBM give the same answer
+    x_bad = next(x for x in range(2, 100) if pow((x**3 + 7) % O.P, (O.P - 1) // 2, O.P) != 1)
+    cf = bytearray(bad[4000][0]); cf[8:40] = E.put_field(x_bad); bad[4000] = (bytes(cf), bad[4000][1])
+    ok, status, _ = nat.verify_batch([c for c, _ in bad], [p for _, p in bad], seed, want_status=True)
+    assert not ok and {i: s_ for i, s_ in enumerate(status) if s_} == {1234: 1, 4000: 2}
+    dc = gpu.to_device(np.frombuffer(b"".join(c for c, _ in bad), dtype=np.uint8)); dp = gpu.to_device(np.frombuffer(b"".join(p for _, p in bad), dtype=np.uint8))
+    ok2, status2, _ = nat.verify_batch_device(B, dc, dp, seed, want_status=True)
+    gpu.free(dc); gpu.free(dp)
+    assert not ok2 and list(status2) == list(status)
     nat.close()
 
 
