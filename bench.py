@@ -312,6 +312,16 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(cf), vp(pf), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
     hdt = time.perf_counter() - th0
     assert acc.value == 1
+    # the same call with the files in page-locked buffers of the library (bppp_host_alloc): DMA transfers beside the decode kernels
+    pcf, ppf = gpu.host_alloc(cf.nbytes), gpu.host_alloc(pf.nbytes)
+    pcf[:] = cf; ppf[:] = pf
+    gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(pcf), vp(ppf), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
+    tp0 = time.perf_counter()
+    for _ in range(3):
+        gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(pcf), vp(ppf), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
+    pdt_pinned = (time.perf_counter() - tp0) / 3
+    assert acc.value == 1
+    gpu.host_free(pcf); gpu.host_free(ppf)
     # a corrupted member must be rejected (one flipped sign bit)
     pf_bad = pf.copy(); pf_bad[(batch // 2) * shp["proof_bytes"] + 32 * (fn + fl)] ^= 1
     gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(cf), vp(pf_bad), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
@@ -337,7 +347,9 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
                                    "arithmetic, SHA-256), none HBM-bound" % bytes_per_proof},
               "concurrent": concurrent,
               "host_buffer_call": {"entry": "bppp_rp_verify_batch (files in pageable host memory, %d B per proof over PCIe)" % file_bytes,
-                                   "ms_per_batch": hdt * 1e3, "value": batch / hdt, "unit": "verifies/s"}}
+                                   "ms_per_batch": hdt * 1e3, "value": batch / hdt, "unit": "verifies/s",
+                                   "pinned": {"entry": "the same call with the files in page-locked host buffers (bppp_host_alloc)", "ms_per_batch": pdt_pinned * 1e3,
+                                              "value": batch / pdt_pinned, "unit": "verifies/s"}}}
     if strong is not None:
         # N > 1: the stated configuration (one job, strong scaling) is the leg's `value`; the weak figure (a full batch per GPU) stays beside it
         weak = {k_: verify[k_] for k_ in ("value", "unit", "ms_per_batch", "batch_per_gpu", "job_proofs", "achieved_GBps", "hbm_frac")}

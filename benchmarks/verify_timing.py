@@ -20,8 +20,16 @@ gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, B, vp(amt), vp(typ), vp(bld), vp(p
 dc = torch.from_numpy(cf).to(dev); dp = torch.from_numpy(pf).to(dev)
 seed = np.frombuffer(b"\x05" * 32, dtype=np.uint8)
 acc = C.c_int(0)
+hostbuf = int(os.environ.get("HOSTBUF", "0"))        # 1: bppp_rp_verify_batch from pageable host arrays, 2: from page-locked ones (bppp_host_alloc)
+if hostbuf == 2:
+    pcf, ppf = gpu.host_alloc(cf.nbytes), gpu.host_alloc(pf.nbytes)
+    pcf[:] = cf; ppf[:] = pf
+    cf, pf = pcf, ppf
 for it in range(4):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    gpu._check(gpu.lib.bppp_rp_verify_batch_device(nat.h, B, C.c_void_p(dc.data_ptr()), C.c_void_p(dp.data_ptr()), vp(seed), C.byref(acc), None, None, None), "verify")
+    if hostbuf:
+        gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, B, vp(cf), vp(pf), vp(seed), C.byref(acc), None, None, None), "verify")
+    else:
+        gpu._check(gpu.lib.bppp_rp_verify_batch_device(nat.h, B, C.c_void_p(dc.data_ptr()), C.c_void_p(dp.data_ptr()), vp(seed), C.byref(acc), None, None, None), "verify")
     print("verify ms", (time.perf_counter() - t0) * 1e3, "accept", acc.value, file=sys.stderr)

@@ -24,7 +24,7 @@ SYMBOLS = [
     "bppp_nl_get_witness", "bppp_nl_download", "bppp_nl_verify", "bppp_nl_verify_batch_device", "bppp_nl_prove", "bppp_nl_verify_challenges",
     "bppp_nlb_create", "bppp_nlb_destroy", "bppp_nlb_lengths", "bppp_nlb_round_commit", "bppp_nlb_round_collapse", "bppp_nlb_get_witness",
     "bppp_ip_create", "bppp_ip_destroy", "bppp_ip_lengths", "bppp_ip_round_commit", "bppp_ip_round_collapse", "bppp_ip_get_witness", "bppp_ip_verify", "bppp_ip_verify_batch_device",
-    "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download",
+    "bppp_lift_x_device", "bppp_device_alloc", "bppp_device_free", "bppp_upload", "bppp_download", "bppp_host_alloc", "bppp_host_free",
     "bppp_profile_enable", "bppp_profile_read",
     "bppp_trrp_create", "bppp_trrp_destroy", "bppp_trrp_public_device",
     "bppp_glv_decompose_device", "bppp_msm_glv_device",
@@ -108,6 +108,8 @@ def load_library() -> C.CDLL:
     lib.bppp_nl_verify.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, vp]
     lib.bppp_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.bppp_device_free.argtypes = [vp, vp]
+    lib.bppp_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.bppp_host_free.argtypes = [vp, vp]
     lib.bppp_upload.argtypes = [vp, vp, vp, sz]
     lib.bppp_download.argtypes = [vp, vp, vp, sz]
     lib.bppp_basis_create.argtypes = [vp, vp, sz, i, sz, C.POINTER(vp)]
@@ -403,6 +405,22 @@ class Bppp:
 
     def free(self, d_ptr: int):
         self._check(self.lib.bppp_device_free(self.h, _ptr(d_ptr)), "bppp_device_free")
+
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """page-locked host memory as a uint8 array (bppp_host_alloc): copies from it are DMA transfers; release with host_free"""
+        p = C.c_void_p()
+        self._check(self.lib.bppp_host_alloc(self.h, nbytes, C.byref(p)), "bppp_host_alloc")
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is None:
+            raise ValueError("not an array from host_alloc")
+        self._check(self.lib.bppp_host_free(self.h, _ptr(p)), "bppp_host_free")
 
     def upload(self, d_dst: int, src: np.ndarray):
         src = np.ascontiguousarray(src)

@@ -304,6 +304,18 @@ int bppp_device_free(bppp_ctx *ctx, void *d_ptr) {
   BPPP_HIP(ctx, hipFree(d_ptr));
   return BPPP_OK;
 }
+int bppp_host_alloc(bppp_ctx *ctx, size_t bytes, void **ptr) {
+  CTX_ENTER(ctx);
+  if (!ptr) return fail(ctx, BPPP_ERR_ARG, "host_alloc: null pointer");
+  BPPP_HIP(ctx, hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+  return BPPP_OK;
+}
+int bppp_host_free(bppp_ctx *ctx, void *ptr) {
+  CTX_ENTER(ctx);
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));      // a copy out of the buffer may still be in flight
+  BPPP_HIP(ctx, hipHostFree(ptr));
+  return BPPP_OK;
+}
 int bppp_upload(bppp_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
   CTX_ENTER(ctx);
   if (!bytes) return BPPP_OK;

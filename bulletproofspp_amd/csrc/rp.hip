@@ -831,7 +831,16 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
   {
     const uint8_t *hc = rp->host_coms, *hp = rp->host_proofs;
     rp->host_coms = rp->host_proofs = nullptr;
-    const size_t nslices = (hc && B >= 1024) ? 4 : 1;
+    // how many: a slice's decode launch is latency-bound (one square-root chain, ~0.18 ms for 1024 proofs against 0.53 ms for all 4096),
+    // so slices cost decode time; pageable files arrive at the host's staging rate (0.7 ms per 4096 proofs) and four slices hide most of
+    // it, page-locked ones (bppp_host_alloc) arrive in 0.25 ms and two are enough
+    size_t nslices = 1;
+    if (hc && B >= 1024) {
+      hipPointerAttribute_t at;
+      const bool pinned = hipPointerGetAttributes(&at, hc) == hipSuccess && at.type == hipMemoryTypeHost;
+      if (!pinned) (void)hipGetLastError();                 // an ordinary pointer is "invalid value" to the runtime: not an error of this call
+      nslices = pinned ? 2 : 4;
+    }
     for (size_t sl = 0; sl < nslices; sl++) {
       const size_t b0 = B * sl / nslices, b1 = B * (sl + 1) / nslices, nb = b1 - b0;
       const uint8_t *dc = (const uint8_t *)d_coms_files + b0 * (size_t)D.coms_bytes, *dp = (const uint8_t *)d_proof_files + b0 * (size_t)D.proof_bytes;

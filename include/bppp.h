@@ -460,6 +460,12 @@ int bppp_device_alloc(bppp_ctx *ctx, size_t bytes, void **d_ptr);
 int bppp_device_free(bppp_ctx *ctx, void *d_ptr);
 int bppp_upload(bppp_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 int bppp_download(bppp_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* Page-locked host memory for the buffers a caller hands to the host-buffer entry points (bppp_msm, bppp_rp_verify_batch,
+ * bppp_rp_prove_batch, bppp_upload ...): from such a buffer the copies to the device are DMA transfers that run beside the kernels;
+ * from ordinary (pageable) memory every copy first passes through a staging buffer at the host's memcpy rate.  Optional: every entry
+ * point takes either kind (a Haskell binding would wrap these in a ForeignPtr with bppp_host_free as its finalizer). */
+int bppp_host_alloc(bppp_ctx *ctx, size_t bytes, void **ptr);
+int bppp_host_free(bppp_ctx *ctx, void *ptr);
 
 /* ---- measurement hooks ---------------------------------------------------------------------
  * When enabled, each MSM call brackets its stages with hipEvents on the context's stream; the

@@ -50,3 +50,24 @@ def test_context_destroyed_before_its_children_exits_cleanly():
     p = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
     assert "lifetime ok" in p.stdout
+
+
+def test_page_locked_host_buffers(gpu, oracle_lib):
+    """bppp_host_alloc / bppp_host_free: a host-buffer entry point takes a page-locked buffer like any other (here the scalars and points
+    of an MSM), and freeing one that was never allocated through the library is refused by the binding."""
+    import numpy as np
+    import pyoracle as O
+    from bulletproofspp_amd.capi import points_to_array, scalars_to_array
+    pts = O.hash_points(b"pinned", 33)
+    sc = [(977 * i + 5) % O.N for i in range(33)]
+    a, b_ = scalars_to_array(sc), points_to_array(pts)
+    pa, pb = gpu.host_alloc(a.nbytes), gpu.host_alloc(b_.nbytes)
+    pa[:] = a.view(np.uint8).reshape(-1); pb[:] = b_.view(np.uint8).reshape(-1)
+    got = gpu.msm(pa.view(np.uint64).reshape(-1, 4), pb.view(np.uint64).reshape(-1, 8))
+    assert got == oracle_lib.inner_product(list(zip(sc, pts)))
+    gpu.host_free(pa); gpu.host_free(pb)
+    try:
+        gpu.host_free(np.zeros(8, dtype=np.uint8))
+        assert False, "freeing a foreign array must be refused"
+    except ValueError:
+        pass
