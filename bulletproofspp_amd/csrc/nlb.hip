@@ -19,6 +19,7 @@
 #include "ctx.hpp"
 #include "comb.hpp"
 #include "foldcore.hip.h"
+#include "fr26.hip.h"
 #include "hostmath.hpp"
 
 namespace bppp {
@@ -52,40 +53,46 @@ BPPP_DI void block_sum4(fe v[4], uint32_t *lds) {
 __global__ void __launch_bounds__(256) k_nlb_round(const uint32_t *__restrict__ x, const uint32_t *__restrict__ lc, const uint32_t *__restrict__ lx,
                                                    uint32_t n, uint32_t l, uint32_t xstride, uint32_t lstride, const uint32_t *__restrict__ qs /*[B][2]: q, qinv*/,
                                                    uint32_t T, uint32_t *__restrict__ sc /*[2B][T]*/, uint32_t *__restrict__ sums /*[B][4]*/) {
+  // Fr in 10 x 26-bit limbs (fr26.hip.h: 413 instructions per multiplication against 785); canonical 8 x 32 values in memory
   __shared__ uint32_t lds[256 * 4 * 8];
   const uint32_t b = blockIdx.x, t = threadIdx.x;
   const uint32_t ne = n + (n & 1), np = (n + 1) / 2, lp = (l + 1) / 2;
-  const fe q = fe_load(qs + (size_t)b * 16), qinv = fe_load(qs + (size_t)b * 16 + 8);
-  fe q2 = fe_sqr<1>(q), q4 = fe_sqr<1>(q2);
+  const fr q = fr_load(qs + (size_t)b * 16), qinv = fr_load(qs + (size_t)b * 16 + 8);
+  const fr q2 = fr_sqr(q), q4 = fr_sqr(q2);
   const uint32_t bs = blockDim.x;                  // 64 .. 256: late rounds have a handful of pairs per proof
-  fe w = frb_pow(q4, t), step = frb_pow(q4, bs);
+  auto powu = [](fr base, uint32_t e) { fr acc = fr_one(); while (e) { if (e & 1u) acc = fr_mul(acc, base); base = fr_sqr(base); e >>= 1; } return acc; };
+  fr w = powu(q4, t);
+  const fr step = powu(q4, bs);
   uint32_t *scX = sc + (size_t)(2 * b) * T * 8, *scR = sc + (size_t)(2 * b + 1) * T * 8;
   const uint32_t *xb = x + (size_t)b * xstride * 8, *lcb = lc + (size_t)b * lstride * 8, *lxb = lx + (size_t)b * lstride * 8;
-  fe s[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
+  fr s0 = fr_zero(), s1 = s0, s2 = s0, s3 = s0;
   for (uint32_t j = t; j < np; j += bs) {
-    fe xl = fe_load(xb + (size_t)(2 * j) * 8);
-    fe xr = (2 * j + 1 < n) ? fe_load(xb + (size_t)(2 * j + 1) * 8) : fe_zero();
-    fe wxr = fe_mul<1>(w, xr);
-    s[0] = fe_add<1>(s[0], fe_mul<1>(wxr, xl));
-    s[1] = fe_add<1>(s[1], fe_mul<1>(wxr, xr));
-    fe_store(scX + (size_t)(2 * j) * 8, fe_mul<1>(q, xr));
-    fe_store(scX + (size_t)(2 * j + 1) * 8, fe_mul<1>(qinv, xl));
+    const fe xl8 = fe_load(xb + (size_t)(2 * j) * 8);
+    const fe xr8 = (2 * j + 1 < n) ? fe_load(xb + (size_t)(2 * j + 1) * 8) : fe_zero();
+    const fr xl = fr_from_fe(xl8), xr = fr_from_fe(xr8);
+    const fr wxr = fr_mul(w, xr);
+    s0 = fr_addr(s0, fr_mul(wxr, xl));
+    s1 = fr_addr(s1, fr_mul(wxr, xr));
+    fr_store(scX + (size_t)(2 * j) * 8, fr_mul(q, xr));
+    fr_store(scX + (size_t)(2 * j + 1) * 8, fr_mul(qinv, xl));
     fe_store(scR + (size_t)(2 * j) * 8, fe_zero());
-    fe_store(scR + (size_t)(2 * j + 1) * 8, xr);
-    w = fe_mul<1>(w, step);
+    fe_store(scR + (size_t)(2 * j + 1) * 8, xr8);
+    w = fr_mul(w, step);
   }
   for (uint32_t j = t; j < lp; j += bs) {
-    bool has = 2 * j + 1 < l;
-    fe cl = fe_load(lcb + (size_t)(2 * j) * 8), xl = fe_load(lxb + (size_t)(2 * j) * 8);
-    fe cr = has ? fe_load(lcb + (size_t)(2 * j + 1) * 8) : fe_zero();
-    fe xr = has ? fe_load(lxb + (size_t)(2 * j + 1) * 8) : fe_zero();
-    s[2] = fe_add<1>(s[2], fe_add<1>(fe_mul<1>(cl, xr), fe_mul<1>(cr, xl)));
-    s[3] = fe_add<1>(s[3], fe_mul<1>(cr, xr));
-    fe_store(scX + (size_t)(ne + 2 * j) * 8, xr);
-    fe_store(scX + (size_t)(ne + 2 * j + 1) * 8, xl);
+    const bool has = 2 * j + 1 < l;
+    const fe xl8 = fe_load(lxb + (size_t)(2 * j) * 8), xr8 = has ? fe_load(lxb + (size_t)(2 * j + 1) * 8) : fe_zero();
+    const fr cl = fr_load(lcb + (size_t)(2 * j) * 8), xl = fr_from_fe(xl8);
+    const fr cr = has ? fr_load(lcb + (size_t)(2 * j + 1) * 8) : fr_zero();
+    const fr xr = fr_from_fe(xr8);
+    s2 = fr_addr(s2, fr_add(fr_mul(cl, xr), fr_mul(cr, xl)));
+    s3 = fr_addr(s3, fr_mul(cr, xr));
+    fe_store(scX + (size_t)(ne + 2 * j) * 8, xr8);
+    fe_store(scX + (size_t)(ne + 2 * j + 1) * 8, xl8);
     fe_store(scR + (size_t)(ne + 2 * j) * 8, fe_zero());
-    fe_store(scR + (size_t)(ne + 2 * j + 1) * 8, xr);
+    fe_store(scR + (size_t)(ne + 2 * j + 1) * 8, xr8);
   }
+  fe s[4] = {fr_to_fe(s0), fr_to_fe(s1), fr_to_fe(s2), fr_to_fe(s3)};
   block_sum4(s, lds);
   if (t == 0) for (int k = 0; k < 4; k++) fe_store(sums + ((size_t)b * 4 + k) * 8, s[k]);
 }
@@ -107,21 +114,21 @@ __global__ void __launch_bounds__(256) k_nlb_fold_scalars(const uint32_t *__rest
   const CollapseK &k = K[b];
   if (j < (n + 1) / 2) {
     const uint32_t *xb = x + (size_t)b * xstride * 8;
-    fe r = fe_mul<1>(fe_of8(k.nu), fe_load(xb + (size_t)(2 * j) * 8));
-    if (2 * j + 1 < n) r = fe_add<1>(r, fe_mul<1>(fe_of8(k.nv), fe_load(xb + (size_t)(2 * j + 1) * 8)));
-    fe_store(xo + ((size_t)b * xstride + j) * 8, r);
+    fr r = fr_mul(fr_from_fe(fe_of8(k.nu)), fr_load(xb + (size_t)(2 * j) * 8));
+    if (2 * j + 1 < n) r = fr_add(r, fr_mul(fr_from_fe(fe_of8(k.nv)), fr_load(xb + (size_t)(2 * j + 1) * 8)));
+    fr_store(xo + ((size_t)b * xstride + j) * 8, r);
   }
   if (j < (l + 1) / 2) {
     const uint32_t *cb = lc + (size_t)b * lstride * 8, *xb = lx + (size_t)b * lstride * 8;
     bool has = 2 * j + 1 < l;
-    fe c = fe_mul<1>(fe_of8(k.cu), fe_load(cb + (size_t)(2 * j) * 8));
-    fe r = fe_mul<1>(fe_of8(k.lu), fe_load(xb + (size_t)(2 * j) * 8));
+    fr c = fr_mul(fr_from_fe(fe_of8(k.cu)), fr_load(cb + (size_t)(2 * j) * 8));
+    fr r = fr_mul(fr_from_fe(fe_of8(k.lu)), fr_load(xb + (size_t)(2 * j) * 8));
     if (has) {
-      c = fe_add<1>(c, fe_mul<1>(fe_of8(k.cv), fe_load(cb + (size_t)(2 * j + 1) * 8)));
-      r = fe_add<1>(r, fe_mul<1>(fe_of8(k.lv), fe_load(xb + (size_t)(2 * j + 1) * 8)));
+      c = fr_add(c, fr_mul(fr_from_fe(fe_of8(k.cv)), fr_load(cb + (size_t)(2 * j + 1) * 8)));
+      r = fr_add(r, fr_mul(fr_from_fe(fe_of8(k.lv)), fr_load(xb + (size_t)(2 * j + 1) * 8)));
     }
-    fe_store(lco + ((size_t)b * lstride + j) * 8, c);
-    fe_store(lxo + ((size_t)b * lstride + j) * 8, r);
+    fr_store(lco + ((size_t)b * lstride + j) * 8, c);
+    fr_store(lxo + ((size_t)b * lstride + j) * 8, r);
   }
 }
 
@@ -171,11 +178,11 @@ __global__ void __launch_bounds__(256) k_nlb_expand(const uint32_t *__restrict__
   else if (pos <= l0) {
     const uint32_t i = pos - 1;
     v = fe_load(row + (size_t)(ne_r + (i >> r)) * 8);
-    if (r && !fe_is_zero(v)) v = fe_mul<1>(v, fe_load(coefl + ((size_t)b * l0 + i) * 8));
+    if (r && !fe_is_zero(v)) v = fr_to_fe(fr_mul(fr_from_fe(v), fr_load(coefl + ((size_t)b * l0 + i) * 8)));
   } else {
     const uint32_t i = pos - 1 - l0;
     v = fe_load(row + (size_t)(i >> r) * 8);
-    if (r && !fe_is_zero(v)) v = fe_mul<1>(v, fe_load(coefn + ((size_t)b * n0 + i) * 8));
+    if (r && !fe_is_zero(v)) v = fr_to_fe(fr_mul(fr_from_fe(v), fr_load(coefn + ((size_t)b * n0 + i) * 8)));
   }
   fe_store(full + ((size_t)inst * Tc + pos) * 8, v);
 }
@@ -185,11 +192,11 @@ __global__ void __launch_bounds__(256) k_nlb_coef_update(uint32_t *__restrict__ 
   const uint32_t b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i < n0 && ((i >> r) & 1u)) {
     uint32_t *c = coefn + ((size_t)b * n0 + i) * 8;
-    fe_store(c, fe_mul<1>(fe_load(c), fe_load(A + (size_t)b * 16)));
+    fr_store(c, fr_mul(fr_load(c), fr_load(A + (size_t)b * 16)));
   }
   if (i < l0 && ((i >> r) & 1u)) {
     uint32_t *c = coefl + ((size_t)b * l0 + i) * 8;
-    fe_store(c, fe_mul<1>(fe_load(c), fe_load(A + (size_t)b * 16 + 8)));
+    fr_store(c, fr_mul(fr_load(c), fr_load(A + (size_t)b * 16 + 8)));
   }
 }
 __global__ void __launch_bounds__(256) k_nlb_fill_one(uint32_t *__restrict__ v, uint64_t count) {
@@ -423,8 +430,11 @@ int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR) {
   const int c = o->cur;
   hipStream_t st = ctx->stream;
   NLB_HIP(o, hipMemsetAsync(o->sc, 0, 2 * B * T * 32, st));
+  // threads per proof: every thread pays ~15-20 multiplications for its powers of q^4 before its first pair, so a batch that fills the chip
+  // anyway takes four pairs per thread (a lone proof keeps one pair per thread: its round is a dependency chain)
   unsigned round_threads = 64;
-  while (round_threads < 256 && round_threads < std::max((o->n + 1) / 2, (o->l + 1) / 2)) round_threads <<= 1;
+  const size_t pairs = std::max((o->n + 1) / 2, (o->l + 1) / 2), per_thread = B >= 256 ? 4 : 1;
+  while (round_threads < 256 && (size_t)round_threads * per_thread < pairs) round_threads <<= 1;
   k_nlb_round<<<dim3((unsigned)B), dim3(round_threads), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l, (uint32_t)o->xstride, (uint32_t)o->lstride,
                                                                  o->qs, (uint32_t)T, o->sc, o->sums);
   k_nlb_tails<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(o->sums, o->qs, o->stt, (uint32_t)B, (uint32_t)o->n, (uint32_t)o->l, (uint32_t)T, o->sc);
