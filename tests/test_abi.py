@@ -43,6 +43,20 @@ def test_library_exports_nothing_but_the_c_abi():
     assert names == _declared("bppp.h"), sorted(set(names) ^ set(_declared("bppp.h")))
 
 
+def test_c_client_builds_and_links_without_a_gpu(tmp_path):
+    """examples/c_client/rp_roundtrip.c (plain C99 against include/bppp.h) compiles warning-free and links against the product library;
+    without a GPU it must fail at bppp_ctx_create with a non-zero exit, not crash (tests/test_gpu_c_client.py runs it on the card)."""
+    import subprocess
+    import torch
+    lib = os.path.dirname(capi.lib_path())
+    exe = str(tmp_path / "rp_roundtrip")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_client", "rp_roundtrip.c"),
+                    "-L", lib, "-lbppp_hip", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 1 and "bppp_ctx_create" in p.stderr, (p.returncode, p.stdout, p.stderr)
+
+
 def test_rational_reduce_host_entry_point():
     import pyoracle as O
     lib = capi.load_library()
