@@ -383,6 +383,66 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     return verify, prove
 
 
+def bench_binary_verify(gpu, torch, dev, batch: int, steps: int):
+    """RangeProof.Binary (src/RangeProof/Binary.hs) at the 64 x 64-bit shape — BASELINE config 3 read literally ("64x64-bit aggregated BINARY
+    range proof"): 64 outputs in [0, 2^64), one bit per norm position (nrmLen 4096, linLen 2, 10 rounds, an 867-byte proof), conserved
+    against one public input as witnessBRP requires (:158-166), norm-linear argument.  `batch` DISTINCT proofs made in this run by the
+    library's lockstep prover (bppp_rp_prove_batch on a bppp_rp_create_binary handle: proveBRPM + proveBPM, field algebra on the host
+    cores) and verified end to end from their files in HBM (bppp_rp_verify_batch_device: verifyBRPM's two oracle calls, verifyBPM, one
+    combined MSM of 4100 + batch * 86 terms); one corrupted member must be rejected and identified."""
+    from bulletproofspp_amd import rangeproof as RP, rangeproof_binary as RB
+    from bulletproofspp_amd.capi import array_to_point
+    count, amount = 64, 10000
+    rds = [RB.make_range_data(0, 2**64, True, False)] * count
+    need = 4 + sum(len(rd.base_coeffs) for rd in rds)
+    rng = np.random.default_rng(0xB1)
+    pts = None
+    while pts is None or pts.shape[0] < need:
+        xs = rng.integers(0, 2**64, size=(3 * need, 4), dtype=np.uint64)
+        dx = torch.from_numpy(xs.view(np.int64)).to(dev)
+        dp = torch.zeros((3 * need, 8), dtype=torch.int64, device=dev)
+        gpu.lift_x(dx.data_ptr(), 3 * need, dp.data_ptr())
+        pts = dp[(dp != 0).any(dim=1)]
+    P = pts[:need].cpu().numpy().view(np.uint64)
+    basis = [array_to_point(P[i]) for i in range(need)]
+    st = RB.setup(RP.GpuBackend(gpu), basis, True, rds, amount * count, "NL")
+    nat = RB.NativeBinaryRangeProofs(gpu, st, h=basis[0])
+    shp = nat.shape
+    dlt = rng.integers(-5000, 5000, size=(batch, count // 2))
+    vals = np.concatenate([amount + dlt, amount - dlt], axis=1).astype(np.uint64)
+    bld = rng.integers(1, 2**63, size=(batch, count), dtype=np.uint64)
+    inputs = [[(int(v), int(x)) for v, x in zip(vals[i], bld[i])] for i in range(batch)]
+    tp0 = time.perf_counter()
+    files = nat.prove_batch(inputs, [b"bench bin %010d" % i for i in range(batch)])
+    pdt = time.perf_counter() - tp0
+    cf = np.frombuffer(b"".join(c for c, _ in files), dtype=np.uint8); pf = np.frombuffer(b"".join(p for _, p in files), dtype=np.uint8)
+    dc, dpf = gpu.to_device(cf), gpu.to_device(pf)
+    seed = os.urandom(32)
+    assert nat.verify_batch_device(batch, dc, dpf, seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ok = nat.verify_batch_device(batch, dc, dpf, seed)
+    dt = time.perf_counter() - t0
+    assert ok
+    pf2 = pf.copy(); pf2[(batch // 2) * shp["proof_bytes"] + 9] ^= 4
+    dp2 = gpu.to_device(pf2)
+    ok2, status, _ = nat.verify_batch_device(batch, dc, dp2, seed, want_status=True)
+    assert not ok2 and [i for i, s_ in enumerate(status) if s_] == [batch // 2], "a corrupted binary proof was not identified"
+    gpu.free(dc); gpu.free(dpf); gpu.free(dp2)
+    k, ninit = shp["rounds"], 2 + count
+    out = {"metric": "aggregated_64x64bit_binary_range_proof_verifies_per_sec", "value": batch * steps / dt, "unit": "verifies/s", "ms_per_batch": dt / steps * 1e3,
+           "batch": batch, "combined_msm_terms": shp["norm_len"] + shp["lin_len"] + 1 + batch * (ninit + 2 * k),
+           "encoded_bytes_per_proof": shp["coms_bytes"] + shp["proof_bytes"],
+           "shape": "RangeProof.Binary, 64 x 64-bit outputs conserved against one public input: nrmLen %d, linLen %d, %d rounds, proof %d B" % (
+               shp["norm_len"], shp["lin_len"], k, shp["proof_bytes"]),
+           "scope": "verifyBRPM + verifyBPM end to end from the encoded files resident in HBM (bppp_rp_verify_batch_device on a bppp_rp_create_binary handle); one corrupted "
+                    "member rejected and identified",
+           "prove": {"value": batch / pdt, "unit": "proofs/s", "ms_per_batch": pdt * 1e3, "note": "lockstep proveBRPM + proveBPM, field algebra on the host cores, commitments on the GPU; first call (tables included)"}}
+    nat.close()
+    return out
+
+
 def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, cpu_baseline_leg: bool = True):
     """The inner-product flavour at batch scale (the CLI's DEFAULT argument, app/Parse.hs:100): `batch` DISTINCT encoded
     proofs of the examples/64bit shape — ONE 64-bit value, base 16 inline, nrmLen 16, linLen 6, 3 rounds, the paper's 416-byte proof
@@ -587,6 +647,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=4096, help="distinct proofs per GPU proved in lockstep and then batch-verified end to end (0 = skip both legs)")
     ap.add_argument("--ip-batch", type=int, default=1 << 14, help="inner-product flavour leg: single 64-bit proofs (examples/64bit) verified per batch (0 = skip; N = 1 only)")
+    ap.add_argument("--binary-batch", type=int, default=1024, help="RangeProof.Binary leg: 64 x 64-bit binary proofs verified per batch (0 = skip; N = 1 only)")
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -885,6 +946,10 @@ def main():
     if world == 1 and args.ip_batch > 0 and not args.headline_only:
         verify_ip = bench_ip_verify(gpu, torch, dev, args.ip_batch, max(3, args.steps // 2), cpu_baseline_leg=not args.no_cpu_baseline)
 
+    verify_binary = None
+    if world == 1 and args.binary_batch > 0 and not args.headline_only:
+        verify_binary = bench_binary_verify(gpu, torch, dev, args.binary_batch, max(3, args.steps // 2))
+
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
         # with N > 1 each step makes two library calls (the slice MSM and the tiny combine): the dominant
@@ -970,6 +1035,8 @@ def main():
             out["prove"] = prove
         if verify_ip is not None:
             out["verify_ip"] = verify_ip
+        if verify_binary is not None:
+            out["verify_binary"] = verify_binary
         print(json.dumps(out), flush=True)
     gpu.close()
     if dist is not None:

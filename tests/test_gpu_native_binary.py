@@ -106,3 +106,40 @@ def test_native_binary_on_the_reference_example(gpu):
     t_ip = bytearray(f_ip); t_ip[40] ^= 1
     assert not nat_ip.verify_batch([c_ip], [bytes(t_ip)])
     nat_ip.close(); nat.close()
+
+
+def test_native_binary_at_the_64_by_64_bit_shape(gpu):
+    """BASELINE config 3 read literally — a 64 x 64-bit aggregated BINARY range proof: 64 outputs in [0, 2^64), nrmLen 4096, 10 rounds,
+    conserved against one public input.  The lockstep prover's files verify, the end-to-end verifier derives the challenges the host
+    protocol code derives from the same files (both transcript-hashing routes), and a tampered member is identified.  (Byte equality
+    with the host prover is asserted on the smaller shapes above; at 4096 positions the Python prover takes minutes.)"""
+    count, amount = 64, 10000
+    rds = [BRP.make_range_data(0, 2**64, True, False)] * count
+    pts = O.hash_points(b"binary 64by64", 4 + 64 * count)
+    st = BRP.setup(RP.GpuBackend(gpu), pts, True, rds, amount * count, "NL")
+    assert (st.nrm_len, st.rounds) == (4096, 10)
+    nat = BRP.NativeBinaryRangeProofs(gpu, st)
+    assert nat.shape["proof_bytes"] == 867 and nat.shape["challenges_per_proof"] == 14
+    rnd = random.Random(64)
+    B = 3
+    inputs = []
+    for _ in range(B):
+        d = [rnd.randrange(-5000, 5000) for _ in range(count // 2)]
+        inputs.append([(amount + x, rnd.randrange(RP.N)) for x in d] + [(amount - x, rnd.randrange(RP.N)) for x in d])
+    files = nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)])
+    seed = hashlib.sha256(b"binary 64by64").digest()
+    lift = E.gpu_lift_x(gpu)
+    for host_oracle_max in (2**64 - 1, 0):
+        nat.set_option("host_oracle_max", host_oracle_max)
+        ok, status, chs = nat.verify_batch([c for c, _ in files], [p for _, p in files], seed, want_status=True, want_challenges=True)
+        assert ok and status == [0] * B
+        for (cf, pf), (lead, es) in zip(files, chs):
+            coms = E.decode_commitments(count, cf, lift)[0]
+            proof = E.decode_proof(2, st.rounds, st.final_lens, coms, pf, lift)
+            want_lead, want_es = BRP.verifier_challenges(st, proof, RP.sha256_oracle())
+            assert lead == want_lead and es == want_es
+    bad = [list(f) for f in files]
+    pf = bytearray(bad[2][1]); pf[9] ^= 4; bad[2][1] = bytes(pf)
+    ok, status, _ = nat.verify_batch([c for c, _ in bad], [p for _, p in bad], seed, want_status=True)
+    assert not ok and status == [0, 0, 1]
+    nat.close()
