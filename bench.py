@@ -411,11 +411,16 @@ def bench_binary_verify(gpu, torch, dev, batch: int, steps: int):
     dlt = rng.integers(-5000, 5000, size=(batch, count // 2))
     vals = np.concatenate([amount + dlt, amount - dlt], axis=1).astype(np.uint64)
     bld = rng.integers(1, 2**63, size=(batch, count), dtype=np.uint64)
-    inputs = [[(int(v), int(x)) for v, x in zip(vals[i], bld[i])] for i in range(batch)]
+    import ctypes as C
+    amt = np.zeros((batch, count, 4), dtype=np.uint64); amt[:, :, 0] = vals
+    typ = np.zeros((batch, count, 4), dtype=np.uint64)
+    bl4 = np.zeros((batch, count, 4), dtype=np.uint64); bl4[:, :, 0] = bld
+    pre = np.frombuffer(b"".join(b"bench bin %010d" % i for i in range(batch)), dtype=np.uint8)
+    cf = np.zeros(batch * shp["coms_bytes"], dtype=np.uint8); pf = np.zeros(batch * shp["proof_bytes"], dtype=np.uint8)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
     tp0 = time.perf_counter()
-    files = nat.prove_batch(inputs, [b"bench bin %010d" % i for i in range(batch)])
+    gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bl4), vp(pre), 20, vp(cf), vp(pf)), "bppp_rp_prove_batch (binary)")
     pdt = time.perf_counter() - tp0
-    cf = np.frombuffer(b"".join(c for c, _ in files), dtype=np.uint8); pf = np.frombuffer(b"".join(p for _, p in files), dtype=np.uint8)
     dc, dpf = gpu.to_device(cf), gpu.to_device(pf)
     seed = os.urandom(32)
     assert nat.verify_batch_device(batch, dc, dpf, seed)
