@@ -666,7 +666,7 @@ static int choose_window(size_t n, size_t batch, const MsmTune &tune) {
   // One large MSM: the reduction is latency-bound and nearly flat in the bucket count (0.12 ms at c = 11 .. 0.26 ms at c = 16),
   // so the model above overprices wide windows; thresholds read off the (n, c, L) table of benchmarks/sweep_window.py
   // (profiles/r02_window_sweep.txt): c = 16 has 17 windows against 20 at c = 13 and no heavy top window.
-  if (batch == 1 && n >= 4096) return n < 12288 ? 8 : n < 46000 ? 10 : n < 200000 ? 13 : 16;
+  if (batch == 1 && n >= 4096) return n < 12288 ? 8 : n < 38000 ? 10 : n < 200000 ? 13 : 16;
   const double gcost = tune.gcost > 0 ? tune.gcost : 3.5;               // tuning sweeps override both
   const int cmin = tune.cmin ? std::max(2, tune.cmin) : 4;
   double best = 1e300; int bc = 8;
