@@ -37,8 +37,10 @@ struct RecodeK { uint32_t k[9]; };
 
 // ------------------------------------------------------------------------------------------------
 // 1. digits
+// Window widths: the first `acnt` windows are c bits wide, the others c - 1 (balanced windows, make_plan; acnt = W: all c).  A digit of a
+// narrow window is stored re-biased by 2^(c-2), so that every consumer reads  stored - 2^(c-1)  as the signed digit whatever the width.
 __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint64_t total, uint32_t n, uint32_t stride, int c,
-                                                int W, RecodeK K, uint16_t *__restrict__ dig,
+                                                int W, int acnt, RecodeK K, uint16_t *__restrict__ dig,
                                                 unsigned long long *__restrict__ negmask) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = i < total;
@@ -57,13 +59,14 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
     }
     sp[8] = (uint32_t)cy + K.k[8];
     uint32_t inst = (uint32_t)(i / n), j = (uint32_t)(i % n);
-    uint32_t mask = (1u << c) - 1u;
     size_t base = (size_t)inst * W * stride + j;
     for (int w = 0; w < W; w++) {
-      dig[base + (size_t)w * stride] = (uint16_t)(sp[0] & mask);
+      const int cw = w < acnt ? c : c - 1;
+      const uint32_t mask = (1u << cw) - 1u, bias = w < acnt ? 0u : (1u << (c - 2));
+      dig[base + (size_t)w * stride] = (uint16_t)((sp[0] & mask) + bias);
 #pragma unroll
-      for (int k = 0; k < 8; k++) sp[k] = (sp[k] >> c) | (sp[k + 1] << (32 - c));
-      sp[8] >>= c;
+      for (int k = 0; k < 8; k++) sp[k] = (sp[k] >> cw) | (sp[k + 1] << (32 - cw));
+      sp[8] >>= cw;
     }
   }
   unsigned long long m = __ballot(valid && neg);
@@ -236,7 +239,15 @@ __global__ void __launch_bounds__(256) k_acc_points(const uint32_t *__restrict__
       if (first && from_prev) xyzz_store(rec_pt + (2 * g) * XYZZ_WORDS, acc);
       else xyzz_store(buckets + (size_t)cur * XYZZ_WORDS, acc);
       first = false; acc = xyzz_inf();
-      do { cur++; end = start[cur + 1]; } while (end <= p);   // next non-empty bucket
+      cur++; end = start[cur + 1];
+      if (end <= p) {                                         // an empty bucket — there may be thousands in a row (the unused half of a narrow
+        uint32_t lo2 = cur + 1, hi2 = FB - 1;                 // window, an empty carry window): bisect for the bucket that holds p
+        while (lo2 < hi2) {
+          const uint32_t mid = lo2 + (hi2 - lo2 + 1) / 2;
+          if (start[mid] <= p) lo2 = mid; else hi2 = mid - 1;
+        }
+        cur = lo2; end = start[cur + 1];
+      }
     }
     const uint32_t idx = e & 0x7FFFFFFFu;
     const bool sg = (e >> 31) & 1u;
@@ -666,7 +677,9 @@ static int choose_window(size_t n, size_t batch, const MsmTune &tune) {
   // One large MSM: the reduction is latency-bound and nearly flat in the bucket count (0.12 ms at c = 11 .. 0.26 ms at c = 16),
   // so the model above overprices wide windows; thresholds read off the (n, c, L) table of benchmarks/sweep_window.py
   // (profiles/r02_window_sweep.txt): c = 16 has 17 windows against 20 at c = 13 and no heavy top window.
-  if (batch == 1 && n >= 4096) return n < 12288 ? 8 : n < 38000 ? 10 : n < 200000 ? 13 : 16;
+  // (re-read after the balanced windows of make_plan, which removed the heavy top window of every width that does not divide 256:
+  // 9000-12000 terms 0.47 ms at c = 8 against 0.33 at c = 11; 22 016 terms 0.376 at c = 12; 43 782 terms 0.423 at c = 13)
+  if (batch == 1 && n >= 4096) return n < 20000 ? 11 : n < 30000 ? 12 : n < 200000 ? 13 : 16;
   const double gcost = tune.gcost > 0 ? tune.gcost : 3.5;               // tuning sweeps override both
   const int cmin = tune.cmin ? std::max(2, tune.cmin) : 4;
   double best = 1e300; int bc = 8;
@@ -683,7 +696,7 @@ static int choose_window(size_t n, size_t batch, const MsmTune &tune) {
 }
 
 struct MsmPlan {
-  size_t n, batch; int c, W, M, CH, hist_threads, Lw, WPW;
+  size_t n, batch; int c, W, acnt, M, CH, hist_threads, Lw, WPW;   // acnt: windows [0, acnt) are c bits wide, the others c - 1
   bool flat;                   // precomputed table 2^(c w) P_i: all windows of an instance share ONE bucket set
   int Wc;                      // windows left for the window combine (1 when flat)
   uint64_t NB, NS, FB, total_max;   // digit rows (batch * W), bucket sets (batch * W, or batch when flat), buckets, sorted entries
@@ -696,6 +709,16 @@ struct MsmPlan {
 static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat, const MsmTune &tune) {
   MsmPlan p;
   p.n = n; p.batch = batch; p.c = c; p.W = 256 / c + 1; p.M = 1 << (c - 1);
+  p.acnt = p.W;
+  // Balanced windows (one MSM over arbitrary points, c not a divisor of 256): with uniform widths the top window holds only
+  // 256 - c floor(256 / c) real bits, i.e. a few buckets with n / 2^r entries each — the "heavy" merges (0.05 ms at 2^16 terms, c = 13:
+  // 256 buckets of 256 entries).  Instead ceil(256 / c) windows of widths c (the low ones) and c - 1 share the 256 bits, so every
+  // window's buckets are evenly filled; the extra top window only catches the carry of the rare scalars within 2^-(c-2) of 2^255.
+  if (batch == 1 && !flat && c >= 3 && 256 % c != 0 && !tune.no_balance) {
+    const int Wr = (256 + c - 1) / c;
+    p.acnt = 256 - Wr * (c - 1);
+    p.W = Wr + 1;
+  }
   p.flat = flat; p.Wc = flat ? 1 : p.W;
   p.NB = (uint64_t)batch * p.W; p.NS = flat ? batch : p.NB; p.FB = p.NS * p.M; p.total_max = p.NB * n;
   p.hist_threads = p.M >= 8192 ? 1024 : 256;
@@ -770,11 +793,14 @@ static MsmPlan make_plan(size_t n, size_t batch, int c, bool flat, const MsmTune
 }
 
 // sets K = sum_{w<W} 2^(c-1) * 2^(w*c) as 9 x 32-bit limbs
-static RecodeK make_recode_k(int c, int W) {
+static RecodeK make_recode_k(int c, int W, int acnt = -1) {
   RecodeK K; memset(&K, 0, sizeof K);
+  if (acnt < 0) acnt = W;
+  int off = 0;
   for (int w = 0; w < W; w++) {
-    int bit = w * c + c - 1;
+    const int cw = w < acnt ? c : c - 1, bit = off + cw - 1;
     if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31);
+    off += cw;
   }
   return K;
 }
@@ -877,8 +903,8 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
     prof_mark(ctx, 0);
     // 1. digits
     uint64_t total_sc = (uint64_t)batch * n;
-    k_digits<<<dim3((unsigned)((total_sc + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_scalars, total_sc, (uint32_t)n, stride, c, p.W,
-                                                                            make_recode_k(c, p.W), dig, negmask);
+    k_digits<<<dim3((unsigned)((total_sc + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)d_scalars, total_sc, (uint32_t)n, stride, c, p.W, p.acnt,
+                                                                            make_recode_k(c, p.W, p.acnt), dig, negmask);
     prof_mark(ctx, 1);
     // 2. sort
     k_hist<<<dim3((unsigned)p.NB, p.CH), dim3(p.hist_threads), lds, st>>>(dig, (uint32_t)n, stride, c, p.CH, blockhist);
@@ -930,14 +956,15 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
         HJac r = hj_inf();
         auto pt = [&](const uint32_t *q) { return hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)); };
         for (int w = p.Wc - 1; w >= 0; w--) {
-          if (p.marg) {                               // window value = 2^a * W1 + W2: the c doublings are split around W1
+          const int cw = (p.flat || w < p.acnt) ? c : c - 1;     // this window's width = the doublings that separate it from the one above
+          if (p.marg) {                               // window value = 2^a * W1 + W2: the doublings are split around W1
             const uint32_t *q = ws + ((size_t)b * p.Wc + w) * 2 * XYZZ_WORDS;
-            for (int k = 0; k < c - p.mg.a; k++) r = hj_dbl(r);
+            for (int k = 0; k < cw - p.mg.a; k++) r = hj_dbl(r);
             r = hj_add(r, pt(q));
             for (int k = 0; k < p.mg.a; k++) r = hj_dbl(r);
             r = hj_add(r, pt(q + XYZZ_WORDS));
           } else {
-            for (int k = 0; k < c; k++) r = hj_dbl(r);
+            for (int k = 0; k < cw; k++) r = hj_dbl(r);
             r = hj_add(r, pt(ws + ((size_t)b * p.Wc + w) * XYZZ_WORDS));
           }
         }
