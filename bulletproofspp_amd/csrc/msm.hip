@@ -546,7 +546,7 @@ static constexpr size_t MSM_SMALL_DEFAULT_MAX = 8192;      // terms per MSM on t
                                                            // pays the ~17-operation reduction chain with most lanes idle, so the general pipeline wins from ~2^14 terms
                                                            // (benchmarks/sweep_small_msm.py: 858 terms 0.36 -> 0.21 ms, 4096 0.38 -> 0.27, 8192 0.40 -> 0.33, 22016 0.45 -> 0.43, 65536 0.52 -> 0.78)
 __global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ scalars_all, const uint32_t *__restrict__ points_all, uint32_t n_all, uint32_t slice_len,
-                                                   int c, RecodeK K, uint32_t *__restrict__ winsum) {
+                                                   int c, int acnt, RecodeK K, uint32_t *__restrict__ winsum) {
   // slice blockIdx.y of the terms: its own bucket set, its own partial window sum (k_msm_small_join adds the slices of a window)
   const uint32_t j0 = blockIdx.y * slice_len, n = min(slice_len, n_all - j0);
   const uint32_t *scalars = scalars_all + (size_t)j0 * 8, *points = points_all + (size_t)j0 * 16;
@@ -558,7 +558,11 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ 
   uint32_t *bsum = sm + (((size_t)(2 * M + 1) + n + (n + 1) / 2 + 3) & ~(size_t)3);    // [M + 4] bucket sums, then the wavefronts' results
   for (int t = tid; t < M; t += 256) hist[t] = 0;
   __syncthreads();
-  const uint32_t bit0 = (uint32_t)c * w, mask = (1u << c) - 1u;
+  // balanced windows (as make_plan's): windows [0, acnt) are c bits wide, the others c - 1 and use half of the M buckets — with uniform widths
+  // the top window (3 real bits at c = 6) had 4 buckets of n / 4 entries and its workgroup set the kernel's time
+  const int cw = (int)w < acnt ? c : c - 1;
+  const uint32_t bit0 = (int)w < acnt ? (uint32_t)c * w : (uint32_t)(c * acnt + (c - 1) * ((int)w - acnt)), mask = (1u << cw) - 1u;
+  const int half = 1 << (cw - 1);
   for (uint32_t j = tid; j < n; j += 256) {
     const fe s_ = fe_load(scalars + (size_t)j * 8);
     fe t, tmp;
@@ -574,7 +578,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t *__restrict__ 
     for (int q = 0; q < 9; q++) if ((bit0 >> 5) == (uint32_t)q) { lo = sp[q]; hi = sp[q + 1]; }
     const uint32_t sh = bit0 & 31u;
     const uint32_t d = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
-    const int v = (int)d - M;
+    const int v = (int)d - half;
     uint16_t kx = 0xFFFFu;
     if (v) {
       const uint32_t mb = (uint32_t)(v < 0 ? -v : v) - 1u;
@@ -824,7 +828,9 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
   // wavefront each, then the host's Horner combine over the W window sums
   const size_t small_max = ctx->tune.small_max ? (size_t)ctx->tune.small_max : MSM_SMALL_DEFAULT_MAX;
   if (batch == 1 && !table_stride && !window_bits && n <= small_max && !ctx->tune.no_small) {
-    const int c = ctx->tune.small_c >= 5 && ctx->tune.small_c <= 8 ? ctx->tune.small_c : 6, W = 256 / c + 1, M = 1 << (c - 1);
+    const int c = ctx->tune.small_c >= 5 && ctx->tune.small_c <= 8 ? ctx->tune.small_c : 6, M = 1 << (c - 1);
+    const bool bal = 256 % c != 0 && !ctx->tune.no_balance;
+    const int Wr = (256 + c - 1) / c, acnt = bal ? 256 - Wr * (c - 1) : 256 / c + 1, W = bal ? Wr + 1 : 256 / c + 1;
     size_t len = ctx->tune.small_len >= 64 && ctx->tune.small_len <= (int)MSM_SMALL_MAX ? (size_t)ctx->tune.small_len : (n <= 2048 ? 512 : 1024);
     if (n <= len + len / 2) len = n;                                  // a second slice has to pay for the join launch
     const size_t S = (n + len - 1) / len;
@@ -840,7 +846,7 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
     if (ctx->pre_acc) { auto f = ctx->pre_acc; ctx->pre_acc = nullptr; int rc_ = f(ctx->pre_acc_arg); if (rc_) return rc_; }
     const size_t lds = (((size_t)(2 * M + 1) + len + (len + 1) / 2 + 3) & ~(size_t)3) * 4 + (size_t)(M + 4) * XYZZ_WORDS * 4;
     k_msm_small<<<dim3((unsigned)W, (unsigned)S), dim3(256), lds, st>>>((const uint32_t *)d_scalars, (const uint32_t *)d_points, (uint32_t)n, (uint32_t)len, c,
-                                                                       make_recode_k(c, W), S > 1 ? partials : winsum);
+                                                                       acnt, make_recode_k(c, W, acnt), S > 1 ? partials : winsum);
     if (S > 1) k_msm_small_join<<<dim3((unsigned)W), dim3(64), 0, st>>>(partials, (uint32_t)S, winsum);
     for (int i = 3; i <= 5; i++) prof_mark(ctx, i);
     BPPP_HIP(ctx, hipMemcpyAsync(ctx->pinned, winsum, bytes, hipMemcpyDeviceToHost, st));
@@ -850,7 +856,7 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
     HJac r = hj_inf();
     for (int w = W - 1; w >= 0; w--) {
       const uint32_t *q = ws + (size_t)w * XYZZ_WORDS;
-      for (int k = 0; k < c; k++) r = hj_dbl(r);
+      for (int k = 0; k < (w < acnt ? c : c - 1); k++) r = hj_dbl(r);
       r = hj_add(r, hj_from_xyzz(from_limbs26(q), from_limbs26(q + 10), from_limbs26(q + 20), from_limbs26(q + 30)));
     }
     HAff a = hj_to_aff(r);
