@@ -33,6 +33,7 @@
 #include "sha256.hip.h"
 #include "rp_internal.hpp"
 #include "rphash.hip.h"
+#include "fr26.hip.h"
 
 namespace bppp {
 
@@ -316,18 +317,23 @@ __global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, co
     for (int i = 0; i < 8; i++) half.v[i] = (tt.v[i] >> 1) | (i < 7 ? tt.v[i + 1] << 31 : carry << 31); }
   fe acc = fe_zero();
   {
-    fe qp = powu(q0, l + 1), qi = powu(q0i, l + 1);
-    const fe qs = powu(q0, 64), qis = powu(q0i, 64);
+    // the per-position part in 10 x 26-bit limbs (fr26.hip.h: 413 instructions per multiplication against 785): nlen / 64 positions per lane,
+    // seven multiplications each — all of this kernel's time at the 64 x 64-bit shape (4096 positions)
+    auto powr = [](fr base, uint32_t e) { fr a = fr_one(); while (e) { if (e & 1u) a = fr_mul(a, base); base = fr_sqr(base); e >>= 1; } return a; };
+    const fr q0r = fr_from_fe(q0), q0ir = fr_from_fe(q0i), tr_ = fr_from_fe(t), halfr = fr_from_fe(half);
+    fr qp = powr(q0r, l + 1), qi = powr(q0ir, l + 1), accr = fr_zero();
+    const fr qs = powr(q0r, 64), qis = powr(q0ir, 64);
     for (uint32_t i = l; i < D.nlen; i += 64) {
-      fe p = fe_zero();
+      fr p = fr_zero();
       if (i < D.nlive) {
-        p = fe_sub<1>(fe_mul<1>(fe_mul<1>(x2(pos_range[i]), fe_load(pos_coeff + (size_t)i * 8)), qi), half);
-        acc = fe_add<1>(acc, fe_mul<1>(qp, fe_sqr<1>(p)));
-        p = fe_mul<1>(t, p);
+        p = fr_sub<1>(fr_mul(fr_mul(fr_from_fe(x2(pos_range[i])), fr_load(pos_coeff + (size_t)i * 8)), qi), halfr);     // magnitude 3
+        accr = fr_addr(accr, fr_mul(qp, fr_sqr(p)));
+        p = fr_mul(tr_, p);
       }
-      fe_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
-      qp = fe_mul<1>(qp, qs); qi = fe_mul<1>(qi, qis);
+      fr_store(out_norm + ((size_t)b * D.nlen + i) * 8, p);
+      qp = fr_mul(qp, qs); qi = fr_mul(qi, qis);
     }
+    acc = fr_to_fe(accr);
   }
   // z = -2 (net' + sum_j min_j x^(2(j+1)))  (assumed ranges contribute no minimum, :91)
   fe z = fe_zero();
