@@ -218,7 +218,7 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     # ---- verify
     d_c = torch.from_numpy(cf).to(dev)
     d_p = torch.from_numpy(pf).to(dev)
-    seed = bytes((17 * rank + i) & 0xFF for i in range(32))
+    seed = os.urandom(32)        # fresh secret weights per rank (include/bppp.h: never a constant outside tests)
 
     def step():
         ok, part = nat.verify_batch_device_point(batch, d_c.data_ptr(), d_p.data_ptr(), seed)

@@ -312,7 +312,8 @@ int bppp_host_alloc(bppp_ctx *ctx, size_t bytes, void **ptr) {
 }
 int bppp_host_free(bppp_ctx *ctx, void *ptr) {
   CTX_ENTER(ctx);
-  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));      // a copy out of the buffer may still be in flight
+  BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));      // a copy out of the buffer may still be in flight,
+  if (ctx->aux_stream) BPPP_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));   // on either stream (the verifier's sliced uploads use the second)
   BPPP_HIP(ctx, hipHostFree(ptr));
   return BPPP_OK;
 }

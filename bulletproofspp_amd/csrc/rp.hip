@@ -799,9 +799,23 @@ int bppp_rp_verify_batch_device(bppp_rp *rp, size_t batch, const void *d_coms_fi
   return bppp_rp_verify_shard_device(rp, batch, 0, d_coms_files, d_proof_files, seed, accept, proof_status, challenges_out, combined_xy);
 }
 
+static int rp_verify_shard_run(bppp_rp *rp, size_t batch, uint64_t index_offset, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32],
+                               int *accept, uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy);
 int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32],
                                 int *accept, uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
   if (!rp || !accept) return BPPP_ERR_ARG;
+  const int rc = rp_verify_shard_run(rp, batch, index_offset, d_coms_files, d_proof_files, seed, accept, proof_status, challenges_out, combined_xy);
+  // A failed call may leave work queued on either stream that still reads the caller's buffers (the sliced uploads from host files run on
+  // the context's second stream): nothing of this call is in flight once it has returned, whatever the outcome.
+  if (rc && rp->ctx && !ctx_closed(rp->ctx)) {
+    hipStreamSynchronize(rp->ctx->stream);
+    if (rp->ctx->aux_stream) hipStreamSynchronize(rp->ctx->aux_stream);
+    (void)hipGetLastError();
+  }
+  return rc;
+}
+static int rp_verify_shard_run(bppp_rp *rp, size_t batch, uint64_t index_offset, const void *d_coms_files, const void *d_proof_files, const uint8_t seed[32],
+                               int *accept, uint32_t *proof_status, uint64_t *challenges_out, uint64_t *combined_xy) {
   bppp_ctx *ctx = rp->ctx;
   if (ctx_closed(ctx)) return BPPP_ERR_ARG;
   *accept = 0;
@@ -913,9 +927,11 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
     if (k) BPPP_HIP(ctx, hipMemcpyAsync(es, hes, B * k * 32, hipMemcpyHostToDevice, st));       // (pinned staging: the next call's downloads are ordered behind this copy on the stream)
   } else {
     // transcript text, then the hashing in two halves: the seven challenges of verifyTRRPM on the call's stream, followed there by
-    // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it.  Only while the
-    // batch leaves SIMDs idle (<= 1024 proofs: 256 proofs 1.65 -> 1.38 ms of kernels); at 4096 proofs the three kernels already
-    // fill the VALU and running them side by side only stretches each (hash 0.65 -> 0.55 + 0.87, scalars 0.84 -> 1.04 ms: measured, not kept)
+    // k_trrp_public (all it needs); the k round challenges of verifyBPM on the context's second stream, beside it — only up to
+    // RpOptions::hash_fork_max proofs (default 64, rp_internal.hpp): above that the device oracle's one launch over every hash wins.
+    // (Round-2 measurement with the 8 x 32-limb scalar kernels had the fork ahead up to 1024 proofs, 256 proofs 1.65 -> 1.38 ms; with the
+    // 10 x 26 kernels of round 3 the crossover fell to ~64.  At 4096 proofs the three kernels already fill the VALU and side by side
+    // each only stretches: hash 0.65 -> 0.55 + 0.87, scalars 0.84 -> 1.04 ms: measured, not kept.)
     if (rp_text_lds_bytes(D) <= 64 * 1024) k_rp_text_lds<<<dim3((unsigned)B), dim3(256), rp_text_lds_bytes(D), st>>>(D, init_pts, resp_pts, text, text_off);
     else k_rp_text<<<dim3((unsigned)B), dim3(256), (npts + 1) * 4, st>>>(D, init_pts, resp_pts, text, text_off);
     const uint32_t nch = D.nch, nes = rp->nhash - D.nch;
@@ -1018,6 +1034,7 @@ int bppp_rp_verify_batch(bppp_rp *rp, size_t batch, const uint8_t *coms_files, c
   int rc = bppp_rp_verify_batch_device(rp, batch, stage, (char *)stage + cbp, seed, accept, proof_status, challenges_out, combined_xy);
   rp->host_coms = rp->host_proofs = nullptr;
   hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);     // the sliced uploads read the caller's files from there
   return rc;
 }
 

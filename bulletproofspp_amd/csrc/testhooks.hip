@@ -4,6 +4,7 @@
 #include "ctx.hpp"
 #include "ec.hip.h"
 #include "modinv.hip.h"
+#include "fr26.hip.h"
 
 namespace bppp {
 template <int MOD> BPPP_DI fe apply_op(int op, const fe &a, const fe &b) {
@@ -37,6 +38,33 @@ BPPP_DI fe apply_mag8_mul(const fe &a, const fe &b) {
   fq x8 = fq_mul_int(x, 8), y8 = fq_neg<7>(fq_mul_int(y, 7));   // magnitudes 8 and 8
   return fq_to_fe(fq_mul(x8, y8));                               // = -56 a b
 }
+// Fr through the 10 x 26-bit lazy limbs the verifier's and provers' scalar kernels use (csrc/fr26.hip.h)
+BPPP_DI fe apply_op_fr26(int op, const fe &a, const fe &b) {
+  fr x = fr_from_fe(a), y = fr_from_fe(b);
+  switch (op) {
+    case BPPP_FE_ADD: return fr_to_fe(fr_add(x, y));
+    case BPPP_FE_SUB: return fr_to_fe(fr_sub<1>(x, y));
+    case BPPP_FE_MUL: return fr_to_fe(fr_mul(x, y));
+    case BPPP_FE_SQR: return fr_to_fe(fr_sqr(x));
+    case 6: {                                                 // (8a) * (-7b): both operands at the magnitude-8 bound of fr_mul
+      fr x8 = fr_mul_int(x, 8), y8 = fr_neg<7>(fr_mul_int(y, 7));
+      return fr_to_fe(fr_mul(x8, y8));
+    }
+    case 10: {                                                // (8a)^2 through fr_sqr's doubled operand (a2 = a << 1 < 2^31)
+      return fr_to_fe(fr_sqr(fr_mul_int(x, 8)));
+    }
+    case 11: {                                                // magnitude 16 into fr_normalize: 8a - 7b with sub<7>, result magnitude 16
+      return fr_to_fe(fr_sub<7>(fr_mul_int(x, 8), fr_mul_int(y, 7)));
+    }
+    case 12: {                                                // the reduced linear operations, chained: ((a + b) - 2b) + (-a) + 2a = a - b + ... = 2a - b
+      fr t = fr_subr(fr_addr(x, y), fr_dblr(y));             // a - b
+      return fr_to_fe(fr_addr(fr_addr(t, fr_negr(x)), fr_dblr(x)));   // a - b - a + 2a = 2a - b
+    }
+    case 13: return fr_to_fe(fr_weak(fr_mul_int(x, 16)));    // one weak pass from magnitude 16, then normalise: 16a
+    case 14: return fe{{(uint32_t)fr_is_zero(fr_sub<7>(fr_mul_int(x, 8), fr_mul_int(y, 7))), 0, 0, 0, 0, 0, 0, 0}};   // 8a == 7b ? (magnitude 16)
+    default: return fr_to_fe(fr_neg<1>(x));
+  }
+}
 __global__ void k_test_fe(int op, int mod, const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t *out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -44,6 +72,7 @@ __global__ void k_test_fe(int op, int mod, const uint32_t *a, const uint32_t *b,
   fe r;
   if (mod == 1) r = apply_op<1>(op, x, y);            // Fr, 8 x 32
   else if (mod == 2) r = apply_op<0>(op, x, y);       // Fq, legacy 8 x 32 code path (cross-check)
+  else if (mod == 3) r = apply_op_fr26(op, x, y);     // Fr, production 10 x 26 (fr26.hip.h)
   else if (op == 6) r = apply_mag8_mul(x, y);
   else r = apply_op_fq(op, x, y);                     // Fq, production 10 x 26
   fe_store(out + (size_t)i * 8, r);

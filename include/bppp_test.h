@@ -17,7 +17,8 @@ extern "C" {
 #define BPPP_FE_SQR 3
 #define BPPP_FE_INV 4
 #define BPPP_FE_NEG 5
-/* out[i] = a[i] (op) b[i] in Fq (modulus = 0) or Fr (modulus = 1); host arrays of n x 4 uint64 */
+/* out[i] = a[i] (op) b[i] in Fq (modulus = 0: production 10x26 limbs; 2: the 8x32 code path) or Fr (modulus = 1: 8x32; 3: production
+ * 10x26 limbs of csrc/fr26.hip.h, whose ops 6 and 10-14 drive the lazy limbs to their magnitude bounds); host arrays of n x 4 uint64 */
 int bppp_test_fe_op(bppp_ctx *ctx, int op, int modulus, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 /* out[i] = p[i] + q[i] (complete group law; op 0: mixed XYZZ+affine, op 1: XYZZ+XYZZ, op 2: 2*p[i]);
  * host arrays of n x 8 uint64 affine points */

@@ -10,8 +10,10 @@ from bulletproofspp_amd.capi import points_to_array, scalars_to_array, array_to_
 
 pytestmark = pytest.mark.gpu
 
-OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5, "mag8mul": 6, "inv_vartime": 7, "inv_safegcd": 8, "inv_fermat": 9}
-# modulus selector of bppp_test_fe_op: 0 = Fq via the production 10x26 limbs, 1 = Fr (8x32), 2 = Fq via the 8x32 code path
+OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "neg": 5, "mag8mul": 6, "inv_vartime": 7, "inv_safegcd": 8, "inv_fermat": 9,
+       "fr_mag8sqr": 10, "fr_mag16norm": 11, "fr_reduced_chain": 12, "fr_weak16": 13, "fr_is_zero16": 14}
+# modulus selector of bppp_test_fe_op: 0 = Fq via the production 10x26 limbs, 1 = Fr (8x32), 2 = Fq via the 8x32 code path,
+# 3 = Fr via the production 10x26 limbs (fr26.hip.h)
 
 
 def _fe_op(gpu, op, mod, a, b):
@@ -88,3 +90,45 @@ def test_group_law_complete(gpu, oracle_lib):
     assert _pt_op(gpu, 2, ps, qs) == [py.add(py.add(p, p), py.add(p, p)) for p in ps]
     # lambda*G = (beta*Gx, Gy): the endomorphism constants of FastSECP256K1.hs:39,53
     assert oracle_lib.mul(O.LAMBDA, G) == (O.BETA * O.GX % O.P, O.GY)
+
+
+def _edge_fr():
+    n = O.N
+    e = _edge_values(n) + [n - 1] * 3 + [(n - 1) // 2, (n + 1) // 2, 2**255, 2**256 - 1, 2**256 - n, 2**256 - n - 1, n - (2**256 - n),
+                                         2**252 - 1, 2**234 - 1, (1 << 26) - 1, ((1 << 256) - 1) // 3]
+    # every 26-bit limb all-ones below the top, and single saturated limbs
+    e += [((1 << 26) - 1) << (26 * i) for i in range(9)] + [((1 << 22) - 1) << 234]
+    return [x % n for x in e]
+
+
+def test_fr26_ops_match_python(gpu):
+    """Fr in 10 x 26-bit lazy limbs (csrc/fr26.hip.h) — the representation the verifier's scalar kernels (k_trrp_*, k_vb_shared4,
+    k_ipvb_proof, k_brp_public) and the prover rounds compute in — against Python integers, edge scalars included."""
+    n = O.N
+    rnd = random.Random(26)
+    edge = _edge_fr()
+    a = edge + [rnd.randrange(n) for _ in range(3000)] + [e for e in edge for _ in edge]
+    b = edge[::-1] + [rnd.randrange(n) for _ in range(3000)] + [f for _ in edge for f in edge]
+    assert _fe_op(gpu, "add", 3, a, b) == [(x + y) % n for x, y in zip(a, b)]
+    assert _fe_op(gpu, "sub", 3, a, b) == [(x - y) % n for x, y in zip(a, b)]
+    assert _fe_op(gpu, "mul", 3, a, b) == [(x * y) % n for x, y in zip(a, b)]
+    assert _fe_op(gpu, "sqr", 3, a, b) == [(x * x) % n for x in a]
+    assert _fe_op(gpu, "neg", 3, a, b) == [(-x) % n for x in a]
+
+
+def test_fr26_worst_case_magnitudes(gpu):
+    """every limb at its magnitude-8 (mul, sqr) / magnitude-16 (normalize, weak, is_zero) bound must still be exact"""
+    n = O.N
+    rnd = random.Random(27)
+    edge = _edge_fr()
+    a = edge + [rnd.randrange(n) for _ in range(3000)] + [e for e in edge for _ in edge]
+    b = edge[::-1] + [rnd.randrange(n) for _ in range(3000)] + [f for _ in edge for f in edge]
+    assert _fe_op(gpu, "mag8mul", 3, a, b) == [(-56 * x * y) % n for x, y in zip(a, b)]
+    assert _fe_op(gpu, "fr_mag8sqr", 3, a, b) == [(64 * x * x) % n for x in a]
+    assert _fe_op(gpu, "fr_mag16norm", 3, a, b) == [(8 * x - 7 * y) % n for x, y in zip(a, b)]
+    assert _fe_op(gpu, "fr_reduced_chain", 3, a, b) == [(2 * x - y) % n for x, y in zip(a, b)]
+    assert _fe_op(gpu, "fr_weak16", 3, a, b) == [(16 * x) % n for x in a]
+    # is_zero at magnitude 16: 8a == 7b exactly when b = 8a/7
+    inv7 = O.inv_mod(7, n)
+    b2 = [(8 * x * inv7) % n if i % 2 == 0 else y for i, (x, y) in enumerate(zip(a, b))]
+    assert _fe_op(gpu, "fr_is_zero16", 3, a, b2) == [int((8 * x - 7 * y) % n == 0) for x, y in zip(a, b2)]
