@@ -32,6 +32,7 @@
 #include "rpsetup.hpp"
 #include "sha256.hip.h"
 #include "rp_internal.hpp"
+#include "brp.hpp"
 #include "rphash.hip.h"
 #include "fr26.hip.h"
 
@@ -289,7 +290,6 @@ __global__ void __launch_bounds__(128) k_rp_hash(RpDims D, uint32_t batch, uint3
 //   the argument's public opening (:215-219): scalar t^2 sc, norm vector t p_i (zero beyond the live positions), linear weights
 //   [0, r t] (setupBRP's psv, :151-152), and the initCom scalars of TranscriptBRP (:107-110) in commitment order blCom : dCom : nComs =
 //   1, t, 2 t^2 inputCoeffs (:127-129).  q0 = q^2 (NL) or -q^2 (IP) as qPowers' has it.
-struct BrpDims { uint32_t nlen, nlive, nr, conserve, flavour; };
 __global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, const uint32_t *__restrict__ pos_range, const uint32_t *__restrict__ pos_coeff,
                                                    const uint32_t *__restrict__ range_min, const uint32_t *__restrict__ range_flags, const uint32_t *__restrict__ net_public,
                                                    const uint32_t *__restrict__ ch, uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp,
@@ -444,11 +444,6 @@ int rp_build_plan(bppp_rp *rp) {
 
 extern "C" void bppp_basis_destroy(bppp_basis *basis);
 
-// device tables of a RangeProof.Binary setup (k_brp_public)
-struct bppp_brp_tabs {
-  uint32_t *pos_range = nullptr, *pos_coeff = nullptr, *range_min = nullptr, *range_flags = nullptr, *net_public = nullptr;
-  BrpDims D{};
-};
 static void brp_tabs_destroy(bppp_brp_tabs *t) {
   if (!t) return;
   for (uint32_t *p : {t->pos_range, t->pos_coeff, t->range_min, t->range_flags, t->net_public}) if (p) hipFree(p);
@@ -480,7 +475,8 @@ static int brp_build_tables(bppp_rp *rp) {
     return rc;
   return BPPP_OK;
 }
-static int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint32_t *q, uint32_t *sp, uint32_t *pub_norm, uint32_t *pub_lin_c, uint32_t *init_sc) {
+namespace bppp {
+int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint32_t *q, uint32_t *sp, uint32_t *pub_norm, uint32_t *pub_lin_c, uint32_t *init_sc) {
   bppp_ctx *ctx = rp->ctx;
   const bppp_brp_tabs *t = rp->btabs;
   const size_t lds = ((size_t)t->D.nr + 64) * 32;
@@ -490,6 +486,7 @@ static int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint
   BPPP_HIP(ctx, hipGetLastError());
   return BPPP_OK;
 }
+}  // namespace bppp
 
 void RpOptions::from_env() {
   auto num = [](const char *name, size_t &dst) { if (const char *e = getenv(name)) dst = (size_t)atol(e); };
@@ -522,6 +519,7 @@ void bppp_rp_destroy(bppp_rp *rp) {
   if (rp->d_fixed) hipFree(rp->d_fixed);
   if (rp->commit_basis) bppp_basis_destroy(rp->commit_basis);
   if (rp->pwork) hipFree(rp->pwork);
+  if (rp->awork) hipFree(rp->awork);
   if (rp->hpin) hipHostFree(rp->hpin);
   if (rp->twin) bppp_rp_destroy(rp->twin);
   if (rp->d_comb_out) hipFree(rp->d_comb_out);

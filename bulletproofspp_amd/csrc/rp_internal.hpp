@@ -102,6 +102,7 @@ struct bppp_rp {
   uint32_t *d_fixed = nullptr;
   bppp_basis *commit_basis = nullptr;           // [g | H | G] registered with its fixed-base table: the range-proof commitments
   void *pwork = nullptr; size_t pwork_bytes = 0;
+  void *awork = nullptr; size_t awork_bytes = 0;   // grow-only workspace of the device-resident inner-product argument (csrc/ipb.hip)
   void *hpin = nullptr; size_t hpin_bytes = 0;     // pinned host staging of the batch prover
   // the creation arguments, kept so that a second handle on its OWN context (stream, workspaces) can be made: a large prove batch
   // runs as two half-batches in flight, the host shares of one under the kernels of the other (csrc/rpprove.hip)

@@ -730,6 +730,8 @@ static int ip_argument_lockstep(bppp_rp *rp, size_t B, size_t k, const uint64_t 
 
 static int prove_batch_binary(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
                               uint8_t *coms_files, uint8_t *proof_files);
+static int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
+                                  uint8_t *coms_files, uint8_t *proof_files);
 
 static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base);
@@ -742,21 +744,27 @@ extern "C" int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *am
   if (!batch) return BPPP_OK;
   if (!amounts || (!types && rp->st.kind == 0) || !blinds || (prefix_len && !rand_prefix) || !coms_files || !proof_files || batch >= (1u << 20) || prefix_len > 4096)
     return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: bad arguments");
-  if (rp->st.kind == 1) return prove_batch_binary(rp, batch, amounts, blinds, rand_prefix, prefix_len, coms_files, proof_files);
-  // inner-product flavour: the range-proof phases with their field algebra on the host cores, then the lockstep argument of
+  const size_t comb_min = rp->opt.comb_min;     // default 1024: the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
+  // ... or one that has proved that many proofs in smaller batches: with the table in place every batch size is faster (one 64by64 proof:
+  // 12 ms against 22 ms; 256: 22 against 48)
+  if (!rp->is_twin && !rp->opt.host_algebra) {
+    rp->proved_total += batch;
+    if (batch >= comb_min || rp->proved_total >= comb_min) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
+  }
+  // RangeProof.Binary: with the comb table in place the whole proof is a stream of kernels (csrc/brpprove_dev.hip); before that (small
+  // batches) and under BPPP_RP_HOST_ALGEBRA the field algebra and the hashing run on the host cores (prove_batch_binary)
+  if (rp->st.kind == 1) {
+    if (rp->comb && !rp->opt.host_algebra && !rp->opt.fold_points) return prove_batch_binary_dev(rp, batch, amounts, blinds, rand_prefix, prefix_len, coms_files, proof_files);
+    return prove_batch_binary(rp, batch, amounts, blinds, rand_prefix, prefix_len, coms_files, proof_files);
+  }
+  // inner-product flavour without a table: the range-proof phases with their field algebra on the host cores, then the lockstep argument of
   // ip_argument_lockstep (no basis change, no point fold: every commitment an MSM over the registered original basis)
-  if (rp->st.flavour != 0) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
+  if (rp->st.flavour != 0 && (!rp->comb || rp->opt.fold_points))
+    return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
   // A large batch runs as TWO half-batches in flight, the second on a twin handle with its own context (stream, workspaces, host
   // thread): the proofs are independent, and the host shares of a half (digits, the argument's half-GCDs and round bookkeeping,
   // the challenge round trips) fall under the kernels of the other.  Same bytes out as one batch (tests).
   const size_t split_min = rp->opt.split_min;   // default 4096; measured: 4096 proofs 91-93 ms split against 95-97 ms, but 2048 proofs (128by64) 109 ms split against 104 ms
-  const size_t comb_min = rp->opt.comb_min;     // default 1024: the table costs ~0.3 s and tens of GB once: worth it for a handle that proves large batches
-  // ... or one that has proved that many proofs in smaller batches: with the table in place every batch size is faster (one 64by64 proof:
-  // 12 ms against 22 ms; 256: 22 against 48)
-  if (!rp->is_twin) {
-    rp->proved_total += batch;
-    if (batch >= comb_min || rp->proved_total >= comb_min) { int rc = rp_ensure_comb(rp); if (rc) return rc; }
-  }
   if (batch < split_min || batch < 2 || rp->is_twin || rp->opt.no_split)
     return prove_batch_one(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, 0);
   { int rc = rp_ensure_twin(rp); if (rc) return rc; }
@@ -783,7 +791,7 @@ static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, c
   for (const RangeData &rd : st.rds) max_base = std::max(max_base, rd.base);
   // the device algebra looks digits up in a 256-entry table of reciprocals; wider bases (and BPPP_RP_HOST_ALGEBRA=1, kept for
   // comparison) take the host-algebra path: same bytes out
-  if (max_base > 256 || rp->opt.host_algebra) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
+  if (max_base > 256 || rp->opt.host_algebra || (st.flavour && !rp->comb)) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
   hipSetDevice(ctx->device);
   const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
   if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");
@@ -1261,5 +1269,83 @@ static int prove_batch_binary(bppp_rp *rp, size_t batch, const uint64_t *amounts
       encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 2 + 2 * k);
     }
   });
+  return BPPP_OK;
+}
+
+// The same proofs with proveBRPM's field algebra, randomness and transcript on the device (csrc/brpprove_dev.hip): the host checks the
+// witness (witnessBRP, Binary.hs:158-166), extracts the binary digits of the plain amounts (makeDigits :56-69) and writes the files.
+static int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
+                                  uint8_t *coms_files, uint8_t *proof_files) {
+  bppp_ctx *ctx = rp->ctx;
+  hipSetDevice(ctx->device);
+  const Setup &st = rp->st;
+  const size_t B = batch, nr = st.rds.size(), nlive = st.nlive, k = st.rounds;
+  const bool timing = rp->opt.timing;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = timing ? now() : 0;
+  auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[rp_prove binary] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
+  // pinned staging, grow-only: [in_sc B nr 3 | input commitments B nr | bits B nlive]
+  const size_t n_in_sc = B * nr * 12, n_in_pt = B * nr * 8;
+  const size_t pin_need = (n_in_sc + n_in_pt) * 8 + B * nlive + 64;
+  if (pin_need > rp->hpin_bytes) {
+    BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rp->hpin) BPPP_HIP(ctx, hipHostFree(rp->hpin));
+    rp->hpin = nullptr; rp->hpin_bytes = 0;
+    BPPP_HIP(ctx, hipHostMalloc(&rp->hpin, pin_need + pin_need / 8, hipHostMallocDefault));
+    rp->hpin_bytes = pin_need + pin_need / 8;
+  }
+  uint64_t *h_in_sc = (uint64_t *)rp->hpin, *h_in_pt = h_in_sc + n_in_sc;
+  uint8_t *bits = (uint8_t *)(h_in_pt + n_in_pt);
+  std::atomic<int> failed{-1};
+  std::vector<std::string> errs(B);
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    std::vector<uint32_t> dg;
+    for (size_t b = lo; b < hi; b++) {
+      U256 vsum = st.net_public;
+      const char *err = nullptr;
+      size_t p = 0;
+      for (size_t i = 0; i < nr && !err; i++) {
+        const RangeData &rd = st.rds[i];
+        const U256 amt = U256::load(amounts + 4 * (b * nr + i));
+        if (!scalars_canonical(blinds + 4 * (b * nr + i), 1)) { err = "blinding is not canonical"; break; }
+        const U256 v = bppp_rps::s_mod_n(amt);
+        vsum = rd.output ? fs(vsum, v) : fa(vsum, v);
+        uint64_t *row = &h_in_sc[(b * nr + i) * 12];          // scalarRPW' (Internal.hs:56-57): v g + bl h0
+        v.store(row); memcpy(row + 4, blinds + 4 * (b * nr + i), 32); memset(row + 8, 0, 32);
+        if (rd.assumed) continue;
+        if (bppp_rps::s_lt(amt, rd.lo) || !bppp_rps::s_lt(amt, rd.hi)) { err = "value outside its range"; break; }
+        bppp_rps::digits_binary_into(rd, bppp_rps::u_sub(amt, rd.lo), dg);
+        for (uint32_t d : dg) bits[b * nlive + p++] = (uint8_t)d;
+      }
+      if (!err && !(st.conserve && vsum.is_zero())) err = "a binary witness needs a conserved schema whose amounts balance (Binary.hs:162-164)";
+      if (!err && p != nlive) err = "digit count disagrees with the setup";
+      if (err) { failed = (int)b; errs[b] = err; }
+    }
+  });
+  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed) + ": " + errs[failed]);
+  lap("witness, digits (host)");
+  std::vector<uint64_t> c_d(B * 8), c_bl(B * 8), resp(B * (k ? k : 1) * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
+  BrpHostInputs in{B, h_in_sc, bits, rand_prefix, prefix_len};
+  BrpOutputs out{h_in_pt, c_d.data(), c_bl.data(), resp.data(), wn.data(), wl.data()};
+  { int rc = brp_device_prove(rp, in, out); if (rc) return rc; }
+  lap("phases + argument (device)");
+  // encodeProof': commitments file = the input commitments; proof file = final witness scalars, then blCom, dCom and the responses
+  const RpDims &D = rp->D;
+  rp_parallel(B, [&](size_t lo, size_t hi) {
+    std::vector<const uint64_t *> pts;
+    for (size_t b = lo; b < hi; b++) {
+      pts.assign(nr, nullptr);
+      for (size_t i = 0; i < nr; i++) pts[i] = &h_in_pt[(b * nr + i) * 8];
+      encode_points(coms_files + b * D.coms_bytes, pts.data(), nr);
+      uint8_t *pf = proof_files + b * D.proof_bytes;
+      for (size_t i = 0; i < st.fn; i++) put_field(pf + 32 * i, U256::load(&wn[(b * st.fn + i) * 4]));
+      for (size_t i = 0; i < st.fl; i++) put_field(pf + 32 * (st.fn + i), U256::load(&wl[(b * st.fl + i) * 4]));
+      pts.assign(2 + 2 * k, nullptr);
+      pts[0] = &c_bl[8 * b]; pts[1] = &c_d[8 * b];
+      for (size_t j = 0; j < 2 * k; j++) pts[2 + j] = &resp[(b * k) * 16 + 8 * j];
+      encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 2 + 2 * k);
+    }
+  });
+  lap("encode (host)");
   return BPPP_OK;
 }

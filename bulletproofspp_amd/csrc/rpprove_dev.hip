@@ -31,6 +31,8 @@
 #include "rphash.hip.h"
 #include "comb.hpp"
 #include "rpprove_dev.hpp"
+#include "rpp_transcript.hpp"
+#include "ipb.hpp"
 #include "trrp.hpp"
 
 namespace bppp {
@@ -46,48 +48,8 @@ BPPP_DI fe pf_small(uint32_t v) { fe r = fe_zero(); r.v[0] = v; return r; }
 BPPP_DI fe lget(const uint32_t *p, uint32_t i) { fe r; for (int k = 0; k < 8; k++) r.v[k] = p[i * 8 + k]; return r; }
 BPPP_DI void lput(uint32_t *p, uint32_t i, const fe &a) { for (int k = 0; k < 8; k++) p[i * 8 + k] = a.v[k]; }
 
-// ------------------------------------------------------------------------------------------------ randomness
-// random n = hash (prefix <> show n) (hashToScalar, app/Main.hs:83-84; ZKPT.random, src/ZKP.hs:88-92), n = 0 .. nd-1
-__global__ void __launch_bounds__(64) k_rpp_draws(const uint8_t *__restrict__ prefix, uint32_t plen, uint32_t batch, uint32_t nd, uint32_t *__restrict__ rnd) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint64_t)batch * nd) return;
-  const uint32_t b = (uint32_t)(g / nd), c = (uint32_t)(g % nd);
-  // decimal digits of the counter (at most 10), most significant first
-  uint32_t dig[10], nd10 = 0, v = c;
-  do { dig[nd10++] = v % 10u; v /= 10u; } while (v);
-  const uint8_t *pre = prefix + (size_t)b * plen;
-  const uint32_t mlen = plen + nd10, nblk = (mlen + 9 + 63) / 64;
-  uint32_t st[8], w[16];
-  sha256_init(st);
-  for (uint32_t blk = 0; blk < nblk; blk++) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      uint32_t word = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t p = blk * 64 + 4 * i + j;
-        uint32_t byte = 0;
-        if (p < plen) byte = pre[p];
-        else if (p < mlen) {
-          const uint32_t k = nd10 - 1 - (p - plen);
-          uint32_t dv = 0;
-#pragma unroll
-          for (int q = 0; q < 10; q++) if ((uint32_t)q == k) dv = dig[q];
-          byte = '0' + dv;
-        } else if (p == mlen) byte = 0x80;
-        word = (word << 8) | byte;
-      }
-      w[i] = word;
-    }
-    if (blk == nblk - 1) { w[14] = 0; w[15] = mlen * 8; }
-    sha256_compress(st, w);
-  }
-  fe r; sha256_digest_to_limbs(st, r.v);
-  fe t; const uint32_t br = raw_sub(t, r, fr_modulus());
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : t.v[i];
-  fe_store(rnd + g * 8, r);
-}
+// (k_rpp_draws: csrc/rpp_transcript.hip)
+
 
 // ------------------------------------------------------------------------------------------------ phase 1 rows
 // dmWit = blindWitness 3 2 msShared ds, mWit = blindWitness 3 1 [] msInline (TypedReciprocal.hs:408-410; Internal.hs:130-139):
@@ -238,7 +200,8 @@ __global__ void __launch_bounds__(64) k_rpp_phase3(PDims D, TrrpDims TD, const u
   const fe e = fe_load(c), x = fe_load(c + 8), q = fe_load(c + 24), xp = fe_load(c + 32), r1 = fe_load(c + 40);
   const uint32_t *it = invtab + (size_t)b * (INV_DIG + 256) * 8;
   const fe e_inv = fe_load(it + INV_E * 8), r0_inv = fe_load(it + INV_R0 * 8);
-  const fe q0 = pfs(q);                               // qPowers' of the NL norm (NormArgument.hs:148)
+  fe q0 = pfs(q);                                     // qPowers': powers' (q^2) of the NL norm (NormArgument.hs:148),
+  if (TD.flavour) q0 = fe_neg<1>(q0);                 // powers' (-q^2) of the IP one (InnerProductArgument.hs:231)
   if (t == 0) lput(sh, 0, fe_modinv<1>(r1));
   const fe xx = pfs(x), x3 = pfm(xx, x);
   for (uint32_t j = t; j < D.nr; j += 64) lput(x2, j, pf_pow(xx, j + 1));
@@ -375,62 +338,8 @@ __global__ void __launch_bounds__(256) k_rpp_combine(PDims D, uint32_t batch, co
   }
 }
 
-// ------------------------------------------------------------------------------------------------ transcript
-// The text of a proof sits RIGHT-ALIGNED in its buffer [b * stride, (b + 1) * stride - 16): new commitments are written in front
-// of the current start (ZKPT.oracle prepends, src/ZKP.hs:98).  One workgroup per proof; pts is [batch][m] affine.
-__global__ void __launch_bounds__(256) k_rpp_text_prepend(const uint32_t *__restrict__ pts, uint32_t m, uint8_t *__restrict__ text, uint32_t stride,
-                                                          uint32_t *__restrict__ tstart) {
-  extern __shared__ uint32_t lens[];            // [m + 1]
-  __shared__ uint32_t wsum[4];
-  const uint32_t b = blockIdx.x, tid = threadIdx.x;
-  for (uint32_t t = tid; t < m; t += 256) {
-    const uint32_t *p = pts + ((size_t)b * m + t) * 16;
-    lens[t] = dec_convert(fe_load(p)).len + dec_convert(fe_load(p + 8)).len;
-  }
-  __syncthreads();
-  const uint32_t per = (m + 255) / 256, lo = min(m, tid * per), hi = min(m, lo + per);
-  uint32_t s = 0;
-  for (uint32_t t = lo; t < hi; t++) s += lens[t];
-  uint32_t inc = s;
-  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if ((int)(tid & 63) >= d) inc += o; }
-  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-  __syncthreads();
-  uint32_t run = inc - s;
-  for (uint32_t w = 0; w < (tid >> 6); w++) run += wsum[w];
-  __syncthreads();
-  for (uint32_t t = lo; t < hi; t++) { const uint32_t l = lens[t]; lens[t] = run; run += l; }
-  if (tid == 255) lens[m] = run;
-  __syncthreads();
-  const uint32_t total = lens[m], start = tstart[b] - total;
-  uint8_t *tx = text + (size_t)b * stride + start;
-  for (uint32_t t = tid; t < m; t += 256) {
-    const uint32_t *p = pts + ((size_t)b * m + t) * 16;
-    const Dec dx = dec_convert(fe_load(p)), dy = dec_convert(fe_load(p + 8));
-    uint8_t *end = tx + lens[t] + dx.len + dy.len;
-    end = dec_write_backward(dy, end);
-    dec_write_backward(dx, end);
-  }
-  __syncthreads();
-  if (tid == 0) tstart[b] = start;
-}
+// (the transcript kernels and the randomness live in csrc/rpp_transcript.hip)
 
-// challenge n (1 <= n <= count) of every proof: SHA-256 (hdr_n <> text from the current start); out slot of challenge n: ch_slot[n-1]
-// into ch[b][7] (slot < 7) or es[b] (slot = 7)
-struct RppHdrs { uint32_t hdr_be[3][RP_HDR_MAX / 4]; uint32_t hlen[3]; uint32_t slot[3]; };
-// 64 hashes per workgroup of two wavefronts (producer / consumer, rphash.hip.h): g = n * batch + b
-__global__ void __launch_bounds__(128) k_rpp_hash(const RppHdrs *__restrict__ H, uint32_t count, uint32_t batch, const uint8_t *__restrict__ text, uint32_t stride,
-                                                  const uint32_t *__restrict__ tstart, uint32_t tend, uint32_t *__restrict__ ch, uint32_t *__restrict__ es) {
-  __shared__ uint32_t lds[RP_HASH_PC_LDS_WORDS];
-  const uint64_t g = (uint64_t)blockIdx.x * 64 + (threadIdx.x & 63u);
-  const bool active = g < (uint64_t)batch * count;
-  const uint32_t n = active ? (uint32_t)(g / batch) : 0u, b = active ? (uint32_t)(g % batch) : 0u;
-  const uint32_t s = tstart[b];
-  const fe v = rp_hash_to_fr_pc(active, H->hdr_be[n], H->hlen[n], text + (size_t)b * stride + s, tend - s, lds);
-  if (!active || threadIdx.x < 64) return;
-  const uint32_t slot = H->slot[n];
-  if (slot < 7) fe_store(ch + ((size_t)b * 7 + slot) * 8, v);
-  else fe_store(es + (size_t)b * 8, v);
-}
 
 }  // namespace bppp
 
@@ -438,6 +347,66 @@ using namespace bppp;
 
 // ================================================================================================ host orchestration of one batch
 namespace bppp {
+
+// proveBPM for B proofs whose start state lies in HBM, as ONE stream of kernels behind the range-proof phases: the norm-linear argument in
+// fixed-basis mode (csrc/nlb.hip) or the inner-product argument (csrc/ipb.hip), by the setup's flavour; both commit through the handle's comb
+// table, both take their challenges from `tr` (calls first_call ...).  In (device): s [B], q [B] (makeNorm's r for the inner-product flavour),
+// nx [B][nlen], lc / lx [B][llen]; d_resp [k][B][2][16] scratch.  Out (host): resp [B][k][16] LAST round first (Bulletproof.hs:359), the final
+// witness; `d_extra` (extra_points affine points, e.g. the range-proof commitments) comes back in the same download.  Synchronises the stream.
+int rpp_argument_stream(bppp_rp *rp, RppTranscript &tr, size_t first_call, size_t B, const uint32_t *a_s, const uint32_t *a_q, const uint32_t *a_nx, const uint32_t *a_lc,
+                        const uint32_t *a_lx, uint32_t *d_resp, uint64_t *resp_out, uint64_t *wn_out, uint64_t *wl_out, const uint32_t *d_extra, size_t extra_points,
+                        std::vector<uint64_t> &extra_out) {
+  bppp_ctx *ctx = rp->ctx;
+  hipStream_t st = ctx->stream;
+  const bppp_rps::Setup &S = rp->st;
+  const size_t nlen = S.nlen, llen = S.llen, k = S.rounds;
+  int rc = BPPP_OK;
+  extra_out.resize(extra_points * 8);
+  std::vector<uint64_t> hresp(k * B * 16 + 16);
+  if (S.flavour) {
+    const size_t wb = ipb_work_bytes(B, nlen, llen), wit = (B * (S.fn + S.fl) * 32 + 255) & ~(size_t)255;
+    if (wb + wit + 256 > rp->awork_bytes) {
+      BPPP_HIP(ctx, hipStreamSynchronize(st));
+      if (rp->awork) BPPP_HIP(ctx, hipFree(rp->awork));
+      rp->awork = nullptr; rp->awork_bytes = 0;
+      BPPP_HIP(ctx, hipMalloc(&rp->awork, wb + wit + 256));
+      rp->awork_bytes = wb + wit + 256;
+    }
+    uint32_t *d_wn = (uint32_t *)((char *)rp->awork + wb), *d_wl = d_wn + B * S.fn * 8, *d_flag = nullptr;
+    rc = ipb_prove_stream(ctx, rp->comb, tr, first_call, B, nlen, llen, k, S.fn, S.fl, a_s, a_q, a_nx, a_lc, a_lx, rp->awork, wb, d_resp, d_wn, d_wl, &d_flag);
+    if (rc) return rc == BPPP_ERR_ARG && !*bppp_last_error(ctx) ? fail(ctx, rc, "rp_prove_batch: inner-product argument: bad arguments") : rc;
+    uint32_t hflag = 0;
+    if (extra_points) BPPP_HIP(ctx, hipMemcpyAsync(extra_out.data(), d_extra, extra_points * 64, hipMemcpyDeviceToHost, st));
+    if (k) BPPP_HIP(ctx, hipMemcpyAsync(hresp.data(), d_resp, k * B * 128, hipMemcpyDeviceToHost, st));
+    if (S.fn) BPPP_HIP(ctx, hipMemcpyAsync(wn_out, d_wn, B * S.fn * 32, hipMemcpyDeviceToHost, st));
+    if (S.fl) BPPP_HIP(ctx, hipMemcpyAsync(wl_out, d_wl, B * S.fl * 32, hipMemcpyDeviceToHost, st));
+    BPPP_HIP(ctx, hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, st));
+    BPPP_HIP(ctx, hipStreamSynchronize(st));
+    if (hflag) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: a round challenge is zero");
+  } else {
+    bppp_nlb *nlb = nullptr;
+    rc = nlb_create_impl(ctx, B, (const uint64_t *)a_s, (const uint64_t *)rp->d_g(), (const uint64_t *)a_q, (const uint64_t *)a_nx, (const uint64_t *)rp->d_G(), nlen,
+                         (const uint64_t *)a_lc, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, rp->comb);
+    if (rc) return rc;
+    for (size_t round = 0; round < k && !rc; round++) {
+      uint32_t *xr_dev = d_resp + round * B * 32;
+      rc = nlb_round_commit_dev(nlb, xr_dev); if (rc) break;
+      rc = tr.call(xr_dev, first_call + round); if (rc) break;
+      if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: round kernels"); break; }
+      rc = nlb_round_collapse_dev(nlb, tr.es);
+    }
+    // everything the files need comes back now: the range-proof commitments, the 2k responses, the final witness
+    if (!rc && ((extra_points && hipMemcpyAsync(extra_out.data(), d_extra, extra_points * 64, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+                (k && hipMemcpyAsync(hresp.data(), d_resp, k * B * 128, hipMemcpyDeviceToHost, st) != hipSuccess)))
+      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: result download");
+    if (!rc) rc = bppp_nlb_get_witness(nlb, wn_out, wl_out, nullptr);        // synchronises the stream
+    bppp_nlb_destroy(nlb);
+    if (rc) return rc;
+  }
+  for (size_t b = 0; b < B; b++)
+    for (size_t round = 0; round < k; round++) memcpy(resp_out + (b * k + (k - 1 - round)) * 16, &hresp[(round * B + b) * 16], 128);   // responses LAST round first (:359)
+  return BPPP_OK;
+}
 
 int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   bppp_ctx *ctx = rp->ctx;
@@ -449,13 +418,13 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   const bppp_trrp *tb = rp->tabs;
   const TrrpDims TD = tb->D;
   // text capacity per proof: every commitment of the final transcript (4 + nr + 2k points), right-aligned, 16 bytes of slack at the end
-  const uint32_t stride = rp->D.text_stride, tend = stride - 16;
+  const uint32_t stride = rp->D.text_stride;
 
   // ---- carve the device workspace
   uint32_t *in_sc = nullptr, *in_pt = nullptr, *dig = nullptr, *mul = nullptr, *mss = nullptr, *rnd = nullptr, *rows_dm_m = nullptr, *row_r = nullptr, *row_bl = nullptr,
            *ccbuf = nullptr, *invtab = nullptr, *aux = nullptr, *ch = nullptr, *es = nullptr, *tstart = nullptr, *ptbuf = nullptr, *a_s = nullptr, *a_q = nullptr,
            *a_lx = nullptr, *a_nx = nullptr, *p_sp = nullptr, *p_norm = nullptr, *p_cs = nullptr, *p_init = nullptr;
-  uint8_t *text = nullptr, *prefix = nullptr; RppHdrs *hdrs = nullptr; uint32_t *d_resp = nullptr, *d_com = nullptr, *cscratch = nullptr;
+  uint8_t *text = nullptr, *prefix = nullptr, *hdrs = nullptr; uint32_t *d_resp = nullptr, *d_com = nullptr, *cscratch = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv(pass ? rp->pwork : nullptr, rp->pwork_bytes);
     in_sc = cv.take<uint32_t>(B * nr * 24); in_pt = cv.take<uint32_t>(B * nr * 16);
@@ -467,7 +436,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     ptbuf = cv.take<uint32_t>(B * (2 + nr) * 16);
     a_s = cv.take<uint32_t>(B * 8); a_q = cv.take<uint32_t>(B * 8); a_lx = cv.take<uint32_t>(B * llen * 8); a_nx = cv.take<uint32_t>(B * nlen * 8);
     p_sp = cv.take<uint32_t>(B * 8); p_norm = cv.take<uint32_t>(B * nlen * 8); p_cs = cv.take<uint32_t>(B * llen * 8); p_init = cv.take<uint32_t>(B * (4 + nr) * 8);
-    text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<RppHdrs>(3 + k);
+    text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<uint8_t>(RppTranscript::hdr_bytes(3 + k) + 16);
     d_resp = cv.take<uint32_t>(k * B * 32 + 16); d_com = cv.take<uint32_t>(4 * B * 16 + 16);
     cscratch = cv.take<uint32_t>(std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B)) / 4 + 16);
     if (!pass) { int rc = rpp_ensure_pwork(rp, cv.off); if (rc) return rc; }
@@ -482,61 +451,16 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   // every oracle call reads its points where they lie, and the headers of all 3 + k oracle calls go up here
   const bool stream_mode = rp->comb != nullptr && !rp->opt.fold_points;
   const size_t cscratch_bytes = std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B));
-  {
-    std::vector<uint32_t> ts(B, tend);
-    BPPP_HIP(ctx, hipMemcpyAsync(tstart, ts.data(), B * 4, hipMemcpyHostToDevice, st));
-    std::vector<RppHdrs> hh(3 + k);
-    if (stream_mode) {
-      size_t np = 0;
-      const size_t add[3] = {2 + nr, 1, 1}; const int cnt[3] = {3, 3, 1}; const uint32_t first_slot[3] = {0, 3, 6};
-      for (size_t c = 0; c < 3 + k; c++) {
-        memset(&hh[c], 0, sizeof(RppHdrs));
-        np += c < 3 ? add[c] : 2;
-        for (int n = 1; n <= (c < 3 ? cnt[c] : 1); n++) {
-          const std::string hs = rp->tag + std::to_string(n) + std::to_string(np);
-          if (hs.size() > 64) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: oracle tag too long");
-          rp_pack_header(hs, hh[c].hdr_be[n - 1]); hh[c].hlen[n - 1] = (uint32_t)hs.size(); hh[c].slot[n - 1] = c < 3 ? first_slot[c] + (uint32_t)(n - 1) : 7u;
-        }
-      }
-      BPPP_HIP(ctx, hipMemcpyAsync(hdrs, hh.data(), (3 + k) * sizeof(RppHdrs), hipMemcpyHostToDevice, st));
-    }
-    BPPP_HIP(ctx, hipStreamSynchronize(st));          // ts, hh go out of scope
-  }
   // A handful of proofs: the oracle moves to the host.  One GPU lane walks the ~160 SHA-256 blocks of a 64by64 transcript in ~0.6 ms
   // (11 times per proof); a host core needs ~50 us, which pays for the round trip of the new points and the challenges as long as
   // the batch is small (BPPP_RP_HOST_ORACLE_MAX, default 64 proofs: 1 proof 5.2 ms against 12.0 ms, 32 proofs 11.2 against 12.7, level at 128; the
   // host hashes with the CPU's SHA extensions, csrc/sha256.hip.h, up to 16 threads).
-  const size_t host_oracle_max = rp->opt.host_oracle_prove;
-  const bool host_oracle = stream_mode && B <= host_oracle_max;
-  std::vector<std::vector<std::string>> h_groups(host_oracle ? B : 0);
-  std::vector<size_t> h_np(host_oracle ? B : 0, 0);
-  auto oracle_dev = [&](const uint32_t *pts_dev, size_t m, size_t call, int count) -> int {
-    if (!host_oracle) {
-      k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), (m + 1) * 4, st>>>(pts_dev, (uint32_t)m, text, stride, tstart);
-      const uint64_t n = (uint64_t)B * count;
-      k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st>>>(hdrs + call, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
-      return BPPP_OK;
-    }
-    std::vector<uint64_t> hp(B * m * 8), ho(B * 3 * 4);
-    BPPP_HIP(ctx, hipMemcpyAsync(hp.data(), pts_dev, B * m * 64, hipMemcpyDeviceToHost, st));
-    BPPP_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t first_slot = call == 0 ? 0u : call == 1 ? 3u : call == 2 ? 6u : 7u;
-    {
-      auto work = [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) rpp_host_oracle(rp->tag, h_groups[b], h_np[b], &hp[b * m * 8], m, count, &ho[b * 12]); };
-      const size_t nt = std::min<size_t>(B / 16, 16);          // a proof's call is ~10 us of hashing and text: threads only pay from a few dozen proofs
-      if (nt <= 1) work(0, B);
-      else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; t++) th.emplace_back(work, B * t / nt, B * (t + 1) / nt);
-        for (auto &x : th) x.join();
-      }
-    }
-    if (first_slot == 7) BPPP_HIP(ctx, hipMemcpy2DAsync(es, 32, ho.data(), 96, 32, B, hipMemcpyHostToDevice, st));
-    else BPPP_HIP(ctx, hipMemcpy2DAsync(ch + first_slot * 8, 7 * 32, ho.data(), 96, (size_t)count * 32, B, hipMemcpyHostToDevice, st));
-    BPPP_HIP(ctx, hipStreamSynchronize(st));          // hp, ho go out of scope
-    return BPPP_OK;
-  };
-  { const uint64_t n = (uint64_t)B * D.nd; k_rpp_draws<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(prefix, (uint32_t)in.prefix_len, (uint32_t)B, D.nd, rnd); }
+  const bool host_oracle = stream_mode && B <= rp->opt.host_oracle_prove;
+  // the oracle calls of proveTRRPM (TypedReciprocal.hs:412, :421, :438): ([dmCom, mCom] ++ nComs) -> e x r0; [rCom] -> q x' r1; [blCom] -> t
+  RppTranscript tr;
+  { int rc_ = tr.begin(rp, B, {RppCall{(uint32_t)(2 + nr), 3, 0}, RppCall{1, 3, 3}, RppCall{1, 1, 6}}, k, host_oracle, text, tstart, hdrs, ch, es); if (rc_) return rc_; }
+  auto oracle_dev = [&](const uint32_t *pts_dev, size_t call) -> int { return tr.call(pts_dev, call); };
+  { int rc_ = rpp_draws(ctx, prefix, in.prefix_len, B, D.nd, rnd); if (rc_) return rc_; }
   { const uint64_t n = (uint64_t)B * T;
     k_rpp_rows_dm_m<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(D, tb->pos_kind, tb->pos_range, in_sc, dig, mul, mss, rnd, (uint32_t)B, rows_dm_m); }
   BPPP_HIP(ctx, hipGetLastError());
@@ -552,49 +476,31 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
       return r_ ? fail(ctx, r_, bppp_last_error(rp->comb->ctx)) : BPPP_OK;
     };
     uint32_t *c_dmm = d_com, *c_r = d_com + 2 * B * 16, *c_bl = d_com + 3 * B * 16;
+    std::vector<uint64_t> hcom_host;
     // (e, x, r0) <- oracle ([dmCom, mCom] ++ nComs)   (TypedReciprocal.hs:412)
     rc = comb(rows_dm_m, 2 * B, c_dmm); if (rc) return rc;
     BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf, (2 + nr) * 64, c_dmm, 128, 128, B, hipMemcpyDeviceToDevice, st));
     BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf + 32, (2 + nr) * 64, in_pt, nr * 64, nr * 64, B, hipMemcpyDeviceToDevice, st));
-    rc = oracle_dev(ptbuf, 2 + nr, 0, 3); if (rc) return rc;
+    rc = oracle_dev(ptbuf, 0); if (rc) return rc;
     k_rpp_phase2<<<dim3((unsigned)B), dim3(64), lds2, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_sym, tb->syms, in_sc, dig, rnd, ch, row_r, ccbuf, invtab);
     // (q, x', r1) <- oracle [rCom]
     rc = comb(row_r, B, c_r); if (rc) return rc;
-    rc = oracle_dev(c_r, 1, 1, 3); if (rc) return rc;
+    rc = oracle_dev(c_r, 1); if (rc) return rc;
     k_rpp_phase3<<<dim3((unsigned)B), dim3(64), lds3, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_coeff, tb->range_assumed, tb->syms, tb->cs_slot, tb->cs_sym,
                                                             in_sc, dig, mul, rnd, ch, rows_dm_m, row_r, ccbuf, invtab, row_bl, aux);
     // t <- oracle [blCom]; public constants and linear weights by the verifier's kernel; the combined witness
     rc = comb(row_bl, B, c_bl); if (rc) return rc;
-    rc = oracle_dev(c_bl, 1, 2, 1); if (rc) return rc;
+    rc = oracle_dev(c_bl, 2); if (rc) return rc;
     BPPP_HIP(ctx, hipGetLastError());
     rc = bppp_trrp_public_device(rp->tabs, B, ch, a_q, p_sp, p_norm, p_cs, p_init); if (rc) return rc;
     { const uint64_t n = (uint64_t)B * T;
       k_rpp_combine<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(D, (uint32_t)B, ch, rows_dm_m, row_r, row_bl, aux, p_sp, p_norm, a_s, a_lx, a_nx); }
     BPPP_HIP(ctx, hipGetLastError());
     // proveBPM in lockstep (src/Bulletproof.hs:357-359): the start state taken where it lies in HBM, k rounds queued back to back
-    bppp_nlb *nlb = nullptr;
-    rc = nlb_create_impl(ctx, B, (const uint64_t *)a_s, (const uint64_t *)rp->d_g(), (const uint64_t *)a_q, (const uint64_t *)a_nx, (const uint64_t *)rp->d_G(), nlen,
-                         (const uint64_t *)p_cs, (const uint64_t *)a_lx, (const uint64_t *)rp->d_H(), llen, &nlb, true, rp->comb);
-    if (rc) return rc;
-    for (size_t round = 0; round < k && !rc; round++) {
-      uint32_t *xr_dev = d_resp + round * B * 32;
-      rc = nlb_round_commit_dev(nlb, xr_dev); if (rc) break;
-      rc = oracle_dev(xr_dev, 2, 3 + round, 1); if (rc) break;
-      if (hipGetLastError() != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: round kernels"); break; }
-      rc = nlb_round_collapse_dev(nlb, es);
-    }
-    // everything the files need comes back now: the four commitments, the 2k responses, the final witness
-    std::vector<uint64_t> hcom(4 * B * 8), hresp(k * B * 16);
-    if (!rc && (hipMemcpyAsync(hcom.data(), d_com, 4 * B * 64, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(hresp.data(), d_resp, k * B * 128, hipMemcpyDeviceToHost, st) != hipSuccess))
-      rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: result download");
-    if (!rc) rc = bppp_nlb_get_witness(nlb, out.wit_norm, out.wit_lin, nullptr);        // synchronises the stream
-    bppp_nlb_destroy(nlb);
-    if (rc) return rc;
+    rc = rpp_argument_stream(rp, tr, 3, B, a_s, a_q, a_nx, p_cs, a_lx, d_resp, out.resp, out.wit_norm, out.wit_lin, d_com, 4 * B, hcom_host); if (rc) return rc;
     for (size_t b = 0; b < B; b++) {
-      memcpy(out.c_dm + 8 * b, &hcom[16 * b], 64); memcpy(out.c_m + 8 * b, &hcom[16 * b + 8], 64);
-      memcpy(out.c_r + 8 * b, &hcom[(2 * B + b) * 8], 64); memcpy(out.c_bl + 8 * b, &hcom[(3 * B + b) * 8], 64);
-      for (size_t round = 0; round < k; round++) memcpy(out.resp + (b * k + (k - 1 - round)) * 16, &hresp[(round * B + b) * 16], 128);   // responses LAST round first (:359)
+      memcpy(out.c_dm + 8 * b, &hcom_host[16 * b], 64); memcpy(out.c_m + 8 * b, &hcom_host[16 * b + 8], 64);
+      memcpy(out.c_r + 8 * b, &hcom_host[(2 * B + b) * 8], 64); memcpy(out.c_bl + 8 * b, &hcom_host[(3 * B + b) * 8], 64);
     }
     return BPPP_OK;
   }
@@ -602,23 +508,11 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   rc = rpp_commit_rows(rp, rows_dm_m, 2 * B, com.data()); if (rc) return rc;            // synchronises
   for (size_t b = 0; b < B; b++) { memcpy(out.c_dm + 8 * b, &com[16 * b], 64); memcpy(out.c_m + 8 * b, &com[16 * b + 8], 64); }
 
-  // the oracle: `pts_host` are the new commitments of every proof ([B][m] affine, in the order the reference conses them); `count` outputs
-  size_t npoints = 0;
-  auto oracle = [&](const uint64_t *pts_host, const uint32_t *pts_dev, size_t m, int count, const uint32_t slots[3]) -> int {
-    if (pts_host) { BPPP_HIP(ctx, hipMemcpyAsync(ptbuf, pts_host, B * m * 64, hipMemcpyHostToDevice, st)); pts_dev = ptbuf; }
-    npoints += m;
-    RppHdrs h; memset(&h, 0, sizeof h);
-    for (int n = 1; n <= count; n++) {
-      const std::string s = rp->tag + std::to_string(n) + std::to_string(npoints);
-      if (s.size() > 64) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: oracle tag too long");
-      rp_pack_header(s, h.hdr_be[n - 1]); h.hlen[n - 1] = (uint32_t)s.size(); h.slot[n - 1] = slots[n - 1];
-    }
-    BPPP_HIP(ctx, hipMemcpyAsync(hdrs, &h, sizeof h, hipMemcpyHostToDevice, st));
-    BPPP_HIP(ctx, hipStreamSynchronize(st));          // h and the caller's staging are on the stack / reused
-    k_rpp_text_prepend<<<dim3((unsigned)B), dim3(256), (m + 1) * 4, st>>>(pts_dev, (uint32_t)m, text, stride, tstart);
-    const uint64_t n = (uint64_t)B * count;
-    k_rpp_hash<<<dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st>>>(hdrs, (uint32_t)count, (uint32_t)B, text, stride, tstart, tend, ch, es);
-    BPPP_HIP(ctx, hipGetLastError());
+  // the oracle of this flow: the new commitments of every proof come from the host ([B][m] affine, in the order the reference conses them)
+  auto oracle = [&](const uint64_t *pts_host, size_t call) -> int {
+    BPPP_HIP(ctx, hipMemcpyAsync(ptbuf, pts_host, B * tr.calls[call].points * 64, hipMemcpyHostToDevice, st));
+    int r_ = tr.call(ptbuf, call); if (r_) return r_;
+    BPPP_HIP(ctx, hipStreamSynchronize(st));          // the caller's staging is on the stack / reused
     return BPPP_OK;
   };
 
@@ -630,9 +524,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
       memcpy(&pts[(b * (2 + nr)) * 8], out.c_dm + 8 * b, 64); memcpy(&pts[(b * (2 + nr) + 1) * 8], out.c_m + 8 * b, 64);
       memcpy(&pts[(b * (2 + nr) + 2) * 8], out.input_coms + 8 * nr * b, nr * 64);
     }
-    const uint32_t slots[3] = {0, 1, 2};
-    rc = oracle(pts.data(), nullptr, 2 + nr, 3, slots); if (rc) return rc;
-    BPPP_HIP(ctx, hipStreamSynchronize(st));          // pts goes out of scope
+    rc = oracle(pts.data(), 0); if (rc) return rc;
   }
   const size_t m2 = INV_DIG + 256 + nr;
   const size_t lds2 = (2 * m2 + 128 + TRRP_MAX_SLOTS) * 32;
@@ -642,7 +534,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   BPPP_HIP(ctx, hipGetLastError());
   rc = rpp_commit_rows(rp, row_r, B, out.c_r); if (rc) return rc;
   // ---- (q, x', r1) <- oracle [rCom]
-  { const uint32_t slots[3] = {3, 4, 5}; rc = oracle(out.c_r, nullptr, 1, 3, slots); if (rc) return rc; }
+  rc = oracle(out.c_r, 1); if (rc) return rc;
   const size_t lds3 = ((size_t)6 * 64 + nr + TRRP_MAX_SLOTS + 4) * 32;
   if (lds3 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
   k_rpp_phase3<<<dim3((unsigned)B), dim3(64), lds3, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_coeff, tb->range_assumed, tb->syms, tb->cs_slot, tb->cs_sym,
@@ -650,7 +542,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   BPPP_HIP(ctx, hipGetLastError());
   rc = rpp_commit_rows(rp, row_bl, B, out.c_bl); if (rc) return rc;
   // ---- t <- oracle [blCom]; public constants and linear weights by the verifier's kernel; the combined witness
-  { const uint32_t slots[3] = {6, 0, 0}; rc = oracle(out.c_bl, nullptr, 1, 1, slots); if (rc) return rc; }
+  rc = oracle(out.c_bl, 2); if (rc) return rc;
   rc = bppp_trrp_public_device(rp->tabs, B, ch, a_q, p_sp, p_norm, p_cs, p_init); if (rc) return rc;
   { const uint64_t n = (uint64_t)B * T;
     k_rpp_combine<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(D, (uint32_t)B, ch, rows_dm_m, row_r, row_bl, aux, p_sp, p_norm, a_s, a_lx, a_nx); }
@@ -670,8 +562,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
       memcpy(&xr[16 * b], &X[8 * b], 64); memcpy(&xr[16 * b + 8], &R[8 * b], 64);
       memcpy(out.resp + (b * k + slot) * 16, &xr[16 * b], 128);
     }
-    const uint32_t slots[3] = {7, 0, 0};
-    rc = oracle(xr.data(), nullptr, 2, 1, slots); if (rc) break;
+    rc = oracle(xr.data(), 3 + round); if (rc) break;
     if (hipMemcpyAsync(eh.data(), es, B * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail(ctx, BPPP_ERR_HIP, "rp_prove_batch: challenge download"); break; }
     rc = bppp_nlb_round_collapse(nlb, eh.data());
   }

@@ -28,6 +28,29 @@ struct RppOutputs {          // host arrays
 
 int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out);
 
+// RangeProof.Binary (csrc/brpprove_dev.hip): proveBRPM + proveBPM of B proofs as one stream of kernels over the handle's comb table
+struct BrpHostInputs {
+  size_t batch;
+  const uint64_t *in_sc;     // [batch][nr][3][4]: amount, blinding, 0 as field elements (scalarRPW', src/RangeProof/Internal.hs:56-57)
+  const uint8_t *bits;       // [batch][nlive]: the binary digit of every live norm position (makeDigits, src/RangeProof/Binary.hs:56-69)
+  const uint8_t *prefix; size_t prefix_len;
+};
+struct BrpOutputs {          // host arrays
+  uint64_t *input_coms;      // [batch][nr][8]
+  uint64_t *c_d, *c_bl;      // [batch][8] each
+  uint64_t *resp;            // [batch][rounds][16]: (X, R) resp. (L, R), last round first
+  uint64_t *wit_norm, *wit_lin;
+};
+int brp_device_prove(bppp_rp *rp, const BrpHostInputs &in, BrpOutputs &out);
+
+struct RppTranscript;
+// proveBPM of the setup's flavour behind the range-proof phases, device-resident (csrc/rpprove_dev.hip)
+int rpp_argument_stream(bppp_rp *rp, RppTranscript &tr, size_t first_call, size_t B, const uint32_t *a_s, const uint32_t *a_q, const uint32_t *a_nx, const uint32_t *a_lc,
+                        const uint32_t *a_lx, uint32_t *d_resp, uint64_t *resp_out, uint64_t *wn_out, uint64_t *wl_out, const uint32_t *d_extra, size_t extra_points,
+                        std::vector<uint64_t> &extra_out);
+// verifyBRPM's public scalars for a batch (k_brp_public, csrc/rp.hip): the binary prover reuses them as the TR prover reuses k_trrp_public
+int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint32_t *q, uint32_t *sp, uint32_t *pub_norm, uint32_t *pub_lin_c, uint32_t *init_sc);
+
 // provided by rpprove.hip
 int rpp_ensure_pwork(bppp_rp *rp, size_t bytes);
 int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *d_out);                 // asynchronous on the context's stream

@@ -46,6 +46,16 @@ def test_native_binary_prover_and_verifier(gpu, oracle_lib, name):
         assert got[b][0] == want[0], "commitments file differs (proof %d)" % b
         assert got[b][1] == want[1], "proof file differs (proof %d)" % b
         assert BRP.verify(st, proof, RP.sha256_oracle())
+    # the device-resident route (csrc/brpprove_dev.hip: field algebra, randomness, transcript and the fixed-basis argument as one stream of
+    # kernels over a comb table of the setup's basis): the same bytes, with the transcript hashed on the device and on the host cores;
+    # then the host-algebra cross-check (prove_batch_binary) once more
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 7)
+    for host_oracle_max in (0, 2**64 - 1):
+        nat.set_option("host_oracle_max", host_oracle_max)
+        assert nat.prove_batch(inputs, prefixes) == got, "device-resident binary prover differs (host_oracle_max %d)" % host_oracle_max
+    nat.set_option("host_algebra", 1)
+    assert nat.prove_batch(inputs, prefixes) == got
+    nat.set_option("host_algebra", 0)
     # proof 0 again with every group operation done by the oracle (Straus commits, the reference's fold): the same bytes
     p_o = BRP.prove(st_o, BRP.witness(st_o, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0]))
     assert E.encode_proof(2, p_o) == got[0] and BRP.verify(st_o, p_o, RP.sha256_oracle())
@@ -103,6 +113,16 @@ def test_native_binary_on_the_reference_example(gpu):
     c_ip, f_ip = E.encode_proof(2, p_ip)
     assert nat_ip.verify_batch([c_ip], [f_ip])
     assert nat_ip.prove_batch([row], [b"bin ip"])[0] == (c_ip, f_ip)                 # the binary prover over the lockstep inner-product argument
+    # ... and device-resident (csrc/brpprove_dev.hip + csrc/ipb.hip over a comb table), 70 randomness streams, both hashing routes
+    ip_files = nat_ip.prove_batch([row] * B, [b"bin ip %03d" % b for b in range(B)])
+    nat_ip.set_option("comb_min", 1); nat_ip.set_option("comb_bits", 7)
+    for host_oracle_max in (0, 2**64 - 1):
+        nat_ip.set_option("host_oracle_max", host_oracle_max)
+        assert nat_ip.prove_batch([row] * B, [b"bin ip %03d" % b for b in range(B)]) == ip_files
+    assert nat_ip.prove_batch([row], [b"bin ip"])[0] == (c_ip, f_ip) and nat_ip.verify_batch([c for c, _ in ip_files], [p for _, p in ip_files])
+    # the norm-linear setup the same way: the device route writes what the host-algebra route wrote above
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 7); nat.set_option("host_oracle_max", 0)
+    assert nat.prove_batch([row] * B, [b"bin_test %03d" % b for b in range(B)]) == files
     t_ip = bytearray(f_ip); t_ip[40] ^= 1
     assert not nat_ip.verify_batch([c_ip], [bytes(t_ip)])
     nat_ip.close(); nat.close()
@@ -127,6 +147,10 @@ def test_native_binary_at_the_64_by_64_bit_shape(gpu):
         d = [rnd.randrange(-5000, 5000) for _ in range(count // 2)]
         inputs.append([(amount + x, rnd.randrange(RP.N)) for x in d] + [(amount - x, rnd.randrange(RP.N)) for x in d])
     files = nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)])
+    # the device-resident route over a (narrow, 1.3-GB) comb table of the 4099 points: byte-identical to the host-algebra route above
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 9); nat.set_option("host_oracle_max", 0)
+    assert nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)]) == files
+    nat.set_option("host_oracle_max", 2**64 - 1)
     seed = hashlib.sha256(b"binary 64by64").digest()
     lift = E.gpu_lift_x(gpu)
     for host_oracle_max in (2**64 - 1, 0):

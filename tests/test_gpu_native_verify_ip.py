@@ -148,6 +148,12 @@ def test_native_ip_lockstep_prover_equals_host_protocol_bytes(gpu, oracle_lib, n
     p_o = RP.prove(st_o, RP.witness(st_o, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0]))
     assert got[0] == E.encode_proof(4, p_o) and RP.verify(st_o, p_o, RP.sha256_oracle())
     assert nat.verify_batch([c for c, _ in got], [p for _, p in got])
+    # the device-resident route (csrc/rpprove_dev.hip phases + csrc/ipb.hip: one stream of kernels over a comb table of the setup's basis),
+    # transcript hashed on the device and on the host cores: the same bytes again
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 8)
+    for host_oracle_max in (0, 2**64 - 1):
+        nat.set_option("host_oracle_max", host_oracle_max)
+        assert nat.prove_batch(inputs, prefixes) == got, "device-resident inner-product prover differs (host_oracle_max %d)" % host_oracle_max
     nat.close()
 
 
@@ -166,6 +172,8 @@ def test_native_ip_lockstep_prover_on_a_long_vector(gpu):
     proof = RP.prove(st, RP.witness(st, inputs[1]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[1]))
     assert got[1] == E.encode_proof(4, proof)
     assert nat.verify_batch([c for c, _ in got], [p for _, p in got])
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 8); nat.set_option("host_oracle_max", 0)       # device-resident: odd lengths on the way down
+    assert nat.prove_batch(inputs, prefixes) == got
     nat.close()
 
 
