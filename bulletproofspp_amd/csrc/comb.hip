@@ -253,11 +253,13 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   // become 5 + 6, the join one level deeper)
   uint32_t tparts = 1, wsplit = 1;
   const uint32_t groups = (uint32_t)((nterms + 63) / 64);
-  if (d_scratch && ninst < 1024 && groups > 1) {
-    tparts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((1024 + ninst - 1) / ninst));
+  // (round 4: also a few thousand LONG instances — the binary prover's 2 x 1024 rows of 4099 terms are exactly one wavefront per slot of the
+  // chip, the X rows twice as long as the R rows: the launch then lasts as long as an X row on a half-idle SIMD.  Aim at ~8192 wavefronts.)
+  if (d_scratch && ninst < COMB_SPLIT_BELOW && groups > 1) {
+    tparts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((COMB_SPLIT_BELOW + ninst - 1) / ninst));
     while (tparts > 1 && (size_t)ninst * tparts * XYZZ_WORDS * 4 > scratch_bytes) tparts--;
     if (tparts == groups && !t->ctx->tune.comb_no_wsplit) {
-      wsplit = std::min<uint32_t>(std::min<uint32_t>(64u / tparts, 4u), (uint32_t)(1024 / (ninst * tparts)));
+      wsplit = std::min<uint32_t>(std::min<uint32_t>(64u / tparts, 4u), (uint32_t)(1024 / std::max<size_t>(1, ninst * tparts)));
       while (wsplit > 1 && (size_t)ninst * tparts * wsplit * XYZZ_WORDS * 4 > scratch_bytes) wsplit--;
       if (wsplit < 1) wsplit = 1;
     }

@@ -37,26 +37,107 @@ BPPP_DI bool fq_all_zero(const fq &a) {        // exact all-limbs-zero test (the
 }
 
 // ---- multiplication: 100 carry-free v_mad_u64_u32 + 20 for the 2^260 fold
-// Measured codegen (hipcc 7.2, gfx950): 224 instructions per fq_mul — 113 v_mad_u64_u32, 28 v_lshl_add_u64, 22
-// v_lshrrev_b64, 23 v_and, 9 v_lshlrev_b64, ~10 v_mov: the compiler starts every column from zero (independent chains, good
-// ILP) and adds the previous column's carry with one 64-bit add.  Pinning a single dependent chain per column (empty-asm
-// barriers) removes those adds but back-to-back dependent v_mad_u64_u32 need a wait state on this target (hipcc pads
-// with s_nop 0): 254-272 instructions, slower.  The plain C below is therefore the production form.
+// Cost model (benchmarks/valu_microbench.hip, >= 2 wavefronts per SIMD): v_mad_u64_u32, every 64-bit add / shift and every VOP3 32-bit
+// op issue in ~4.8 cycles per wave-instruction, VOP1/VOP2 32-bit ops (and, add, mov, shift) in ~2.8.  What a multiplication costs beyond
+// its 120 products is therefore counted in 64-bit adds and shifts.
+// Round 1-3 form (kept as fq_mul_cols for the record, benchmarks/fqmul_variants.hip): plain C columns — the compiler starts every column
+// from zero and adds the previous column's carry with one v_lshl_add_u64, and turns u * R1 (R1 = 2^10) into a 64-bit shift plus a 64-bit
+// add: 111 v_mad_u64_u32 + 32 v_lshl_add_u64 + 22 v_lshrrev_b64 + 11 v_lshlrev_b64 + 33 v_mov + 23 v_and = 233 instructions, 176 G/s.
+// Round 4 form: TWO carry chains — H = columns 9 .. 18, L = columns 0 .. 8 with the fold of H's limbs — in which the carry of a column is
+// the ADDEND of the next column's first product (no 64-bit add), pinned product by product (an empty asm after each), with R0 / R1 held in
+// scalar registers so that u * R1 stays one v_mad_u64_u32: 119 v_mad_u64_u32 + 7 v_lshl_add_u64 + 22 v_lshrrev_b64 + 3 v_lshlrev_b64 +
+// 6 v_mov + 23 v_and (+ 42 s_nop 0 the compiler puts between back-to-back dependent products: hidden by the other wavefronts of the
+// SIMD) — 203 G/s in the same microbenchmark, bit-identical results (also at the magnitude-8 bounds); k_acc_points 1.106 -> 1.04 ms.
+// A third form that fills those slots with the 45 low products as free column sums (benchmarks/fqmul_variants.h v3: no s_nop, 15
+// v_lshl_add_u64) measures 196 G/s there and the same in the kernels: not kept.  ISA histograms: profiles/r04_fq_mul_isa_histogram.txt.
+BPPP_DI uint64_t fq_madc(uint32_t x, uint32_t y, uint64_t acc) { uint64_t r = (uint64_t)x * y + acc; asm("" : "+v"(r)); return r; }
+BPPP_DI uint32_t fq_sreg(uint32_t v) { asm("" : "+s"(v)); return v; }
+// the tail shared by mul and sqr: limb 9 and everything above 2^256 folded back (2^256 = 2^32 + 0x3D1)
+BPPP_DI void fq_mul_tail(fq &r, uint64_t c, uint32_t t9, uint64_t u9, uint32_t u8) {
+  c += (uint64_t)t9 + u9 * FQ_R0 + (uint64_t)u8 * FQ_R1;
+  r.n[9] = (uint32_t)c & FQ_M22;
+  const uint64_t top = (c >> 22) + ((u9 * FQ_R1) << 4);   // units of 2^256 = 2^32 + 0x3D1
+  c = (uint64_t)r.n[0] + top * 0x3D1u; r.n[0] = (uint32_t)c & FQ_M26; c >>= 26;
+  c += (uint64_t)r.n[1] + (top << 6); r.n[1] = (uint32_t)c & FQ_M26; c >>= 26;
+  c += r.n[2]; r.n[2] = (uint32_t)c & FQ_M26; c >>= 26;
+  r.n[3] += (uint32_t)c;
+}
+BPPP_DI fq fq_mul(const fq &a, const fq &b) {
+  const uint32_t R0 = fq_sreg(FQ_R0), R1 = fq_sreg(FQ_R1);
+  uint64_t d = 0;
+#pragma unroll
+  for (int i = 0; i <= 9; i++) d = fq_madc(a.n[i], b.n[9 - i], d);
+  const uint32_t t9 = (uint32_t)d & FQ_M26; d >>= 26;
+  uint32_t u[9];
+#pragma unroll
+  for (int k = 10; k <= 18; k++) {
+#pragma unroll
+    for (int i = k - 9; i <= 9; i++) d = fq_madc(a.n[i], b.n[k - i], d);
+    u[k - 10] = (uint32_t)d & FQ_M26; d >>= 26;
+  }
+  const uint64_t u9 = d;                           // leftover carry, < 2^38
+  fq r;
+  uint64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) c = fq_madc(a.n[i], b.n[k - i], c);
+    c = fq_madc(u[k], R0, c);
+    if (k) c = fq_madc(u[k - 1], R1, c);
+    r.n[k] = (uint32_t)c & FQ_M26; c >>= 26;
+  }
+  fq_mul_tail(r, c, t9, u9, u[8]);
+  return r;
+}
+
+// squaring: 55 products (off-diagonal terms use the doubled limb), the same two chains
+#define FQ_SQCHAIN(acc, k)                                                                              \
+  _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); 2 * i < (k); i++) acc = fq_madc(a2[i], a.n[(k)-i], acc); \
+  if (((k)&1) == 0) acc = fq_madc(a.n[(k) / 2], a.n[(k) / 2], acc);
+
+BPPP_DI fq fq_sqr(const fq &a) {
+  const uint32_t R0 = fq_sreg(FQ_R0), R1 = fq_sreg(FQ_R1);
+  uint32_t a2[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) a2[i] = a.n[i] << 1;     // < 2^31 for magnitude <= 8
+  uint64_t d = 0;
+  FQ_SQCHAIN(d, 9)
+  const uint32_t t9 = (uint32_t)d & FQ_M26; d >>= 26;
+  uint32_t u[9];
+#pragma unroll
+  for (int k = 10; k <= 18; k++) {
+    FQ_SQCHAIN(d, k)
+    u[k - 10] = (uint32_t)d & FQ_M26; d >>= 26;
+  }
+  const uint64_t u9 = d;
+  fq r;
+  uint64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    FQ_SQCHAIN(c, k)
+    c = fq_madc(u[k], R0, c);
+    if (k) c = fq_madc(u[k - 1], R1, c);
+    r.n[k] = (uint32_t)c & FQ_M26; c >>= 26;
+  }
+  fq_mul_tail(r, c, t9, u9, u[8]);
+  return r;
+}
+
+// the round 1-3 form of the multiplication (plain columns, the compiler's own order): a cross-check for tests and benchmarks
 #define FQ_COL(acc, k)                                                                 \
   _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); i <= ((k) < 9 ? (k) : 9); i++) \
       acc += (uint64_t)a.n[i] * b.n[(k)-i];
-
-BPPP_DI fq fq_mul(const fq &a, const fq &b) {
+BPPP_DI fq fq_mul_cols(const fq &a, const fq &b) {
   uint64_t d = 0;
   FQ_COL(d, 9)
   const uint32_t t9 = (uint32_t)d & FQ_M26; d >>= 26;
-  uint32_t u[10];
+  uint32_t u[9];
 #pragma unroll
   for (int k = 10; k <= 18; k++) {
     FQ_COL(d, k)
     u[k - 10] = (uint32_t)d & FQ_M26; d >>= 26;
   }
-  u[9] = (uint32_t)d; const uint64_t u9 = d;     // leftover carry, < 2^38
+  const uint64_t u9 = d;
   fq r;
   uint64_t c = 0;
 #pragma unroll
@@ -66,52 +147,7 @@ BPPP_DI fq fq_mul(const fq &a, const fq &b) {
     if (k) c += (uint64_t)u[k - 1] * FQ_R1;
     r.n[k] = (uint32_t)c & FQ_M26; c >>= 26;
   }
-  c += (uint64_t)t9 + u9 * FQ_R0 + (uint64_t)u[8] * FQ_R1;
-  r.n[9] = (uint32_t)c & FQ_M22;
-  const uint64_t top = (c >> 22) + ((u9 * FQ_R1) << 4);   // units of 2^256 = 2^32 + 0x3D1
-  c = (uint64_t)r.n[0] + top * 0x3D1u; r.n[0] = (uint32_t)c & FQ_M26; c >>= 26;
-  c += (uint64_t)r.n[1] + (top << 6); r.n[1] = (uint32_t)c & FQ_M26; c >>= 26;
-  c += r.n[2]; r.n[2] = (uint32_t)c & FQ_M26; c >>= 26;
-  r.n[3] += (uint32_t)c;
-  return r;
-}
-
-// squaring: 55 products (off-diagonal terms use the doubled limb)
-#define FQ_SQCOL(acc, k)                                                                    \
-  _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); 2 * i < (k); i++)                   \
-      acc += (uint64_t)a2[i] * a.n[(k)-i];                                                   \
-  if (((k)&1) == 0) acc += (uint64_t)a.n[(k) / 2] * a.n[(k) / 2];
-
-BPPP_DI fq fq_sqr(const fq &a) {
-  uint32_t a2[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) a2[i] = a.n[i] << 1;     // < 2^31 for magnitude <= 8
-  uint64_t d = 0;
-  FQ_SQCOL(d, 9)
-  const uint32_t t9 = (uint32_t)d & FQ_M26; d >>= 26;
-  uint32_t u[10];
-#pragma unroll
-  for (int k = 10; k <= 18; k++) {
-    FQ_SQCOL(d, k)
-    u[k - 10] = (uint32_t)d & FQ_M26; d >>= 26;
-  }
-  u[9] = (uint32_t)d; const uint64_t u9 = d;
-  fq r;
-  uint64_t c = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    FQ_SQCOL(c, k)
-    c += (uint64_t)u[k] * FQ_R0;
-    if (k) c += (uint64_t)u[k - 1] * FQ_R1;
-    r.n[k] = (uint32_t)c & FQ_M26; c >>= 26;
-  }
-  c += (uint64_t)t9 + u9 * FQ_R0 + (uint64_t)u[8] * FQ_R1;
-  r.n[9] = (uint32_t)c & FQ_M22;
-  const uint64_t top = (c >> 22) + ((u9 * FQ_R1) << 4);
-  c = (uint64_t)r.n[0] + top * 0x3D1u; r.n[0] = (uint32_t)c & FQ_M26; c >>= 26;
-  c += (uint64_t)r.n[1] + (top << 6); r.n[1] = (uint32_t)c & FQ_M26; c >>= 26;
-  c += r.n[2]; r.n[2] = (uint32_t)c & FQ_M26; c >>= 26;
-  r.n[3] += (uint32_t)c;
+  fq_mul_tail(r, c, t9, u9, u[8]);
   return r;
 }
 
