@@ -112,8 +112,8 @@ def make_rp_setup(gpu, torch, dev, rank: int, shape: str):
     from bulletproofspp_amd.capi import array_to_point
     nlen, llen, k, fn, fl, ninit = SHAPES[shape]
     count, typed = (64, False) if shape == "64by64" else (128, True)
-    rng = np.random.default_rng(0x64B + rank)
-    need = 2 + llen + nlen
+    rng = np.random.default_rng(0x64B)            # ONE setup for every rank (a sharded job is verified against the same basis everywhere);
+    need = 2 + llen + nlen                          # the ranks' witnesses and randomness differ (the generator returned below)
     pts = None
     while pts is None or pts.shape[0] < need:
         xs = rng.integers(0, 2**64, size=(3 * need, 4), dtype=np.uint64)
@@ -129,7 +129,7 @@ def make_rp_setup(gpu, torch, dev, rank: int, shape: str):
     st = RP.setup(RP.GpuBackend(gpu), basis_pts, typed, pub_vt, [rd] * count)
     assert (st.nrm_len, st.lin_len, st.rounds, st.final_lens) == (nlen, llen, k, (fn, fl)), "shape table out of date"
     nat = RP.NativeRangeProofs(gpu, st, h=basis_pts[0])
-    return st, nat, count, typed, amount, rng
+    return st, nat, count, typed, amount, np.random.default_rng(0x64B0 + rank)
 
 
 def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, steps: int, warmup: int, shape: str = "64by64",
@@ -276,6 +276,17 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
         assert sres is None, "the sum of the rank points of a valid job is not the identity"
         strong = {"scaling": "strong", "job_proofs": batch, "batch_per_gpu": mine, "value": batch * steps / sdt, "unit": "verifies/s",
                   "ms_per_job": sdt / steps * 1e3}
+        # one corrupted proof on ONE rank must fail the whole job on EVERY rank: rank `tamper_rank` flips a bit of a final witness scalar of
+        # its middle proof (outside the timed region), every rank forms the sum of the rank points again
+        tr_ = TAMPER_RANK if 0 <= TAMPER_RANK < world else world - 1
+        d_pt = d_p
+        if rank == tr_ and mine:
+            d_pt = d_p.clone()
+            d_pt[(mine // 2) * nat.shape["proof_bytes"] + 9] ^= 4
+        ok_t, part_t = nat.verify_batch_device_point(mine, d_c.data_ptr(), d_pt.data_ptr(), job_seed, index_offset=lo)
+        assert ok_t == (rank != tr_ or not mine), "the tampered shard verified (or an honest one did not)"
+        assert combine(part_t) is not None, "a job with a corrupted proof on rank %d was accepted" % tr_
+        strong["tamper_check"] = "one corrupted proof on rank %d of %d: its shard rejects and the summed rank points are not the identity on every rank" % (tr_, world)
     # two verifier handles on two contexts (stream + workspace each), one host thread each, the same files: the hashing stage of one
     # batch — one wavefront per SIMD at this batch size, i.e. half of the chip's issue slots — overlaps the arithmetic of the other.
     # Reported beside the single-call figure (which stays `value`), like the MSM's `concurrent` leg.
@@ -357,7 +368,7 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
         verify.update({"value": strong["value"], "scaling": "strong", "ms_per_batch": strong["ms_per_job"], "batch_per_gpu": strong["batch_per_gpu"],
                        "job_proofs": batch, "achieved_GBps": strong["value"] * bytes_per_proof / 1e9,
                        "hbm_frac": strong["value"] * bytes_per_proof / 1e9 / (HBM_PEAK_GBS * world), "weak": weak,
-                       "combined_msm_terms": nlen + llen + 1 + strong["batch_per_gpu"] * (ninit + 2 * k)})
+                       "combined_msm_terms": nlen + llen + 1 + strong["batch_per_gpu"] * (ninit + 2 * k), "tamper_check": strong["tamper_check"]})
     if cpu_baseline_leg and rank == 0:
         # the reference verifies ONE proof with ONE 256-row Straus MSM over nlen + llen + 1 + ninit + 2k terms
         # (src/Bulletproof.hs:377): time the oracle's restatement of that on this host (single thread)
@@ -588,6 +599,9 @@ def launcher_selftest(args):
         dist.destroy_process_group()
 
 
+TAMPER_RANK = -1      # --tamper-rank: which rank corrupts a proof in the strong-scaling check (-1 = the last one)
+
+
 def gpu_device(dev) -> int:
     return dev.index if getattr(dev, "index", None) is not None else 0
 
@@ -656,12 +670,15 @@ def main():
     ap.add_argument("--msm-streams", type=int, default=2, help="extra leg: MSMs in flight on that many contexts (1 = skip; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--tamper-rank", type=int, default=-1, help="N > 1: the rank that corrupts one of its proofs in the strong-scaling rejection check (-1 = the last rank)")
     ap.add_argument("--headline-only", action="store_true", help="only the 2^log2n MSM leg (profiling passes: one launch shape per kernel)")
     ap.add_argument("--check-combined", action="store_true", help="N > 1: rank 0 also computes the whole sharded MSM alone (all ranks' inputs regenerated "
                                                                   "from their seeds) and asserts the combined point equals it")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU: the ranks only rendezvous over gloo, all-gather their rank numbers and shard ranges, "
                                                                     "and rank 0 prints them (the CPU-tier test of the plain `--gpus N` start)")
     args = ap.parse_args()
+    global TAMPER_RANK
+    TAMPER_RANK = args.tamper_rank
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))          # plain start: become the launcher BEFORE torch / HIP are touched

@@ -63,6 +63,36 @@ def test_sharded_msm_world2_gloo(n):
     assert lo0 == 0 and hi0 == lo1 and hi1 == n
 
 
+def test_sharded_msm_world8_gloo():
+    """the 8-rank exchange of BASELINE config 5 (8 x MI355X) on CPU cores: eight gloo ranks, one 64-byte point each, gathered blocking and
+    non-blocking; every rank ends with the whole MSM"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    n, world = 43, 8
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r for r, _, _ in res] == list(range(world)) and all(ok for _, ok, _ in res)
+    rs = [rg for _, _, rg in res]
+    assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+
+
+def test_bench_plain_start_eight_ranks_selftest():
+    """`python bench.py --gpus 8` started plainly (no GPU: --launcher-selftest): eight children rendezvous, the 4096-proof job of config 5 is cut
+    into 8 x 512"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BPPP_SELFTEST_FAIL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launcher-selftest"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["ranks"] == list(range(8)) and out["shards"] == [[512 * r, 512 * (r + 1)] for r in range(8)]
+
+
 def test_shard_ranges_partition():
     from bulletproofspp_amd.dist import shard_range
     for n in (0, 1, 7, 8, 1 << 20, 344838):

@@ -161,6 +161,48 @@ def test_sharded_weights_are_global_and_bound_to_the_proofs(gpu):
     nat.close()
 
 
+def test_eight_shards_of_one_job(gpu):
+    """BASELINE config 5's layout, shard by shard in one process (a one-GPU box admits at most 6 processes on its card; 2, 4 and 6 real ranks
+    run in tests/test_gpu_two_ranks.py): ONE job of 44 proofs cut into the 8 contiguous shards dist.shard_range gives 8 ranks (6 + 6 + 6 + 6 +
+    5 + 5 + 5 + 5), each verified by bppp_rp_verify_shard_device with the job-wide seed and its own offset.  Honest job: every shard's point is
+    the identity.  One corrupted proof in shard 5: only that shard rejects, the sum of the 8 points is not the identity and equals, point
+    for point, what one rank forms over the whole job."""
+    from bulletproofspp_amd.capi import points_to_array
+    from bulletproofspp_amd.dist import shard_range
+    st = _setup(gpu, False)
+    nat = RP.NativeRangeProofs(gpu, st)
+    rnd = random.Random(85)
+    J, W = 44, 8
+    inputs = [[(rnd.randrange(256), 0, rnd.randrange(O.N)), (10 + rnd.randrange(256), 0, rnd.randrange(O.N)), (rnd.randrange(2**64), 0, rnd.randrange(O.N)),
+               (rnd.randrange(100), 0, rnd.randrange(O.N))] for _ in range(J)]
+    files = nat.prove_batch(inputs, [b"eight shards %02d" % b for b in range(J)])
+    seed = hashlib.sha256(b"job seed, broadcast by rank 0").digest()
+
+    def up(bs):
+        raw = b"".join(bs)
+        return gpu.to_device(np.frombuffer(raw + b"\0" * (-len(raw) % 8), dtype=np.uint64))
+
+    def shard(fs, offset):
+        dc, dp = up([c for c, _ in fs]), up([p for _, p in fs])
+        try:
+            return nat.verify_batch_device_point(len(fs), dc, dp, seed, index_offset=offset)
+        finally:
+            gpu.free(dc); gpu.free(dp)
+    ranges = [shard_range(J, r, W) for r in range(W)]
+    assert [hi - lo for lo, hi in ranges] == [6, 6, 6, 6, 5, 5, 5, 5]
+    res = [shard(files[lo:hi], lo) for lo, hi in ranges]
+    assert all(ok and pt is None for ok, pt in res)
+    bad = list(files)
+    lo5, hi5 = ranges[5]
+    pf = bytearray(bad[lo5 + 2][1]); pf[9] ^= 4; bad[lo5 + 2] = (bad[lo5 + 2][0], bytes(pf))
+    res = [shard(bad[lo:hi], lo) for lo, hi in ranges]
+    assert [ok for ok, _ in res] == [r != 5 for r in range(W)]
+    total = gpu.sum_points(points_to_array([pt for _, pt in res]))
+    ok_all, pt_all = shard(bad, 0)
+    assert total is not None and not ok_all and pt_all == total
+    nat.close()
+
+
 @pytest.mark.parametrize("typed", [False, True])
 def test_native_prover_equals_host_protocol_bytes(gpu, typed):
     """bppp_rp_prove_batch against rangeproof.prove: same inputs, same hashToScalar randomness, same oracle => the same

@@ -39,6 +39,35 @@ def test_bench_two_ranks_plain_start_both_scaling_modes():
     v4 = v["other_shapes"][0]                                                                                          # config 4's layout
     assert v4["scaling"] == "strong" and v4["job_proofs"] == 128 and v4["batch_per_gpu"] == 64 and v4["weak"]["batch_per_gpu"] == 128
     assert out["prove"]["replicas"] == 2
+    assert "rank 1 of 2" in v["tamper_check"] and "rank 1 of 2" in v4["tamper_check"]
+
+
+def _plain_start(n, extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--log2n", "14", "--verify-batch", str(16 * n), "--ip-batch", "0",
+           "--binary-batch", "0", "--backend", "gloo", "--same-device", "--check-combined", "--no-cpu-baseline", "--msm-streams", "1"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return _json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=1100, env=env, cwd=ROOT))
+
+
+@pytest.mark.parametrize("n,tamper", [(4, 2), (6, 5)])
+def test_bench_four_and_six_ranks_on_one_card(n, tamper):
+    """BASELINE config 4 (4 GPUs) and the widest launch a one-GPU box admits (at most 6 processes may hold the card; the 8-rank layout of
+    config 5 is rehearsed shard by shard in test_gpu_native_verify.py::test_eight_shards_of_one_job and rank by rank on the CPU in
+    tests/test_dist_gloo.py): `python bench.py --gpus N` started plainly — N children spawned before any GPU call — every rank on cuda:0,
+    the exchange over gloo, small batches (no rank builds a prover table).  The job shards, the weak and strong figures and the rejection
+    of a job with ONE corrupted proof on a middle / the last rank are asserted."""
+    out = _plain_start(n, ["--tamper-rank", str(tamper)])
+    assert out["n_gpus"] == n and out["scaling"] == "weak"
+    assert out["combined_check"].startswith("sum of %d rank-local MSMs == single-rank MSM" % n)
+    assert out["msm_strong_scaling"]["pairs_per_gpu"] in ((1 << 14) // n, (1 << 14) // n + 1)
+    v = out["verify"]
+    assert v["scaling"] == "strong" and v["job_proofs"] == 16 * n and v["batch_per_gpu"] == 16 and v["value"] > 0
+    assert v["weak"]["batch_per_gpu"] == 16 * n and v["weak"]["job_proofs"] == 16 * n * n
+    assert "rank %d of %d" % (tamper, n) in v["tamper_check"]
+    v4 = v["other_shapes"][0]
+    assert v4["scaling"] == "strong" and v4["job_proofs"] == 8 * n and v4["batch_per_gpu"] == 8 and "rank %d of %d" % (tamper, n) in v4["tamper_check"]
+    assert out["prove"]["replicas"] == n
 
 
 def test_bench_two_ranks_under_torch_distributed_run():
