@@ -99,6 +99,64 @@ def cpu_baseline_threads(sc_np: np.ndarray, pts_np: np.ndarray, per_thread: int)
     return cores * per_thread / dt, cores, dt
 
 
+def profile_table(key: str):
+    """profiles/traffic.json[key]: the per-kernel counter table of one verifier call (rocprofv3 passes of benchmarks/profile_round.sh verifypmc)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+def stage_rows(tab, top: int = 8):
+    """the largest kernels of a profiled verifier call: ms, HBM bytes (FETCH x2 + WRITE), wait fraction, VALU-busy estimate"""
+    if not tab:
+        return None
+    rows = sorted(tab["by_kernel"].items(), key=lambda kv: -kv[1]["ms_per_call"])[:top]
+    return [{"kernel": k.replace("bppp::", "").replace("void ", ""), "ms": round(v["ms_per_call"], 4), "hbm_bytes": int(v["fetch_bytes_x2"] + v["write_bytes"]),
+             "wait_inst_frac": v.get("wait_inst_frac"), "valu_busy_est": v.get("valu_busy_est")} for k, v in rows]
+
+
+def live_msm_traffic(log2n: int, timeout_s: float = 150.0):
+    """HBM bytes of one k_acc_points launch measured IN THIS RUN: two child processes of this script under rocprofv3 --pmc (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, counters only, the program directly after `--`), headline leg only.  gfx950 corrections as the guide's HBM
+    section prescribes: both counters in KB, FETCH_SIZE counts a 128-B request as 64 B (x2).  Returns (bytes, source) or (None, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bppp_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--headline-only", "--no-cpu-baseline",
+               "--steps", "4", "--warmup", "2", "--log2n", str(log2n)]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"))
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d" % (counter, p.returncode)
+            tot, cnt = 0.0, 0
+            for dp_, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        with open(os.path.join(dp_, f)) as fh:
+                            for r in csv.DictReader(fh):
+                                if r["Counter_Name"] == counter and "k_acc_points" in r["Kernel_Name"]:
+                                    tot += float(r["Counter_Value"]); cnt += 1
+            if not cnt:
+                return None, "no k_acc_points rows in the %s pass" % counter
+            vals[counter] = tot / cnt * 1024.0
+        except subprocess.TimeoutExpired:
+            return None, "rocprofv3 --pmc %s timed out" % counter
+        except Exception as e:
+            return None, "rocprofv3 --pmc %s: %s" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of `bench.py --headline-only` "
+                                                          "(mean per k_acc_points launch; FETCH_SIZE %.0f B raw x 2 + WRITE_SIZE %.0f B)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+
+
 SHAPES = {   # SURVEY.md Appendix B: (nrmLen, linLen, rounds, final norm, final lin, transcript commitments)
     "64by64": (512, 261, 8, 2, 2, 68),              # examples/64by64: 64 values, base 256 shared, NL argument
     "128by64+typed": (1152, 261, 9, 3, 1, 132),     # examples/128by64 with "typed": true (BASELINE config 4)
@@ -338,6 +396,7 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     gpu._check(gpu.lib.bppp_rp_verify_batch(nat.h, batch, vp(cf), vp(pf_bad), vp(sd), C.byref(acc), None, None, None), "bppp_rp_verify_batch")
     assert acc.value == 0, "a corrupted proof was accepted"
     terms = nlen + llen + 1 + batch * (ninit + 2 * k)
+    vtab = profile_table("verify_4096_64by64")
     # algorithmic bytes per proof: (ninit + 2k) per-proof pairs x 96 B + (nlen + llen + 1) shared-basis scalars x 32 B
     bytes_per_proof = (ninit + 2 * k) * 96 + (nlen + llen + 1) * 32
     file_bytes = shp["coms_bytes"] + shp["proof_bytes"]
@@ -351,11 +410,16 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
               "scope": "verifyM of RangeProof END TO END (src/RangeProof.hs:99-105) from the encoded files resident in HBM: decodeProof (square roots, "
                        "signs), every SHA-256 transcript hash of verifyTRRPM / verifyBPM (shaOracle, app/Main.hs:64-80), public scalars, challenge "
                        "expansion, shared-basis merge, ONE combined MSM — all on the GPU, all timed (bppp_rp_verify_batch_device)",
-              "roofline": {"bound": "hbm", "kernel": "whole call (decode, text, SHA-256, public scalars, expansion, combined MSM: profiles/r03_bench_default_kernel_stats.csv)",
+              "roofline": {"bound": "hbm", "kernel": "whole call (decode, text, SHA-256, public scalars, expansion, combined MSM: profiles/r04_verify_4096_kernel_stats.csv)",
                            "achieved": world * batch * steps * bytes_per_proof / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                           "frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                           "frac": world * batch * steps * bytes_per_proof / dt / 1e9 / (HBM_PEAK_GBS * world),
+                           "traffic": (vtab or {}).get("per_call", {}).get("bytes_per_call") if (batch == 4096 and shape == "64by64") else None,
+                           "traffic_source": "static: profiles/traffic.json verify_4096_64by64 (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one call of this shape and "
+                                             "batch, summed over its kernels: profiles/r04_pmc_verify_per_kernel.csv)" if (vtab and batch == 4096 and shape == "64by64") else None,
+                           "limiter": "valu / latency",
                            "note": "algorithmic %d B per proof (SURVEY.md 8d) x proofs / call time; every stage is VALU- or latency-bound (256-bit field "
-                                   "arithmetic, SHA-256), none HBM-bound" % bytes_per_proof},
+                                   "arithmetic, SHA-256), none HBM-bound: see `stages`" % bytes_per_proof},
+              "stages": stage_rows(vtab) if (batch == 4096 and shape == "64by64") else None,
               "concurrent": concurrent,
               "host_buffer_call": {"entry": "bppp_rp_verify_batch (files in pageable host memory, %d B per proof over PCIe)" % file_bytes,
                                    "ms_per_batch": hdt * 1e3, "value": batch / hdt, "unit": "verifies/s",
@@ -394,12 +458,12 @@ def bench_rangeproofs(gpu, torch, dev, rank, world, dist, combine, batch: int, s
     return verify, prove
 
 
-def bench_binary_verify(gpu, torch, dev, batch: int, steps: int):
+def bench_binary_verify(gpu, torch, dev, batch: int, steps: int, cpu_baseline_leg: bool = True):
     """RangeProof.Binary (src/RangeProof/Binary.hs) at the 64 x 64-bit shape — BASELINE config 3 read literally ("64x64-bit aggregated BINARY
     range proof"): 64 outputs in [0, 2^64), one bit per norm position (nrmLen 4096, linLen 2, 10 rounds, an 867-byte proof), conserved
     against one public input as witnessBRP requires (:158-166), norm-linear argument.  `batch` DISTINCT proofs made in this run by the
-    library's lockstep prover (bppp_rp_prove_batch on a bppp_rp_create_binary handle: proveBRPM + proveBPM, field algebra on the host
-    cores) and verified end to end from their files in HBM (bppp_rp_verify_batch_device: verifyBRPM's two oracle calls, verifyBPM, one
+    library's lockstep prover (bppp_rp_prove_batch on a bppp_rp_create_binary handle: proveBRPM + proveBPM as one stream of kernels once the
+    comb table of the setup exists) and verified end to end from their files in HBM (bppp_rp_verify_batch_device: verifyBRPM's two oracle calls, verifyBPM, one
     combined MSM of 4100 + batch * 86 terms); one corrupted member must be rejected and identified."""
     from bulletproofspp_amd import rangeproof as RP, rangeproof_binary as RB
     from bulletproofspp_amd.capi import array_to_point
@@ -432,6 +496,11 @@ def bench_binary_verify(gpu, torch, dev, batch: int, steps: int):
     tp0 = time.perf_counter()
     gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bl4), vp(pre), 20, vp(cf), vp(pf)), "bppp_rp_prove_batch (binary)")
     pdt = time.perf_counter() - tp0
+    cf1, pf1 = cf.copy(), pf.copy()
+    tp0 = time.perf_counter()
+    gpu._check(gpu.lib.bppp_rp_prove_batch(nat.h, batch, vp(amt), vp(typ), vp(bl4), vp(pre), 20, vp(cf), vp(pf)), "bppp_rp_prove_batch (binary)")
+    pdt2 = time.perf_counter() - tp0
+    assert np.array_equal(cf, cf1) and np.array_equal(pf, pf1), "the binary prover is not deterministic in its inputs"
     dc, dpf = gpu.to_device(cf), gpu.to_device(pf)
     seed = os.urandom(32)
     assert nat.verify_batch_device(batch, dc, dpf, seed)
@@ -454,7 +523,42 @@ def bench_binary_verify(gpu, torch, dev, batch: int, steps: int):
                shp["norm_len"], shp["lin_len"], k, shp["proof_bytes"]),
            "scope": "verifyBRPM + verifyBPM end to end from the encoded files resident in HBM (bppp_rp_verify_batch_device on a bppp_rp_create_binary handle); one corrupted "
                     "member rejected and identified",
-           "prove": {"value": batch / pdt, "unit": "proofs/s", "ms_per_batch": pdt * 1e3, "note": "lockstep proveBRPM + proveBPM, field algebra on the host cores, commitments on the GPU; first call (tables included)"}}
+           "prove": {"value": batch / pdt2, "unit": "proofs/s", "ms_per_batch": pdt2 * 1e3, "first_call_ms": pdt * 1e3,
+                     "scope": "bppp_rp_prove_batch on the binary handle, second call (the first builds the comb table of the 4099 basis points: first_call_ms): "
+                              "proveBRPM + proveBPM as ONE stream of kernels (csrc/brpprove_dev.hip, csrc/nlb.hip fixed-basis mode, csrc/rpp_transcript.hip), every "
+                              "commitment a comb MSM; the host extracts the binary digits and writes the files",
+                     "bound": "10 rounds x (4099 + 2050) + 4099 full-width terms per proof x 20 windows (c = 13) = 1.31 M mixed additions = 13.1 M field "
+                              "multiplications per proof: at the accumulate kernel's ~170 G mulmod/s that is ~77 us per proof, ~13 k proofs/s for this algorithm"}}
+    bytes_per_proof = (ninit + 2 * k) * 96 + (shp["norm_len"] + shp["lin_len"] + 1) * 32
+    btab = profile_table("verify_binary_1024_64x64bit") if batch == 1024 else None
+    ach = batch * steps * bytes_per_proof / dt / 1e9
+    out["algorithmic_bytes_per_proof"] = bytes_per_proof
+    out["roofline"] = {"bound": "hbm", "kernel": "whole call (decode, text, SHA-256, k_brp_public, expansion, combined MSM: profiles/r04_binary_verify_1024_kernel_stats.csv)",
+                       "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "traffic": (btab or {}).get("per_call", {}).get("bytes_per_call"),
+                       "traffic_source": "static: profiles/traffic.json verify_binary_1024_64x64bit (profiles/r04_pmc_binary_verify_per_kernel.csv)" if btab else None,
+                       "limiter": "valu / latency",
+                       "note": "algorithmic %d B per proof ((2 + 64 + 2 x 10) per-proof pairs x 96 B + 4099 shared-basis scalars x 32 B) x proofs / call time" % bytes_per_proof}
+    out["stages"] = stage_rows(btab)
+    if cpu_baseline_leg:
+        # the reference verifies ONE such proof with ONE 256-row Straus commit over 4099 + 66 + 20 = 4185 terms (src/Bulletproof.hs:377)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        from bulletproofspp_amd.capi import points_to_array
+        ec = pyoracle.CEC()
+        nterm = shp["norm_len"] + shp["lin_len"] + 1 + ninit + 2 * k
+        sc = rng.integers(0, 2**64, size=(nterm, 4), dtype=np.uint64)
+        sc[:, 3] = np.minimum(sc[:, 3], np.uint64(0xFFFFFFFFFFFFFFFD))
+        pts_np = np.ascontiguousarray(np.tile(P[:need], (2, 1))[:nterm])
+        u64p = C.POINTER(C.c_uint64)
+        reps = 3
+        tc0 = time.perf_counter()
+        for _ in range(reps):
+            ec.inner_product_raw(sc.ctypes.data_as(u64p), pts_np.ctypes.data_as(u64p), nterm)
+        cdt = (time.perf_counter() - tc0) / reps
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} single-proof verifier MSMs of {nterm} terms (the reference's one commit per verifyBPM, Bulletproof.hs:377) through "
+                                         "oracle/bppp_oracle.c's 256-row Straus restatement; hashing and decoding not included (they favour the baseline)"}
     nat.close()
     return out
 
@@ -527,8 +631,12 @@ def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, cpu_baseline_leg: b
            "proofs": f"{batch} DISTINCT real proofs made by the lockstep inner-product prover in this run (one checked byte for byte against the host "
                      "protocol code); all verify; one corrupted member is rejected",
            "prove": {"metric": "single_64bit_range_proofs_proved_per_sec (inner-product argument)", "value": batch / prove_s, "unit": "proofs/s", "ms_per_batch": prove_s * 1e3,
-                     "scope": "bppp_rp_prove_batch, flavour 1: range-proof phases and the argument's field algebra on the host cores, every commitment an MSM over "
-                              "the registered original basis on the GPU (csrc/rpprove.hip ip_argument_lockstep)"},
+                     "scope": "bppp_rp_prove_batch, flavour 1: range-proof phases (csrc/rpprove_dev.hip), transcript (csrc/rpp_transcript.hip) and the argument "
+                              "(csrc/ipb.hip) as one stream of kernels, every commitment a comb MSM over the setup's ORIGINAL basis (no basis change, no point "
+                              "fold); the host extracts digits and writes the files"},
+           "roofline": {"bound": "hbm", "kernel": "whole call (profiles/r04_ip_prove_verify_16384_kernel_stats.csv)", "achieved": batch * bytes_per_proof / dt / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": batch * bytes_per_proof / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "limiter": "valu / latency",
+                        "note": "algorithmic %d B per proof x proofs / call time; no counter pass was taken on this leg" % bytes_per_proof},
            "scope": "verifyM of RangeProof end to end from the encoded files in HBM, inner-product flavour (bppp_rp_verify_batch_device, flavour 1)"}
     if cpu_baseline_leg:
         # the reference's verifier for ONE such proof: makeNorm's basis change (one 256-row scalar multiplication per basis pair,
@@ -671,6 +779,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--tamper-rank", type=int, default=-1, help="N > 1: the rank that corrupts one of its proofs in the strong-scaling rejection check (-1 = the last rank)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure the HBM bytes of k_acc_points in this run")
     ap.add_argument("--headline-only", action="store_true", help="only the 2^log2n MSM leg (profiling passes: one launch shape per kernel)")
     ap.add_argument("--check-combined", action="store_true", help="N > 1: rank 0 also computes the whole sharded MSM alone (all ranks' inputs regenerated "
                                                                   "from their seeds) and asserts the combined point equals it")
@@ -970,7 +1079,7 @@ def main():
 
     verify_binary = None
     if world == 1 and args.binary_batch > 0 and not args.headline_only:
-        verify_binary = bench_binary_verify(gpu, torch, dev, args.binary_batch, max(3, args.steps // 2))
+        verify_binary = bench_binary_verify(gpu, torch, dev, args.binary_batch, max(3, args.steps // 2), cpu_baseline_leg=not args.no_cpu_baseline)
 
     if rank == 0:
         per_call = {k: v / max(calls, 1) for k, v in stages.items()}
@@ -979,11 +1088,16 @@ def main():
         launches = args.steps
         acc_ms = stages["acc_points"] / launches
         achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
+        if world == 1 and not args.headline_only and not args.no_live_traffic:
+            traffic, traffic_source = live_msm_traffic(args.log2n)
+            if traffic is None:
+                traffic_source = "live passes failed (%s); " % traffic_source
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.log2n == 20:    # the PMC passes were taken on the 2^20 workload
+        if traffic is None and os.path.exists(tpath) and args.log2n == 20:    # the committed PMC passes were taken on the 2^20 workload
             try:
                 traffic = json.load(open(tpath)).get("k_acc_points_bytes_per_launch")
+                traffic_source = (traffic_source or "") + "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload), not measured in this run"
             except Exception:
                 traffic = None
         out = {
@@ -994,10 +1108,11 @@ def main():
             "config": {"workload": f"pedersen_msm_2^{args.log2n}_secp256k1", "pairs_per_gpu": n, "window_bits": args.window or "auto",
                        "algorithm": "signed-digit Pippenger, affine in / XYZZ buckets", "sharding": f"terms/{world}" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_acc_points", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload), not measured in this run",
-                         "note": "algorithmic 96 B/pair x 2^%d pairs per launch / mean k_acc_points duration (HIP events); "
-                                 "the kernel is VALU-bound (256-bit modular multiplies), see DESIGN.md" % args.log2n},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "limiter": "valu",
+                         "note": "`bound` names the roofline BASELINE.json's north_star asks for (fraction of HBM peak): algorithmic 96 B/pair x 2^%d pairs per launch / "
+                                 "mean k_acc_points duration (HIP events).  What binds the kernel is the integer multiplier (256-bit modular multiplications): "
+                                 "`valu` below prices it against the instruction-issue bound" % args.log2n},
             "stages_ms_per_step": {k: v * calls / launches for k, v in per_call.items()},
         }
         # the bound that actually binds: modular multiplications of the accumulate kernel against the
@@ -1013,10 +1128,15 @@ def main():
                 full, r = 254 // c_eff, 255 - c_eff * (254 // c_eff)
                 adds = n * (full + 1 + (0.5 if r == c_eff else 0.0))
                 mm = adds * 10.0 / (acc_ms * 1e-3)
-                out["valu"] = {"kernel": "k_acc_points", "achieved": mm / 1e9, "peak": rate.value / 1e9, "unit": "G mulmod/s",
-                               "frac": mm / rate.value,
-                               "note": "≈ %.1f M mixed additions per launch x 10 field multiplications (8M+2S) / mean kernel duration, "
-                                       "against a multiply-only Fq kernel at 8 waves/SIMD measured in this run" % (adds / 1e6)}
+                # the issue bound of the multiplier: 1024 SIMDs x 2.4 GHz / 4.8 cycles per v_mad_u64_u32 wave-instruction (benchmarks/valu_microbench.hip)
+                # x 64 lanes / 119 products per multiplication (csrc/fq26.hip.h: 100 + 19 for the 2^260 fold)
+                mad_bound = 1024 * 2.4e9 / 4.8 * 64 / 119.0
+                out["valu"] = {"kernel": "k_acc_points", "achieved": mm / 1e9, "peak": mad_bound / 1e9, "unit": "G mulmod/s", "frac": mm / mad_bound,
+                               "multiply_only_kernel": {"value": rate.value / 1e9, "frac_of_peak": rate.value / mad_bound, "frac_of_it_achieved": mm / rate.value,
+                                                        "note": "bppp_test_mulmod_rate: independent fq_mul chains, 8 waves/SIMD, measured in this run"},
+                               "note": "≈ %.1f M mixed additions per launch x 10 field multiplications (8M+2S) / mean kernel duration, against the v_mad_u64_u32 "
+                                       "issue bound (1024 SIMDs x 2.4 GHz / 4.8 cycles x 64 lanes / 119 products); a multiplication also issues ~32 other 64-bit "
+                                       "instructions at the same cost (profiles/r04_fq_mul_isa_histogram.txt), which is what the multiply-only kernel shows" % (adds / 1e6)}
         except Exception as e:          # the hook is test-only; the headline does not depend on it
             out["valu"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:

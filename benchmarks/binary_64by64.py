@@ -31,20 +31,29 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 64]:
     vals = np.concatenate([amount + dlt, amount - dlt], axis=1).astype(np.uint64)
     bld = rng.integers(1, 2**63, size=(B, count), dtype=np.uint64)
     inputs = [[(int(v), int(x)) for v, x in zip(vals[i], bld[i])] for i in range(B)]
-    t0 = time.perf_counter()
-    files = nat.prove_batch(inputs, [b"bin64 %08d" % i for i in range(B)])
-    tp = time.perf_counter() - t0
-    cf = np.frombuffer(b"".join(c for c, _ in files), dtype=np.uint8); pf = np.frombuffer(b"".join(p for _, p in files), dtype=np.uint8)
+    cache = os.environ.get("PROOF_FILES")           # profiling passes of the VERIFIER: proofs from a file made by an earlier run
+    if cache and os.path.exists(cache):
+        z = np.load(cache); cf, pf = z["cf"], z["pf"]; tp = float("nan")
+    else:
+        t0 = time.perf_counter()
+        files = nat.prove_batch(inputs, [b"bin64 %08d" % i for i in range(B)])
+        tp = time.perf_counter() - t0
+        cf = np.frombuffer(b"".join(c for c, _ in files), dtype=np.uint8); pf = np.frombuffer(b"".join(p for _, p in files), dtype=np.uint8)
+        if cache:
+            np.savez(cache, cf=cf, pf=pf)
     dc, dpf = gpu.to_device(cf), gpu.to_device(pf)
     seed = os.urandom(32)
     ok = nat.verify_batch_device(B, dc, dpf, seed)
     ts = []
     for _ in range(3):
         t0 = time.perf_counter(); ok = ok and nat.verify_batch_device(B, dc, dpf, seed); ts.append(time.perf_counter() - t0)
-    pf2 = pf.copy(); pf2[(B // 2) * nat.shape["proof_bytes"] + 9] ^= 4
-    dp2 = gpu.to_device(pf2)
-    ok2, status, _ = nat.verify_batch_device(B, dc, dp2, seed, want_status=True)
-    assert ok and not ok2 and [i for i, s_ in enumerate(status) if s_] == [B // 2], (ok, ok2)
-    gpu.free(dc); gpu.free(dpf); gpu.free(dp2)
+    if not cache:                                   # (profiling passes skip the rejection check: its bisection would add verifier calls to the trace)
+        pf2 = pf.copy(); pf2[(B // 2) * nat.shape["proof_bytes"] + 9] ^= 4
+        dp2 = gpu.to_device(pf2)
+        ok2, status, _ = nat.verify_batch_device(B, dc, dp2, seed, want_status=True)
+        assert ok and not ok2 and [i for i, s_ in enumerate(status) if s_] == [B // 2], (ok, ok2)
+        gpu.free(dp2)
+    assert ok
+    gpu.free(dc); gpu.free(dpf)
     print(f"B={B}: prove {tp * 1e3:.1f} ms ({B / tp:.0f} proofs/s), verify {min(ts) * 1e3:.3f} ms ({B / min(ts):.0f} verifies/s), proof {nat.shape['proof_bytes']} B + coms {nat.shape['coms_bytes']} B", flush=True)
 nat.close()

@@ -127,9 +127,83 @@ def round3(tag):
         print("wrote traffic.json")
 
 
+def kernel_stats(d):
+    """{kernel: (calls, mean ns)} from gpurun_out/<d>.kernel_stats.csv"""
+    path = os.path.join(G, d + ".kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out[r["Name"].split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]))
+    return out
+
+
+def verifier_table(tag, name, stats_dir, fetch_dir, write_dir, sq_dir, calls, what):
+    """Per-kernel table of ONE verifier call: launches, ms, HBM bytes (FETCH x2 per the guide, raw beside it; WRITE), wait fraction and the
+    VALU-busy estimate.  `calls` = verifier calls in the profiled command.  Returns the dict stored in traffic.json."""
+    ks, fe, wr, sq = kernel_stats(stats_dir), reduced(fetch_dir), reduced(write_dir), reduced(sq_dir)
+    if not (ks and fe and wr):
+        return None
+    rows = []
+    for k, (n, mean_ns) in ks.items():
+        if "bppp::" not in k or k not in fe or k not in wr:
+            continue
+        per_call = n / calls
+        f_raw = fe[k]["FETCH_SIZE"][0] * 1024 * per_call
+        w = wr[k]["WRITE_SIZE"][0] * 1024 * per_call
+        row = {"kernel": k, "launches_per_call": per_call, "ms_per_call": mean_ns * per_call / 1e6, "fetch_bytes_raw": f_raw, "fetch_bytes_x2": 2 * f_raw, "write_bytes": w}
+        if sq and k in sq:
+            c = {cn: v[0] for cn, v in sq[k].items()}
+            if c.get("SQ_WAVE_CYCLES"):
+                row["wait_inst_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+            # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU execution summed over the chip's 1024 SIMDs (it equals SQ_INSTS_VALU for plain
+            # 4-cycle instructions); busy = 4 x that / (1024 SIMDs x kernel cycles at 2.4 GHz)
+            row["valu_busy_est"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * mean_ns * 2.4)
+            row["valu_insts"] = c.get("SQ_INSTS_VALU", 0.0) * per_call
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_call"])
+    with open(os.path.join(P, f"{tag}_pmc_{name}_per_kernel.csv"), "w") as f:
+        f.write(f"# {what}; one verifier call; FETCH_SIZE / WRITE_SIZE / SQ_* in separate rocprofv3 --pmc passes, kernel times from a --kernel-trace --stats pass of the same command\n")
+        f.write("kernel,launches_per_call,ms_per_call,fetch_bytes_raw,fetch_bytes_x2,write_bytes,wait_inst_frac,valu_busy_est,valu_insts\n")
+        for r in rows:
+            f.write("%s,%.2f,%.4f,%.0f,%.0f,%.0f,%s,%s,%.0f\n" % (r["kernel"], r["launches_per_call"], r["ms_per_call"], r["fetch_bytes_raw"], r["fetch_bytes_x2"], r["write_bytes"],
+                                                               "%.3f" % r["wait_inst_frac"] if "wait_inst_frac" in r else "", "%.3f" % r["valu_busy_est"] if "valu_busy_est" in r else "",
+                                                               r.get("valu_insts", 0.0)))
+    tot = {"ms_of_kernels": sum(r["ms_per_call"] for r in rows), "fetch_bytes_x2": sum(r["fetch_bytes_x2"] for r in rows), "fetch_bytes_raw": sum(r["fetch_bytes_raw"] for r in rows),
+           "write_bytes": sum(r["write_bytes"] for r in rows)}
+    tot["bytes_per_call"] = tot["fetch_bytes_x2"] + tot["write_bytes"]
+    print("wrote", f"{tag}_pmc_{name}_per_kernel.csv", tot)
+    return {"source": what + "; " + tag, "per_call": tot, "by_kernel": {r["kernel"]: {k: v for k, v in r.items() if k != "kernel"} for r in rows}}
+
+
+def round4(tag):
+    """round 3's summaries plus the verifier's: per-kernel counters of one 4096-proof 64by64 verify call and one 1024-proof binary 64 x 64-bit one,
+    kernel-time summaries of the new provers"""
+    round3(tag)
+    for d, dst in (("prof_verify", f"{tag}_verify_4096_kernel_stats.csv"), ("prof_binv", f"{tag}_binary_verify_1024_kernel_stats.csv"),
+                   ("prof_binp", f"{tag}_binary_prove_verify_1024_kernel_stats.csv"), ("prof_ipp", f"{tag}_ip_prove_verify_16384_kernel_stats.csv")):
+        s_ = os.path.join(G, d + ".kernel_stats.csv")
+        if os.path.exists(s_):
+            shutil.copy(s_, os.path.join(P, dst)); print("copied", dst)
+    tpath = os.path.join(P, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    v = verifier_table(tag, "verify", "prof_verify", "pmc_verify_fetch", "pmc_verify_write", "pmc_verify_sq", 6,
+                       "VERIFY_REPS=6 python3 benchmarks/verify_timing.py 4096 (4096 distinct 64by64 proofs read from a file, bppp_rp_verify_batch_device)")
+    if v:
+        traffic["verify_4096_64by64"] = v
+    b = verifier_table(tag, "binary_verify", "prof_binv", "pmc_binv_fetch", "pmc_binv_write", "pmc_binv_sq", 4,
+                       "python3 benchmarks/binary_64by64.py 1024 (1024 distinct 64 x 64-bit binary proofs read from a file, 4 calls of bppp_rp_verify_batch_device)")
+    if b:
+        traffic["verify_binary_1024_64x64bit"] = b
+    json.dump(traffic, open(tpath, "w"), indent=1)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--reduce":
         return reduce_on_box()
+    if len(sys.argv) > 1 and sys.argv[1] >= "r04":
+        return round4(sys.argv[1])
     if len(sys.argv) > 1 and sys.argv[1] >= "r03":
         return round3(sys.argv[1])
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"

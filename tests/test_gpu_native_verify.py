@@ -162,7 +162,7 @@ def test_sharded_weights_are_global_and_bound_to_the_proofs(gpu):
 
 
 def test_eight_shards_of_one_job(gpu):
-    """BASELINE config 5's layout, shard by shard in one process (a one-GPU box admits at most 6 processes on its card; 2, 4 and 6 real ranks
+    """BASELINE config 5's layout, shard by shard in one process (a one-GPU box admits at most 6 processes on its card; 2, 4 and 5 real ranks
     run in tests/test_gpu_two_ranks.py): ONE job of 44 proofs cut into the 8 contiguous shards dist.shard_range gives 8 ranks (6 + 6 + 6 + 6 +
     5 + 5 + 5 + 5), each verified by bppp_rp_verify_shard_device with the job-wide seed and its own offset.  Honest job: every shard's point is
     the identity.  One corrupted proof in shard 5: only that shard rejects, the sum of the 8 points is not the identity and equals, point
