@@ -222,6 +222,17 @@ inline bool make_setup(bool has_types, const std::vector<RangeData> &rds, const 
   st.llen = 6;
   for (uint32_t b : mb) st.llen += b - 1;
   if (!st.nlen) { err = "empty norm vector"; return false; }
+  // untrusted sizes: a base of 2^32 - 1 asks for four billion linear entries (shared) or reciprocal symbols (inline) — refuse before anything
+  // is allocated (the argument's kernels index vectors below 2^24 entries, csrc/nlb.hip)
+  if (st.nlen >= ((size_t)1 << 24) || st.llen >= ((size_t)1 << 24)) { err = "setup too large: norm / linear vector of 2^24 entries or more"; return false; }
+  // An inline range whose reciprocal symbols ([1 | has_bit] ++ [1 .. base - 1]) outnumber its digits: makePhase1s pads bs, ds, ms, ns to the
+  // LONGEST (TypedReciprocal.hs:150-153) while setup counts one norm position per digit (:346), so the reference's own norm vector is longer
+  // than its basis gs — the extra entries are committed to the identity (dotWith's padding, Commitment.hs:423-424), bound by nothing, and the
+  // final witness no longer has the length optimalWitnessSize nrmLen promises decodeProof'.  Not a layout a sound proof can use: refused.
+  for (const RangeData &rd : rds)
+    if (!rd.assumed && !rd.shared && (rd.has_bit ? 1 : 0) + (size_t)(rd.base - 1) > rd.coeffs.size()) {
+      err = "an inline range has more reciprocal symbols than digits (base - 1 > number of digits): unsupported layout"; return false;
+    }
   if (flavour) optimal_witness_size_ip(st.nlen, st.llen, st.rounds, st.fn, st.fl);
   else optimal_witness_size_nl(st.nlen, st.llen, st.rounds, st.fn, st.fl);
   // Phase1 records
@@ -248,7 +259,7 @@ inline bool make_setup(bool has_types, const std::vector<RangeData> &rds, const 
       }
     }
   }
-  if (st.pos.size() != st.nlen) { err = "an inline range has more reciprocal symbols than digits (base - 1 > number of digits): unsupported layout"; return false; }
+  if (st.pos.size() != st.nlen) { err = "internal: Phase1 layout and norm length disagree"; return false; }
   for (const Pos &p : st.pos)
     if ((p.kind & 0xFFu) != POS_TYPING && st.slot_of(p.radix) < 0) { err = "internal: digit base missing from the base map"; return false; }
   return true;
@@ -301,6 +312,7 @@ inline bool make_setup_binary(bool conserve, const std::vector<RangeData> &rds, 
   }
   st.nlive = st.pos.size();
   if (!st.nlen) { err = "empty norm vector"; return false; }
+  if (st.nlen >= ((size_t)1 << 24)) { err = "setup too large: norm vector of 2^24 entries or more"; return false; }
   if (flavour) optimal_witness_size_ip(st.nlen, st.llen, st.rounds, st.fn, st.fl);
   else optimal_witness_size_nl(st.nlen, st.llen, st.rounds, st.fn, st.fl);
   return true;

@@ -438,3 +438,21 @@ def test_native_layer_on_a_mixed_schema(gpu):
     assert nat_ip.prove_batch(inputs[:1], prefixes[:1])[0] == (c_ip, f_ip)          # its lockstep prover: the same bytes
     nat_ip.close()
     nat.close()
+
+
+def test_native_setup_refuses_what_the_reference_missizes_and_what_is_too_large(gpu):
+    """bppp_rp_create on untrusted range lists: the padded inline layout of tests/test_rangeproof.py (base - 1 symbols > digits: the reference's own
+    setup mis-sizes it) and a base that asks for billions of linear entries are refused with a message, nothing is allocated for them"""
+    pts = O.hash_points(b"refused layouts", 40)
+    st = RP.setup(RP.GpuBackend(gpu), pts, False, [], [RP.make_range_data(16, 0, 100, False, True, False)], "NL")
+    with pytest.raises(Exception, match="unsupported layout"):
+        RP.NativeRangeProofs(gpu, st)
+    import ctypes as C
+    from bulletproofspp_amd.capi import RP_OUTPUT, RP_SHARED, RpRange, int_to_limbs, points_to_array
+    rng = (RpRange * 1)()
+    rng[0].base = 0xFFFFFFFF; rng[0].flags = RP_OUTPUT | RP_SHARED
+    rng[0].min[:] = [0, 0, 0, 0]; rng[0].max[:] = [int(v) for v in int_to_limbs(2**200)]
+    arr = points_to_array(pts)
+    hnd = C.c_void_p()
+    rc = gpu.lib.bppp_rp_create(gpu.h, 0, 0, C.cast(rng, C.c_void_p), 1, None, 0, C.c_void_p(arr.ctypes.data), arr.shape[0], None, C.byref(hnd))
+    assert rc != 0 and b"too large" in gpu.lib.bppp_last_error(gpu.h)

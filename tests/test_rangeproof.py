@@ -241,3 +241,30 @@ def test_bin_test_example(oracle_lib):
     assert len(proof.coms) == 2 + 3 and BRP.verify(st, proof, RP.sha256_oracle())
     # verifier MSM of the reference: 192 + 2 + 1 shared + 5 commitments + 12 responses = 212 terms (App. B)
     assert st.nrm_len + 2 + 1 + len(proof.coms) + 2 * st.rounds == 212
+
+
+def test_an_inline_range_with_more_symbols_than_digits_is_missized_by_the_references_own_setup():
+    """SURVEY.md App. D, one more entry.  An INLINE range whose reciprocal symbols [1 | hasBit] ++ [1 .. base - 1] outnumber its digits — base 16
+    over [0, 100): coefficients [39, 3, 1], 16 symbols.  makePhase1s pads bs, ds, ms, ns to the LONGEST of the four (TypedReciprocal.hs:150-153):
+    16 Phase1 records, hence a 16-entry norm vector; setup counts one norm position per DIGIT (:346): nrmLen = 3, three generators gs.  In
+    the reference commitRPW pairs the 13 extra norm scalars with the identity (dotWith's padding, Commitment.hs:423-424, Utils.hs:186-189):
+    they are bound by no generator, and the final witness is longer than optimalWitnessSize nrmLen = 3 tells decodeProof' (RangeProof.hs:68-85).
+    The host protocol code restates both functions as they are and therefore shows the mismatch; it refuses to commit a vector longer
+    than its basis (an assertion of its own), and the native layer refuses the setup with a message (csrc/rpsetup.hpp make_setup;
+    tests/native/rpsetup_check.cpp) — a range proof over that layout would not be sound."""
+    rd = RP.make_range_data(16, 0, 100, False, True, False)
+    assert rd.base_coeffs == [39, 3, 1] and rd.has_bit
+    ph1s, shared = RP.make_phase1s(0, rd, 57)
+    assert shared is None and len(ph1s) == 16                            # makePhase1s: padded to the 16 symbols
+    assert [p[3] for p in ph1s[:3]] == [39, 3, 1] and all(p[3] == 0 for p in ph1s[3:])       # coefficient 0 beyond the digits
+    assert [p[6] for p in ph1s] == [1] + list(range(1, 16))              # ns
+    assert sum(p[4] * p[3] for p in ph1s) == 57                          # the digits still recombine
+    st = RP.setup(OracleBackend(O.CEC()), _points(40), False, [], [rd], "NL")
+    assert st.nrm_len == 3 and len(st.gs) == 3                           # setup (:346): one position per digit
+    w = RP.witness(st, [(57, 0, 12345)])
+    with pytest.raises(AssertionError):                                  # 16 norm scalars, 3 generators
+        RP.prove(st, w, RP.sha256_oracle(), RP.hash_to_scalar(b"mis-sized"))
+    # the layouts the reference's examples use never hit this: inline bases there have at least base - 1 (+ bit) digits
+    for base, lo, hi in ((9, 0, 2**32), (16, 0, 2**64), (3, 0, 100), (5, 10, 635), (6, 0, 6**6)):
+        r2 = RP.make_range_data(base, lo, hi, False, True, False)
+        assert (1 if r2.has_bit else 0) + base - 1 <= len(r2.base_coeffs)
