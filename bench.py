@@ -567,7 +567,7 @@ def bench_ip_verify(gpu, torch, dev, batch: int, steps: int, cpu_baseline_leg: b
     """The inner-product flavour at batch scale (the CLI's DEFAULT argument, app/Parse.hs:100): `batch` DISTINCT encoded
     proofs of the examples/64bit shape — ONE 64-bit value, base 16 inline, nrmLen 16, linLen 6, 3 rounds, the paper's 416-byte proof
     (README.md:169-172) — made in this run by the library's lockstep prover (bppp_rp_prove_batch over a flavour-1 setup: range-proof phases,
-    then csrc/rpprove.hip's ip_argument_lockstep — every commitment an MSM over the original basis, no basis change, no point fold) and
+    then csrc/ipb.hip's device-resident argument — every commitment an MSM over the original basis, no basis change, no point fold) and
     verified end to end from their files in HBM by bppp_rp_verify_batch_device: decode, all SHA-256 transcript hashing, verifyTRRPM's
     scalars, expandChallenges of InnerProductArgument.hs:103-124 / :172-181 with makeNorm's basis change folded into the shared-basis
     scalars, ONE combined MSM of 23 + batch * 11 terms."""

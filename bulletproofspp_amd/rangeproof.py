@@ -827,7 +827,7 @@ class NativeRangeProofs:
     proofs (the reference's commitments / proof files, bulletproofspp_amd.encoding) are verified end to end there — decoding,
     all SHA-256 transcript hashing (the CLI's shaOracle), verifyTRRPM's scalars, challenge expansion and one combined MSM.
     Both argument flavours verify and prove (bppp_rp_prove_batch: the norm-linear argument through csrc/nlb.hip, the inner-product one
-    through csrc/rpprove.hip's ip_argument_lockstep)."""
+    through csrc/ipb.hip once the handle has its comb table, csrc/rpprove.hip's host-algebra ip_argument_lockstep before that)."""
 
     def __init__(self, gpu, st: SetupTRRP, oracle_tag: bytes = b"", h: Point = None):
         import ctypes as C

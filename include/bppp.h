@@ -325,8 +325,9 @@ int bppp_trrp_public_device(bppp_trrp *t, size_t batch, const void *d_challenges
  * src/Bulletproof/NormArgument.hs:165-178) and the REGISTERED BASIS g, G, H — uploaded once, referenced by every later call
  * (G, H are fixed per setup, TypedReciprocal.hs:348-359).  Argument flavour: 0 = norm-linear (Bulletproof.NormArgument), 1 = inner product
  * (Bulletproof.InnerProductArgument, the CLI's default, app/Parse.hs:100).  Both have the batch verifier and the lockstep batch prover
- * (bppp_rp_prove_batch; flavour 1 proves with its field algebra on the host cores and every commitment as an MSM over the registered
- * original basis — makeNorm's basis change and every point fold are carried in the scalars, same bytes as the folding route).
+ * (bppp_rp_prove_batch; flavour 1 proves with every commitment as an MSM over the registered ORIGINAL basis — makeNorm's basis change and
+ * every point fold are carried in the scalars, same bytes as the folding route; with the handle's comb table in place the whole proof,
+ * argument included, is one stream of kernels (csrc/ipb.hip), before that the field algebra of this flavour runs on the host cores).
  *
  * bppp_rp_create: `ranges` as the schema gives them (app/Parse.hs:125-172): base, min, max (plain INTEGERS in 256-bit two's complement — a minimum may be negative, examples/rec_test — max exclusive
  * as in makeRangeData), flags.  `pubs`: the public (isOutput, type, amount) triples.  `points_xy` = h : g : hs ++ gs, the stream the
@@ -359,7 +360,8 @@ int bppp_rp_create(bppp_ctx *ctx, int flavour, int has_types, const bppp_rp_rang
  * binary protocol: bppp_rp_info (lin_len = 2; proof file = final witness scalars, then blCom, dCom and the responses;
  * challenges_per_proof = 4 + rounds: q, x, r, t), bppp_rp_verify_batch* / _shard_device (verifyBRPM :206-222 with its two oracle
  * calls, then verifyBPM) and bppp_rp_prove_batch (proveBRPM :169-204 + proveBPM in lockstep; `types` is ignored, a binary proof is
- * untyped).  Both sides take the round count from optimalWitnessSize (the reference's prover uses integerLog 2 nrmLen - 1, which
+ * untyped; from its first 1024 proofs on — COMB_MIN — the handle keeps a comb table of its basis, 21.5 GB for the 4099 points of 64 outputs of
+ * 64 bits, and a proof is one stream of kernels, csrc/brpprove_dev.hip; before that the field algebra runs on the host cores; same bytes).  Both sides take the round count from optimalWitnessSize (the reference's prover uses integerLog 2 nrmLen - 1, which
  * agrees wherever its own proofs verify — SURVEY.md App. D-1). */
 int bppp_rp_create_binary(bppp_ctx *ctx, int flavour, int conserve, const bppp_rp_range *ranges, size_t nranges, const uint64_t net_public[4],
                           const uint64_t *points_xy, size_t npoints, const char *oracle_tag, bppp_rp **out);
