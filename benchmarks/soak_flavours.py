@@ -19,6 +19,13 @@ for name in ("64bit", "rec_test", "bin_test"):
     else:
         st = RP.setup_from_schema(RP.GpuBackend(gpu), schema); nat = RP.NativeRangeProofs(gpu, st)
     t_end, it = time.time() + secs, 0
+    # round 4: a second handle with the comb table forced from the first proof (the device-resident provers) must write the SAME BYTES as the
+    # default handle, whose small batches take the host-algebra routes
+    if binary:
+        dev = BRP.NativeBinaryRangeProofs(gpu, st)
+    else:
+        dev = RP.NativeRangeProofs(gpu, st)
+    dev.set_option("comb_min", 1); dev.set_option("comb_bits", 8)
     while time.time() < t_end:
         B = rnd.choice([1, 2, 3, 8, 9, 17, 64, 65, 130, 300, 1025]) if it % 2 else rnd.randrange(1, 200)
         inputs = []
@@ -26,6 +33,8 @@ for name in ("64bit", "rec_test", "bin_test"):
             rows = RP.inputs_from_witness(wit, b"soak %d %d" % (it, j))
             inputs.append([(v, bl) for v, _, bl in rows] if binary else rows)
         files = nat.prove_batch(inputs, [b"soak %06d %06d" % (it, j) for j in range(B)])
+        dev.set_option("host_oracle_max", 0 if it % 2 == 0 else 2**64 - 1)
+        assert dev.prove_batch(inputs, [b"soak %06d %06d" % (it, j) for j in range(B)]) == files, (name, it, B, "device-resident prover differs")
         seed = os.urandom(32)
         nat.set_option("host_oracle_max", 0 if it % 3 == 0 else 2**64 - 1)
         assert nat.verify_batch([c for c, _ in files], [p for _, p in files], seed), (name, it, B)
@@ -36,5 +45,5 @@ for name in ("64bit", "rec_test", "bin_test"):
         assert not ok and [i for i, s_ in enumerate(status) if s_] == [j], (name, it, B, j, status[:8])
         it += 1
     print(f"{name}: {it} batches ok", flush=True)
-    nat.close()
+    nat.close(); dev.close()
 print("soak ok")
