@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
-HIP_SOURCES = ["msm.hip", "basis.hip", "comb.hip", "fold.hip", "rounds.hip", "nl.hip", "nlb.hip", "nlbatch.hip", "ip.hip", "trrp.hip", "rp.hip", "rpprove.hip", "rpprove_dev.hip", "rpp_transcript.hip", "ipb.hip", "brpprove_dev.hip", "glv.hip", "capi.hip"]
+HIP_SOURCES = ["msm.hip", "basis.hip", "comb.hip", "fold.hip", "rounds.hip", "nl.hip", "nlb.hip", "nlbatch.hip", "ip.hip", "trrp.hip", "rp.hip", "rpprove.hip", "rpprove_dev.hip", "rpp_transcript.hip", "ipb.hip", "ipb_host.hip", "brpprove.hip", "brpprove_dev.hip", "glv.hip", "capi.hip"]
 TEST_SOURCES = ["testhooks.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"] + os.environ.get("BPPP_EXTRA_FLAGS", "").split()

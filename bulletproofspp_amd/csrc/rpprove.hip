@@ -29,6 +29,7 @@
 #include "comb.hpp"
 #include "rp_internal.hpp"
 #include "rpprove_dev.hpp"
+#include "rpprove_host.hpp"
 #include "sha256.hip.h"
 
 namespace bppp {
@@ -60,105 +61,9 @@ __global__ void __launch_bounds__(64) k_rp_commit_inputs(const uint32_t *__restr
 
 using namespace bppp;
 using namespace bppp_host;
+using namespace bppp_rpp;
 
-extern "C" {
-int bppp_nlb_create(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64_t g_xy[8], const uint64_t *q, const uint64_t *norm_x, const uint64_t *norm_g_xy,
-                    size_t nlen, const uint64_t *lin_c, const uint64_t *lin_x, const uint64_t *lin_h_xy, size_t llen, bppp_nlb **out);
-int bppp_basis_create_device(bppp_ctx *ctx, const void *d_points_xy, size_t n, int window_bits, size_t batch_hint, bppp_basis **out);
-int bppp_msm_basis(bppp_basis *basis, const void *d_scalars, size_t n_terms, size_t batch, uint64_t *out_xy);
-}
 
-namespace {
-
-using bppp_rps::Pos;
-using bppp_rps::RangeData;
-using bppp_rps::Setup;
-
-inline const Mod &MR() { return FR(); }
-inline U256 fa(const U256 &a, const U256 &b) { return madd(a, b, MR()); }
-inline U256 fs(const U256 &a, const U256 &b) { return msub(a, b, MR()); }
-inline U256 fm(const U256 &a, const U256 &b) { return frmul(a, b); }
-inline U256 fneg(const U256 &a) { return mneg(a, MR()); }
-inline U256 fdbl(const U256 &a) { return madd(a, a, MR()); }
-inline U256 fpow(U256 b, uint64_t e) { U256 r = U256::one(); while (e) { if (e & 1) r = fm(r, b); b = fm(b, b); e >>= 1; } return r; }
-inline U256 small(uint64_t v) { return U256::from_u64(v); }
-
-// `show` of a field element: its decimal integer (see sha256_oracle in rangeproof.py / shaOracle, app/Main.hs:75-80)
-void dec_append(std::string &out, U256 v) {
-  char buf[80];
-  int n = 0;
-  if (v.is_zero()) { out.push_back('0'); return; }
-  while (!v.is_zero()) {
-    uint64_t rem = 0;
-    v = bppp_rps::u_div64(v, 10000000000000000000ull, &rem);
-    const bool last = v.is_zero();
-    for (int k = 0; k < 19 && (rem || !last); k++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; }
-  }
-  while (n) out.push_back(buf[--n]);
-}
-void point_text(std::string &out, const uint64_t *xy) { dec_append(out, U256::load(xy)); dec_append(out, U256::load(xy + 4)); }
-
-// digest -> field by Binary (Prime p) (src/Encoding.hs:75-79), toP
-U256 digest_to_fr(const uint32_t h[8]) {
-  uint32_t v[8];
-  sha256_digest_to_limbs(h, v);
-  U256 r;
-  for (int i = 0; i < 4; i++) r.w[i] = ((uint64_t)v[2 * i + 1] << 32) | v[2 * i];
-  return bppp_rps::u_mod_n(r);
-}
-
-// hashToScalar prefix . show (app/Main.hs:83-87, :189): the prover's randomness, counter from 0 (ZKPT.random, src/ZKP.hs:88-92)
-struct Rnd {
-  const uint8_t *prefix; size_t plen; uint64_t n = 0;
-  U256 next() {
-    Sha256 h;
-    h.update(prefix, plen);
-    const std::string c = std::to_string(n++);
-    h.update(c.data(), c.size());
-    uint32_t d[8];
-    h.finish(d);
-    return digest_to_fr(d);
-  }
-};
-
-struct RPW { U256 sc; std::vector<U256> lin, nrm; };
-
-struct PState {
-  std::vector<U256> v, ty, bl;                 // inputs (amount, type, blinding) as field elements
-  std::vector<U256> d, mi, pv;                 // per norm position: digit (type for typing), inline multiplicity, ps (amount | 1)
-  std::vector<U256> ms_shared;                 // linLen - 6 shared multiplicities, bases in sorted order
-  RPW dm, m, r, blw;
-  std::vector<U256> u, vv, rr, cc;             // Phase2 (TypedReciprocal.hs:180-181)
-  U256 e, x, r0, q, xp, r1, t, e_inv, r0_inv, q0, q0_inv, r1_inv;
-  std::vector<U256> shared_cs;
-  U256 ns_sc, ns_ty, ns_bl;                    // sum_i inputCoeff_i * (v, ty, bl)_i
-  std::vector<std::string> groups;             // transcript text, one string per oracle call, oldest first
-  size_t npoints = 0;
-  Rnd rnd;
-  std::string err;
-  std::vector<uint32_t> tmp_ds, tmp_cnt, tmp_ms;   // make_witness scratch
-};
-
-// shaOracle (app/Main.hs:75-80) over ZKPT's transcript (src/ZKP.hs:96-101): the new commitments go IN FRONT; output n hashes
-// tag <> show n <> show (length ps) <> text of the whole transcript, newest call first
-void oracle(const std::string &tag, PState &ps, const uint64_t *const *pts, size_t npts, int count, U256 *out) {
-  std::string g;
-  g.reserve(npts * 160);
-  for (size_t i = 0; i < npts; i++) point_text(g, pts[i]);
-  ps.groups.push_back(std::move(g));
-  ps.npoints += npts;
-  for (int n = 1; n <= count; n++) {
-    Sha256 h;
-    const std::string hdr = tag + std::to_string(n) + std::to_string(ps.npoints);
-    h.update(hdr.data(), hdr.size());
-    for (size_t k = ps.groups.size(); k-- > 0;) h.update(ps.groups[k].data(), ps.groups[k].size());
-    uint32_t d[8];
-    h.finish(d);
-    out[n - 1] = digest_to_fr(d);
-  }
-}
-
-}  // namespace
 namespace bppp {
 // the same oracle for the device prover's small batches (csrc/rpprove_dev.hip): `groups` / `npoints` are one proof's transcript so far,
 // pts [m][8] its new commitments; out[count][4].  A host core hashes a 64by64 transcript in ~50 us; one GPU lane needs ~600 us.
@@ -265,29 +170,6 @@ RPW blind_err_witness(const U256 &err7, const std::vector<U256> &ns, Rnd &rnd, s
   for (int i = 0; i < 6; i++) w.lin[i] = b[1 + i];
   w.nrm = ns;
   return w;
-}
-
-// a^(n-2) with the dedicated multiply; 0 -> 0
-U256 finv(const U256 &a) {
-  U256 e; sub_raw(e, MR().m, U256::from_u64(2));
-  U256 acc = U256::one(), base = a;
-  for (int i = 0; i < 256; i++) { if (e.bit(i)) acc = fm(acc, base); base = fm(base, base); }
-  return acc;
-}
-// batchInverse (src/Data/Field/BatchInverse.hs:18-39): Montgomery's trick, 0 -> 0
-void batch_inv(std::vector<U256> &v) {
-  const size_t n = v.size();
-  if (!n) return;
-  std::vector<U256> pre(n);
-  U256 acc = U256::one();
-  for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!v[i].is_zero()) acc = fm(acc, v[i]); }
-  U256 y = finv(acc);
-  for (size_t i = n; i-- > 0;) {
-    if (v[i].is_zero()) continue;
-    const U256 inv = fm(y, pre[i]);
-    y = fm(y, v[i]);
-    v[i] = inv;
-  }
 }
 
 // makeBaseMap: sortedBases zipped with x^3, x^5, ... (TypedReciprocal.hs:349)
@@ -454,20 +336,6 @@ void make_public_consts(const Setup &st, const PState &ps, U256 &sc, std::vector
   sc = fa(z, acc);
 }
 
-void put_field(uint8_t *dst, const U256 &v) {      // Binary (Prime p) put (Encoding.hs:81-86)
-  for (int i = 0; i < 4; i++) for (int k = 0; k < 8; k++) dst[8 * i + k] = (uint8_t)(v.w[i] >> (56 - 8 * k));
-}
-// encodeCommitments (Encoding.hs:130-134): packed sign bits (y > p - y), then the x coordinates
-void encode_points(uint8_t *dst, const uint64_t *const *pts, size_t n) {
-  const size_t ns = (n + 7) / 8;
-  memset(dst, 0, ns);
-  for (size_t i = 0; i < n; i++) {
-    const U256 y = U256::load(pts[i] + 4), ny = mneg(y, FQ());
-    if (cmp(y, ny) > 0) dst[i >> 3] |= (uint8_t)(1u << (i & 7));
-    put_field(dst + ns + 32 * i, U256::load(pts[i]));
-  }
-}
-
 // the fixed-base table of (g, H0, H1): [3][64][15] affine points, built once per setup on the host (2880 additions, one batch inversion)
 int build_fixed_table(bppp_rp *rp) {
   if (rp->d_fixed) return BPPP_OK;
@@ -514,6 +382,7 @@ int ensure_pwork(bppp_rp *rp, size_t bytes) {
 
 namespace bppp {
 int rpp_ensure_pwork(bppp_rp *rp, size_t bytes) { return ensure_pwork(rp, bytes); }
+int rpp_build_fixed_table(bppp_rp *rp) { return build_fixed_table(rp); }
 int rpp_commit_inputs(bppp_rp *rp, const uint32_t *d_in_sc, size_t n, uint32_t *d_out) {
   bppp_ctx *ctx = rp->ctx;
   // g, H0, H1 are the first three points of the registered basis: with its comb table a commitment is <= 3 x 17 additions, not 3 x 64
@@ -588,150 +457,6 @@ static void encode_batch(const bppp_rp *rp, size_t B, const RppOutputs &o, uint8
 }
 
 
-// ------------------------------------------------------------------------------------------------ inner-product flavour, lockstep
-// proveBPM (src/Bulletproof.hs:357-359) of src/Bulletproof/InnerProductArgument.hs for B arguments of one shape, WITHOUT one basis change
-// and WITHOUT one point fold.  Two observations:
-//   (1) makeNorm's basis (:194-206) g'_j = g_2j+1 + r g_2j, h'_j = g_2j+1 - r g_2j enters every commitment linearly:
-//       A g'_j + B h'_j = (A + B) g_2j+1 + r (A - B) g_2j  — so a commitment over the transformed basis is an MSM over the ORIGINAL one;
-//   (2) collapse (:86-101, :162-170) folds a pair of points with the reduced fraction (a', b') of rho = 1/(q e) (resp. e, 1/e) and scales the
-//       scalars by 1/b0 so that the products scalar x point depend on rho only.  Tracking, per original position i, the product coef_i of
-//       the rho's of the right halves i fell into, the level-k basis point at position p is sum_{i >> k = p} coef_i P_i and every round
-//       commitment is again an MSM over the original points with scalars sc_{i >> k} coef_i — the same group elements as the folding
-//       route, hence the same L, R and (the normalisations cancel: nx x and ny y are what getWitness :222-223 emits) the same final witness.
-// Per round and proof: O(nrmLen + linLen) Fr multiplications on the host cores, two rows of 1 + linLen + nrmLen scalars; all 2B rows are ONE
-// batched MSM over the registered basis [g | H | G] (fixed-base table, one bucket set per instance).  The oracle is the setup's shaOracle.
-// in: psv [B] (the PSV scalar), rr [B] (makeNorm's r), nrm [B][nlen], lc / lx [B][llen]; trs: the proofs' transcripts so far
-// out: resp [B][k][16] (L, R per round, LAST round first), wn [B][fn], wl [B][fl]
-static int ip_argument_lockstep(bppp_rp *rp, size_t B, size_t k, const uint64_t *psv_in, const uint64_t *rr, const uint64_t *nrm, const uint64_t *lc_in,
-                                const uint64_t *lx_in, const std::function<PState &(size_t)> &tr_of, uint64_t *resp, uint64_t *wn, uint64_t *wl) {
-  bppp_ctx *ctx = rp->ctx;
-  const Setup &st = rp->st;
-  const size_t nlen = st.nlen, llen = st.llen, m0 = (nlen + 1) / 2, T = 1 + llen + nlen;
-  struct IpState {
-    std::vector<U256> X, Y, LC, LX, cx, cy, cl;       // current vectors (unscaled) and the per-original-position coefficient products
-    U256 r, q, qinv, NX, psv, sL, sR;
-  };
-  std::vector<IpState> sts(B);
-  const U256 half = finv(small(2)), four = small(4);
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    for (size_t b = lo; b < hi; b++) {
-      IpState &p = sts[b];
-      p.r = U256::load(rr + 4 * b);
-      const U256 r2 = fm(p.r, p.r), r2i = finv(fdbl(p.r));
-      p.q = fm(r2, r2); p.qinv = finv(p.q); p.NX = U256::one(); p.psv = U256::load(psv_in + 4 * b);
-      p.X.resize(m0); p.Y.resize(m0); p.cx.assign(m0, U256::one()); p.cy.assign(m0, U256::one());
-      for (size_t j = 0; j < m0; j++) {                   // makeNorm (:202-203): x' = s0 / (2r) + s1 / 2, y' = -s0 / (2r) + s1 / 2
-        const U256 s0 = U256::load(nrm + 4 * (b * nlen + 2 * j)), s1 = 2 * j + 1 < nlen ? U256::load(nrm + 4 * (b * nlen + 2 * j + 1)) : U256::zero();
-        const U256 a = fm(r2i, s0), c = fm(half, s1);
-        p.X[j] = fa(a, c); p.Y[j] = fs(c, a);
-      }
-      p.LC.resize(llen); p.LX.resize(llen); p.cl.assign(llen, U256::one());
-      for (size_t i = 0; i < llen; i++) { p.LC[i] = U256::load(lc_in + 4 * (b * llen + i)); p.LX[i] = U256::load(lx_in + 4 * (b * llen + i)); }
-    }
-  });
-  { int rc = ensure_pwork(rp, 2 * B * T * 32 + 1024); if (rc) return rc; }
-  uint32_t *d_rows = (uint32_t *)rp->pwork;
-  std::vector<uint64_t> h_rows(2 * B * T * 4), h_com(2 * B * 8);
-  for (size_t round = 0; round < k; round++) {
-    // ---- makeScalarsComs (:70-81, :155-158; BPCompose sums the two sub-arguments, Bulletproof.hs:258-261) and the two rows
-    rp_parallel(B, [&](size_t lo, size_t hi) {
-      std::vector<U256> lgx, lhy, rgx, rhy, ll, rl;       // opening scalars per CURRENT position: on g', h' and the linear basis
-      for (size_t b = lo; b < hi; b++) {
-        IpState &p = sts[b];
-        const size_t mc = p.X.size(), lcn = p.LX.size();
-        const U256 q2 = fm(p.q, p.q);
-        lgx.assign(mc + (mc & 1), U256::zero()); lhy = lgx; rgx = lgx; rhy = lgx;
-        U256 w = U256::one(), l = U256::zero(), r_ = U256::zero();
-        for (size_t t = 0; 2 * t < mc; t++) {
-          const U256 xL = p.X[2 * t], yL = p.Y[2 * t], xR = 2 * t + 1 < mc ? p.X[2 * t + 1] : U256::zero(), yR = 2 * t + 1 < mc ? p.Y[2 * t + 1] : U256::zero();
-          l = fa(l, fm(w, fm(xL, yR))); r_ = fa(r_, fm(w, fm(xR, yL)));
-          lgx[2 * t + 1] = fm(p.qinv, xL); lhy[2 * t] = yR;      // L: IPF (qInv xL) gR yR hL
-          rgx[2 * t] = fm(p.q, xR); rhy[2 * t + 1] = yL;         // R: IPF (q xR) gL yL hR
-          w = fm(w, q2);
-        }
-        const U256 kk = fm(four, p.NX);                          // s nx ny with s = 4 (makeNorm), ny = 1 in the unscaled recursion
-        U256 sL = mc ? fm(fm(kk, p.q), l) : U256::zero(), sR = mc ? fm(fm(kk, q2), r_) : U256::zero();
-        ll.assign(lcn + (lcn & 1), U256::zero()); rl = ll;
-        for (size_t t = 0; 2 * t < lcn; t++) {
-          const U256 cL = p.LC[2 * t], xL = p.LX[2 * t], cR = 2 * t + 1 < lcn ? p.LC[2 * t + 1] : U256::zero(), xR = 2 * t + 1 < lcn ? p.LX[2 * t + 1] : U256::zero();
-          sL = fa(sL, fm(cR, xL)); sR = fa(sR, fm(cL, xR));
-          ll[2 * t + 1] = xL; rl[2 * t] = xR;                    // L: LF cR xL gR;  R: LF cL xR gL
-        }
-        p.sL = sL; p.sR = sR;
-        for (int side = 0; side < 2; side++) {
-          uint64_t *row = &h_rows[(2 * b + side) * T * 4];
-          const std::vector<U256> &gx = side ? rgx : lgx, &hy = side ? rhy : lhy, &lv = side ? rl : ll;
-          (side ? sR : sL).store(row);
-          for (size_t i = 0; i < llen; i++) fm(lv[i >> round], p.cl[i]).store(row + 4 * (1 + i));
-          for (size_t i = 0; i < m0; i++) {
-            const size_t pos = i >> round;
-            const U256 A = fm(gx[pos], p.cx[i]), Bv = fm(hy[pos], p.cy[i]);
-            fm(p.r, fs(A, Bv)).store(row + 4 * (1 + llen + 2 * i));                       // on g_2i
-            if (2 * i + 1 < nlen) fa(A, Bv).store(row + 4 * (1 + llen + 2 * i + 1));        // on g_2i+1 (absent for an odd tail: infinity in makeNorm)
-          }
-        }
-      }
-    });
-    BPPP_HIP(ctx, hipMemcpyAsync(d_rows, h_rows.data(), 2 * B * T * 32, hipMemcpyHostToDevice, ctx->stream));
-    { int rc = bppp_msm_basis(rp->commit_basis, d_rows, T, 2 * B, h_com.data()); if (rc) return rc; }
-    // ---- the challenge, s += e0 sL + e1 sR with makeEs e = (1/e, e) (:68), collapse
-    std::atomic<int> bad{0};
-    rp_parallel(B, [&](size_t lo, size_t hi) {
-      for (size_t b = lo; b < hi; b++) {
-        IpState &p = sts[b];
-        const uint64_t *pts[2] = {&h_com[16 * b], &h_com[16 * b + 8]};
-        U256 e;
-        oracle(rp->tag, tr_of(b), pts, 2, 1, &e);
-        if (e.is_zero()) { bad = 1; continue; }
-        const U256 ei = finv(e);
-        const size_t slot = k - 1 - round;                     // responses LAST round first (Bulletproof.hs:359)
-        memcpy(resp + (b * k + slot) * 16, pts[0], 64); memcpy(resp + (b * k + slot) * 16 + 8, pts[1], 64);
-        p.psv = fa(p.psv, fa(fm(ei, p.sL), fm(e, p.sR)));
-        const size_t mc = p.X.size(), lcn = p.LX.size();
-        if (mc) {
-          const U256 eq = fm(e, p.q), rhox = fm(p.qinv, ei);
-          std::vector<U256> nx((mc + 1) / 2), ny((mc + 1) / 2);
-          for (size_t t = 0; 2 * t < mc; t++) {
-            const bool has = 2 * t + 1 < mc;
-            nx[t] = has ? fa(p.X[2 * t], fm(eq, p.X[2 * t + 1])) : p.X[2 * t];
-            ny[t] = has ? fa(p.Y[2 * t], fm(ei, p.Y[2 * t + 1])) : p.Y[2 * t];
-          }
-          p.X.swap(nx); p.Y.swap(ny);
-          for (size_t i = 0; i < m0; i++) if ((i >> round) & 1) { p.cx[i] = fm(p.cx[i], rhox); p.cy[i] = fm(p.cy[i], e); }
-          p.NX = fm(p.NX, p.qinv);
-          p.q = fm(p.q, p.q); p.qinv = fm(p.qinv, p.qinv);
-        }
-        if (lcn) {
-          std::vector<U256> nc((lcn + 1) / 2), nxl((lcn + 1) / 2);
-          for (size_t t = 0; 2 * t < lcn; t++) {
-            const bool has = 2 * t + 1 < lcn;
-            nc[t] = has ? fa(p.LC[2 * t], fm(ei, p.LC[2 * t + 1])) : p.LC[2 * t];
-            nxl[t] = has ? fa(p.LX[2 * t], fm(e, p.LX[2 * t + 1])) : p.LX[2 * t];
-          }
-          p.LC.swap(nc); p.LX.swap(nxl);
-          for (size_t i = 0; i < llen; i++) if ((i >> round) & 1) p.cl[i] = fm(p.cl[i], ei);
-        }
-      }
-    });
-    if (bad) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: a round challenge is zero");
-  }
-  // ---- getWitness: Norm (nx x - ny y, nx x + ny y) (:222-223), Linear nrmlz x (:160)
-  for (size_t b = 0; b < B; b++) {
-    const IpState &p = sts[b];
-    if (2 * p.X.size() != st.fn || p.LX.size() != st.fl) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: the argument ended at an unexpected length");
-    for (size_t j = 0; j < p.X.size(); j++) {
-      const U256 a = fm(p.NX, p.X[j]);
-      fs(a, p.Y[j]).store(wn + 4 * (b * st.fn + 2 * j)); fa(a, p.Y[j]).store(wn + 4 * (b * st.fn + 2 * j + 1));
-    }
-    for (size_t i = 0; i < p.LX.size(); i++) p.LX[i].store(wl + 4 * (b * st.fl + i));
-  }
-  return BPPP_OK;
-}
-
-static int prove_batch_binary(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
-                              uint8_t *coms_files, uint8_t *proof_files);
-static int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
-                                  uint8_t *coms_files, uint8_t *proof_files);
 
 static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
                            size_t prefix_len, uint8_t *coms_files, uint8_t *proof_files, size_t index_base);
@@ -1056,296 +781,3 @@ static int prove_batch_host(bppp_rp *rp, size_t batch, const uint64_t *amounts, 
   return BPPP_OK;
 }
 
-
-// ------------------------------------------------------------------------------------------------ RangeProof.Binary
-// proveM for B binary range proofs of one setup in lockstep: proveBRPM (src/RangeProof/Binary.hs:169-204) then proveBPM
-// (src/Bulletproof.hs:357-359) and encodeProof' (src/RangeProof.hs:60-66).  Work split as in prove_batch_host above: every group
-// operation on the device — input commitments v g + bl h0 through the fixed-base table of (g, h0, h1), the digit and blinding
-// commitments of all proofs as batched MSMs over the registered basis [g | h0 h1 | G], the argument through csrc/nlb.hip — the
-// O(nrmLen) field algebra of a proof and its transcript hashing on the host cores (one proof per thread slice).
-static int prove_batch_binary(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
-                              uint8_t *coms_files, uint8_t *proof_files) {
-  bppp_ctx *ctx = rp->ctx;
-  hipSetDevice(ctx->device);
-  hipStream_t stream = ctx->stream;
-  const Setup &st = rp->st;
-  const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, nlive = st.nlive, llen = 2, k = st.rounds, T = 1 + llen + nlen;
-  const bool timing = rp->opt.timing;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_last = timing ? now() : 0;
-  auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[rp_prove binary] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
-  { int rc = build_fixed_table(rp); if (rc) return rc; }
-  if (!rp->commit_basis) { int rc = bppp_basis_create_device(ctx, rp->d_basis, T, 0, 4096, &rp->commit_basis); if (rc) return rc; }
-  const size_t in_sc = B * nr * 3 * 32, in_pt = B * nr * 64, rows = B * T * 32;
-  { int rc = ensure_pwork(rp, in_sc + in_pt + rows + 1024); if (rc) return rc; }
-  uint32_t *d_in_sc = (uint32_t *)rp->pwork, *d_in_pt = (uint32_t *)((char *)rp->pwork + ((in_sc + 255) & ~(size_t)255)),
-           *d_rows = (uint32_t *)((char *)d_in_pt + ((in_pt + 255) & ~(size_t)255));
-  struct BState {
-    std::vector<U256> v, bl, ds, bls, pub_nrm;
-    U256 s_bl, l_bl0, bl_bl, q, x, r, t, q0, bl0_sc, lin1, pub_sc;
-    PState tr;                                            // transcript text + randomness (oracle() works on a PState)
-    std::string err;
-  };
-  std::vector<BState> ps(B);
-  std::vector<uint64_t> h_in_sc(B * nr * 12), h_in_pt(B * nr * 8), h_rows(B * T * 4), h_com(B * 8), c_d(B * 8), c_bl(B * 8);
-  std::atomic<int> failed{-1};
-  auto put_row = [&](size_t row, const U256 &sc, const U256 &l0, const U256 &l1, const std::vector<U256> &nrm) {
-    uint64_t *dst = &h_rows[row * T * 4];
-    memset(dst, 0, T * 32);
-    sc.store(dst); l0.store(dst + 4); l1.store(dst + 8);
-    for (size_t i = 0; i < nrm.size(); i++) nrm[i].store(dst + 4 * (3 + i));
-  };
-  auto commit_rows = [&]() -> int {
-    BPPP_HIP(ctx, hipMemcpyAsync(d_rows, h_rows.data(), B * T * 32, hipMemcpyHostToDevice, stream));
-    return bppp_msm_basis(rp->commit_basis, d_rows, T, B, h_com.data());
-  };
-  // ---- witnessBRP (:158-166) and phase 1 (:171-178): digits, the digit commitment's scalars
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    std::vector<uint32_t> dg;
-    for (size_t b = lo; b < hi; b++) {
-      BState &p = ps[b];
-      p.tr.rnd = Rnd{rand_prefix + b * prefix_len, prefix_len, 0};
-      p.v.resize(nr); p.bl.resize(nr); p.ds.clear();
-      U256 vsum = st.net_public;
-      bool ok = true;
-      for (size_t i = 0; i < nr && ok; i++) {
-        const RangeData &rd = st.rds[i];
-        const U256 amt = U256::load(amounts + 4 * (b * nr + i));
-        p.bl[i] = U256::load(blinds + 4 * (b * nr + i));
-        if (!scalars_canonical(blinds + 4 * (b * nr + i), 1)) { p.err = "blinding is not canonical"; ok = false; break; }
-        p.v[i] = bppp_rps::s_mod_n(amt);
-        vsum = rd.output ? fs(vsum, p.v[i]) : fa(vsum, p.v[i]);
-        if (rd.assumed) continue;
-        if (bppp_rps::s_lt(amt, rd.lo) || !bppp_rps::s_lt(amt, rd.hi)) { p.err = "value outside its range"; ok = false; break; }
-        bppp_rps::digits_binary_into(rd, bppp_rps::u_sub(amt, rd.lo), dg);
-        for (uint32_t d : dg) p.ds.push_back(small(d));
-      }
-      if (ok && !(st.conserve && vsum.is_zero())) { p.err = "a binary witness needs a conserved schema whose amounts balance (Binary.hs:162-164)"; ok = false; }
-      if (!ok) { failed = (int)b; continue; }
-      for (size_t i = 0; i < nr; i++) {                     // scalarRPW' (Internal.hs:56-57): v g + bl h0
-        p.v[i].store(&h_in_sc[(b * nr + i) * 12]); p.bl[i].store(&h_in_sc[(b * nr + i) * 12 + 4]); U256::zero().store(&h_in_sc[(b * nr + i) * 12 + 8]);
-      }
-      p.s_bl = p.tr.rnd.next(); p.l_bl0 = p.tr.rnd.next();
-      put_row(b, p.s_bl, p.l_bl0, U256::zero(), p.ds);
-    }
-  });
-  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed) + ": " + ps[failed].err);
-  lap("witness, digits (host)");
-  BPPP_HIP(ctx, hipMemcpyAsync(d_in_sc, h_in_sc.data(), in_sc, hipMemcpyHostToDevice, stream));
-  {
-    const uint64_t n = (uint64_t)B * nr;
-    k_rp_commit_inputs<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(rp->d_fixed, d_in_sc, n, d_in_pt);
-    BPPP_HIP(ctx, hipGetLastError());
-    BPPP_HIP(ctx, hipMemcpyAsync(h_in_pt.data(), d_in_pt, in_pt, hipMemcpyDeviceToHost, stream));
-  }
-  { int rc = commit_rows(); if (rc) return rc; }            // dCom of every proof; synchronises the stream
-  memcpy(c_d.data(), h_com.data(), B * 64);
-  lap("input commitments, dCom");
-  // ---- (q, x, r), makePublicConsts, the blinding commitment (:179-189)
-  const std::vector<bool> is_o = [&] { std::vector<bool> v_; for (const RangeData &rd : st.rds) v_.push_back(rd.output); return v_; }();
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    std::vector<const uint64_t *> pts(1 + nr);
-    for (size_t b = lo; b < hi; b++) {
-      BState &p = ps[b];
-      pts[0] = &c_d[8 * b];
-      for (size_t i = 0; i < nr; i++) pts[1 + i] = &h_in_pt[(b * nr + i) * 8];
-      U256 ch[3];
-      oracle(rp->tag, p.tr, pts.data(), pts.size(), 3, ch);
-      p.q = ch[0]; p.x = ch[1]; p.r = ch[2];
-      p.q0 = fm(p.q, p.q);                                  // qPowers': powers' (q^2) for the norm-linear argument (NormArgument.hs:148),
-      if (st.flavour) p.q0 = fneg(p.q0);                    // powers' (-q^2) for the inner-product one (InnerProductArgument.hs:231)
-      const U256 q0i = finv(p.q0), r_inv = finv(p.r), xx = fm(p.x, p.x), half = finv(small(2));
-      // makePublicConsts (:73-98)
-      std::vector<U256> x2s(nr);
-      { U256 c = xx; for (size_t j = 0; j < nr; j++) { x2s[j] = c; c = fm(c, xx); } }
-      U256 z = st.conserve ? fneg(fm(p.x, st.net_public)) : U256::zero();
-      for (size_t j = 0; j < nr; j++) if (!st.rds[j].assumed) z = fa(z, fm(bppp_rps::s_mod_n(st.rds[j].lo), x2s[j]));
-      U256 sc = fneg(fdbl(z));
-      p.pub_nrm.resize(nlive);
-      U256 q2 = p.q0, q2i = q0i;
-      for (size_t i = 0; i < nlive; i++) {
-        const U256 pv = fs(fm(fm(x2s[st.pos[i].range], st.pos[i].coeff), q2i), half);
-        sc = fa(sc, fm(q2, fm(pv, pv)));
-        p.pub_nrm[i] = pv;
-        q2 = fm(q2, p.q0); q2i = fm(q2i, q0i);
-      }
-      p.pub_sc = sc;
-      p.bls.resize(nlen);
-      for (auto &v_ : p.bls) v_ = p.tr.rnd.next();
-      p.bl_bl = p.tr.rnd.next();
-      // makePolyTerms (Internal.hs:69-80) of |bls + T (ds + pub)|^2_q: the constant and the linear coefficient
-      U256 w = p.q0, bl0 = U256::zero(), bl1 = U256::zero();
-      for (size_t i = 0; i < nlen; i++) {
-        bl0 = fa(bl0, fm(w, fm(p.bls[i], p.bls[i])));
-        if (i < nlive) bl1 = fa(bl1, fm(w, fm(p.bls[i], fa(p.ds[i], p.pub_nrm[i]))));
-        w = fm(w, p.q0);
-      }
-      p.bl0_sc = bl0;
-      p.lin1 = fm(r_inv, fs(p.s_bl, fdbl(bl1)));
-      put_row(b, p.bl0_sc, p.bl_bl, p.lin1, p.bls);
-    }
-  });
-  lap("q x r, public consts, bls (host)");
-  { int rc = commit_rows(); if (rc) return rc; }
-  memcpy(c_bl.data(), h_com.data(), B * 64);
-  lap("blCom");
-  // ---- t and the argument's witness (:190-201)
-  std::vector<uint64_t> a_s(B * 4), a_q(B * 4), a_nx(B * nlen * 4), a_lc(B * llen * 4), a_lx(B * llen * 4);
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    for (size_t b = lo; b < hi; b++) {
-      BState &p = ps[b];
-      const uint64_t *pt = &c_bl[8 * b];
-      oracle(rp->tag, p.tr, &pt, 1, 1, &p.t);
-      const U256 xx = fm(p.x, p.x), two_t = fdbl(p.t);
-      U256 x2 = xx, icv = U256::zero(), icb = U256::zero();
-      for (size_t j = 0; j < nr; j++) {                     // inputCoeffs (:127-129)
-        U256 ic = st.rds[j].assumed ? U256::zero() : x2;
-        if (st.conserve) ic = st.rds[j].output ? fs(ic, p.x) : fa(ic, p.x);
-        icv = fa(icv, fm(ic, p.v[j])); icb = fa(icb, fm(ic, p.bl[j]));
-        x2 = fm(x2, xx);
-      }
-      // bpWit = blWit + t (pub' + dWit + 2 t sum_j ic_j nWit_j),  pub' = (t pubSc; pubNrm)
-      fa(p.bl0_sc, fm(p.t, fa(fa(fm(p.t, p.pub_sc), p.s_bl), fm(two_t, icv)))).store(&a_s[4 * b]);
-      p.q.store(&a_q[4 * b]);
-      fa(p.bl_bl, fm(p.t, fa(p.l_bl0, fm(two_t, icb)))).store(&a_lx[(b * 2) * 4]);
-      p.lin1.store(&a_lx[(b * 2 + 1) * 4]);
-      for (size_t i = 0; i < nlen; i++) {
-        U256 v_ = p.bls[i];
-        if (i < nlive) v_ = fa(v_, fm(p.t, fa(p.pub_nrm[i], p.ds[i])));
-        v_.store(&a_nx[(b * nlen + i) * 4]);
-      }
-      U256::zero().store(&a_lc[(b * 2) * 4]); fm(p.r, p.t).store(&a_lc[(b * 2 + 1) * 4]);      // setupBRP's cs' = [0, r t] (:152)
-      p.bls.clear(); p.pub_nrm.clear(); p.ds.clear();
-    }
-  });
-  lap("t, argument witness (host)");
-  // ---- proveBPM in lockstep
-  std::vector<uint64_t> resp(B * (k ? k : 1) * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
-  if (st.flavour) {
-    int rc = ip_argument_lockstep(rp, B, k, a_s.data(), a_q.data(), a_nx.data(), a_lc.data(), a_lx.data(), [&](size_t b) -> PState & { return ps[b].tr; }, resp.data(),
-                                  wn.data(), wl.data());
-    if (rc) return rc;
-  } else {
-    // (measured and not kept: the fixed-basis mode over a comb table of the binary setup's 4099 points — 21.5 GB at c = 13 — takes the
-    // argument of 1024 64x64-bit proofs from 167 to 157 ms: its rounds are host round trips either way)
-    bppp_nlb *nlb = nullptr;
-    int rc = bppp_nlb_create(ctx, B, a_s.data(), rp->h_g.data(), a_q.data(), a_nx.data(), rp->h_G.data(), nlen, a_lc.data(), a_lx.data(), rp->h_H.data(), llen, &nlb);
-    if (rc) return rc;
-    std::vector<uint64_t> sX(B * 4), sR(B * 4), X(B * 8), R(B * 8), es(B * 4);
-    for (size_t round = 0; round < k && !rc; round++) {
-      rc = bppp_nlb_round_commit(nlb, sX.data(), X.data(), sR.data(), R.data());
-      if (rc) break;
-      rp_parallel(B, [&](size_t lo, size_t hi) {
-        for (size_t b = lo; b < hi; b++) {
-          const uint64_t *pts[2] = {&X[8 * b], &R[8 * b]};
-          U256 e;
-          oracle(rp->tag, ps[b].tr, pts, 2, 1, &e);
-          e.store(&es[4 * b]);
-          const size_t slot = k - 1 - round;                 // responses LAST round first (Bulletproof.hs:359)
-          memcpy(&resp[(b * k + slot) * 16], pts[0], 64); memcpy(&resp[(b * k + slot) * 16 + 8], pts[1], 64);
-        }
-      });
-      rc = bppp_nlb_round_collapse(nlb, es.data());
-    }
-    if (!rc) rc = bppp_nlb_get_witness(nlb, wn.data(), wl.data(), nullptr);
-    bppp_nlb_destroy(nlb);
-    if (rc) return rc;
-  }
-  lap("argument (lockstep)");
-  // ---- encodeProof': commitments file = the input commitments; proof file = final witness scalars, then blCom, dCom and the responses
-  const RpDims &D = rp->D;
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    std::vector<const uint64_t *> pts;
-    for (size_t b = lo; b < hi; b++) {
-      pts.assign(nr, nullptr);
-      for (size_t i = 0; i < nr; i++) pts[i] = &h_in_pt[(b * nr + i) * 8];
-      encode_points(coms_files + b * D.coms_bytes, pts.data(), nr);
-      uint8_t *pf = proof_files + b * D.proof_bytes;
-      for (size_t i = 0; i < st.fn; i++) put_field(pf + 32 * i, U256::load(&wn[(b * st.fn + i) * 4]));
-      for (size_t i = 0; i < st.fl; i++) put_field(pf + 32 * (st.fn + i), U256::load(&wl[(b * st.fl + i) * 4]));
-      pts.assign(2 + 2 * k, nullptr);
-      pts[0] = &c_bl[8 * b]; pts[1] = &c_d[8 * b];
-      for (size_t j = 0; j < 2 * k; j++) pts[2 + j] = &resp[(b * k) * 16 + 8 * j];
-      encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 2 + 2 * k);
-    }
-  });
-  return BPPP_OK;
-}
-
-// The same proofs with proveBRPM's field algebra, randomness and transcript on the device (csrc/brpprove_dev.hip): the host checks the
-// witness (witnessBRP, Binary.hs:158-166), extracts the binary digits of the plain amounts (makeDigits :56-69) and writes the files.
-static int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
-                                  uint8_t *coms_files, uint8_t *proof_files) {
-  bppp_ctx *ctx = rp->ctx;
-  hipSetDevice(ctx->device);
-  const Setup &st = rp->st;
-  const size_t B = batch, nr = st.rds.size(), nlive = st.nlive, k = st.rounds;
-  const bool timing = rp->opt.timing;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_last = timing ? now() : 0;
-  auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[rp_prove binary] %-28s %8.2f ms\n", what, t - t_last); t_last = t; } };
-  // pinned staging, grow-only: [in_sc B nr 3 | input commitments B nr | bits B nlive]
-  const size_t n_in_sc = B * nr * 12, n_in_pt = B * nr * 8;
-  const size_t pin_need = (n_in_sc + n_in_pt) * 8 + B * nlive + 64;
-  if (pin_need > rp->hpin_bytes) {
-    BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (rp->hpin) BPPP_HIP(ctx, hipHostFree(rp->hpin));
-    rp->hpin = nullptr; rp->hpin_bytes = 0;
-    BPPP_HIP(ctx, hipHostMalloc(&rp->hpin, pin_need + pin_need / 8, hipHostMallocDefault));
-    rp->hpin_bytes = pin_need + pin_need / 8;
-  }
-  uint64_t *h_in_sc = (uint64_t *)rp->hpin, *h_in_pt = h_in_sc + n_in_sc;
-  uint8_t *bits = (uint8_t *)(h_in_pt + n_in_pt);
-  std::atomic<int> failed{-1};
-  std::vector<std::string> errs(B);
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    std::vector<uint32_t> dg;
-    for (size_t b = lo; b < hi; b++) {
-      U256 vsum = st.net_public;
-      const char *err = nullptr;
-      size_t p = 0;
-      for (size_t i = 0; i < nr && !err; i++) {
-        const RangeData &rd = st.rds[i];
-        const U256 amt = U256::load(amounts + 4 * (b * nr + i));
-        if (!scalars_canonical(blinds + 4 * (b * nr + i), 1)) { err = "blinding is not canonical"; break; }
-        const U256 v = bppp_rps::s_mod_n(amt);
-        vsum = rd.output ? fs(vsum, v) : fa(vsum, v);
-        uint64_t *row = &h_in_sc[(b * nr + i) * 12];          // scalarRPW' (Internal.hs:56-57): v g + bl h0
-        v.store(row); memcpy(row + 4, blinds + 4 * (b * nr + i), 32); memset(row + 8, 0, 32);
-        if (rd.assumed) continue;
-        if (bppp_rps::s_lt(amt, rd.lo) || !bppp_rps::s_lt(amt, rd.hi)) { err = "value outside its range"; break; }
-        bppp_rps::digits_binary_into(rd, bppp_rps::u_sub(amt, rd.lo), dg);
-        for (uint32_t d : dg) bits[b * nlive + p++] = (uint8_t)d;
-      }
-      if (!err && !(st.conserve && vsum.is_zero())) err = "a binary witness needs a conserved schema whose amounts balance (Binary.hs:162-164)";
-      if (!err && p != nlive) err = "digit count disagrees with the setup";
-      if (err) { failed = (int)b; errs[b] = err; }
-    }
-  });
-  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed) + ": " + errs[failed]);
-  lap("witness, digits (host)");
-  std::vector<uint64_t> c_d(B * 8), c_bl(B * 8), resp(B * (k ? k : 1) * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
-  BrpHostInputs in{B, h_in_sc, bits, rand_prefix, prefix_len};
-  BrpOutputs out{h_in_pt, c_d.data(), c_bl.data(), resp.data(), wn.data(), wl.data()};
-  { int rc = brp_device_prove(rp, in, out); if (rc) return rc; }
-  lap("phases + argument (device)");
-  // encodeProof': commitments file = the input commitments; proof file = final witness scalars, then blCom, dCom and the responses
-  const RpDims &D = rp->D;
-  rp_parallel(B, [&](size_t lo, size_t hi) {
-    std::vector<const uint64_t *> pts;
-    for (size_t b = lo; b < hi; b++) {
-      pts.assign(nr, nullptr);
-      for (size_t i = 0; i < nr; i++) pts[i] = &h_in_pt[(b * nr + i) * 8];
-      encode_points(coms_files + b * D.coms_bytes, pts.data(), nr);
-      uint8_t *pf = proof_files + b * D.proof_bytes;
-      for (size_t i = 0; i < st.fn; i++) put_field(pf + 32 * i, U256::load(&wn[(b * st.fn + i) * 4]));
-      for (size_t i = 0; i < st.fl; i++) put_field(pf + 32 * (st.fn + i), U256::load(&wl[(b * st.fl + i) * 4]));
-      pts.assign(2 + 2 * k, nullptr);
-      pts[0] = &c_bl[8 * b]; pts[1] = &c_d[8 * b];
-      for (size_t j = 0; j < 2 * k; j++) pts[2 + j] = &resp[(b * k) * 16 + 8 * j];
-      encode_points(pf + 32 * (st.fn + st.fl), pts.data(), 2 + 2 * k);
-    }
-  });
-  lap("encode (host)");
-  return BPPP_OK;
-}
