@@ -290,13 +290,13 @@ __global__ void __launch_bounds__(128) k_rp_hash(RpDims D, uint32_t batch, uint3
 //   the argument's public opening (:215-219): scalar t^2 sc, norm vector t p_i (zero beyond the live positions), linear weights
 //   [0, r t] (setupBRP's psv, :151-152), and the initCom scalars of TranscriptBRP (:107-110) in commitment order blCom : dCom : nComs =
 //   1, t, 2 t^2 inputCoeffs (:127-129).  q0 = q^2 (NL) or -q^2 (IP) as qPowers' has it.
-__global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, const uint32_t *__restrict__ pos_range, const uint32_t *__restrict__ pos_coeff,
+__global__ void __launch_bounds__(256) k_brp_public(BrpDims D, uint32_t batch, const uint32_t *__restrict__ pos_range, const uint32_t *__restrict__ pos_coeff,
                                                    const uint32_t *__restrict__ range_min, const uint32_t *__restrict__ range_flags, const uint32_t *__restrict__ net_public,
                                                    const uint32_t *__restrict__ ch, uint32_t *__restrict__ out_q, uint32_t *__restrict__ out_sp,
                                                    uint32_t *__restrict__ out_norm, uint32_t *__restrict__ out_cs, uint32_t *__restrict__ out_init) {
-  extern __shared__ uint32_t lds[];               // [nr] x^(2(j+1)), then [64] partial sums
+  extern __shared__ uint32_t lds[];               // [nr] x^(2(j+1)), then [blockDim.x] partial sums
   uint32_t *x2s = lds, *part = lds + (size_t)D.nr * 8;
-  const uint32_t b = blockIdx.x, l = threadIdx.x;
+  const uint32_t b = blockIdx.x, l = threadIdx.x, NT = blockDim.x;      // 64 .. 256 lanes per proof (a power of two)
   const uint32_t *c = ch + (size_t)b * 56;
   const fe q = fe_load(c), x = fe_load(c + 8), r = fe_load(c + 16), t = fe_load(c + 48);
   fe q0 = fe_sqr<1>(q);
@@ -306,8 +306,8 @@ __global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, co
   auto powu = [](fe base, uint32_t e) { fe acc = fe_one(); while (e) { if (e & 1u) acc = fe_mul<1>(acc, base); base = fe_sqr<1>(base); e >>= 1; } return acc; };
   {
     fe xj = powu(xx, l + 1);
-    const fe step = powu(xx, 64);
-    for (uint32_t j = l; j < D.nr; j += 64) { for (int k = 0; k < 8; k++) x2s[j * 8 + k] = xj.v[k]; xj = fe_mul<1>(xj, step); }
+    const fe step = powu(xx, NT);
+    for (uint32_t j = l; j < D.nr; j += NT) { for (int k = 0; k < 8; k++) x2s[j * 8 + k] = xj.v[k]; xj = fe_mul<1>(xj, step); }
   }
   __syncthreads();
   auto x2 = [&](uint32_t j) { fe v; for (int k = 0; k < 8; k++) v.v[k] = x2s[j * 8 + k]; return v; };
@@ -317,13 +317,13 @@ __global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, co
     for (int i = 0; i < 8; i++) half.v[i] = (tt.v[i] >> 1) | (i < 7 ? tt.v[i + 1] << 31 : carry << 31); }
   fe acc = fe_zero();
   {
-    // the per-position part in 10 x 26-bit limbs (fr26.hip.h: 413 instructions per multiplication against 785): nlen / 64 positions per lane,
+    // the per-position part in 10 x 26-bit limbs (fr26.hip.h: 413 instructions per multiplication against 785): nlen / NT positions per lane,
     // seven multiplications each — all of this kernel's time at the 64 x 64-bit shape (4096 positions)
     auto powr = [](fr base, uint32_t e) { fr a = fr_one(); while (e) { if (e & 1u) a = fr_mul(a, base); base = fr_sqr(base); e >>= 1; } return a; };
     const fr q0r = fr_from_fe(q0), q0ir = fr_from_fe(q0i), tr_ = fr_from_fe(t), halfr = fr_from_fe(half);
     fr qp = powr(q0r, l + 1), qi = powr(q0ir, l + 1), accr = fr_zero();
-    const fr qs = powr(q0r, 64), qis = powr(q0ir, 64);
-    for (uint32_t i = l; i < D.nlen; i += 64) {
+    const fr qs = powr(q0r, NT), qis = powr(q0ir, NT);
+    for (uint32_t i = l; i < D.nlen; i += NT) {
       fr p = fr_zero();
       if (i < D.nlive) {
         p = fr_sub<1>(fr_mul(fr_mul(fr_from_fe(x2(pos_range[i])), fr_load(pos_coeff + (size_t)i * 8)), qi), halfr);     // magnitude 3
@@ -337,13 +337,13 @@ __global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, co
   }
   // z = -2 (net' + sum_j min_j x^(2(j+1)))  (assumed ranges contribute no minimum, :91)
   fe z = fe_zero();
-  for (uint32_t j = l; j < D.nr; j += 64)
+  for (uint32_t j = l; j < D.nr; j += NT)
     if (!(range_flags[j] & 2u)) z = fe_add<1>(z, fe_mul<1>(fe_load(range_min + (size_t)j * 8), x2(j)));
   if (l == 0 && D.conserve) z = fe_sub<1>(z, fe_mul<1>(x, fe_load(net_public)));
   acc = fe_sub<1>(acc, fe_dbl<1>(z));
   for (int k = 0; k < 8; k++) part[l * 8 + k] = acc.v[k];
   __syncthreads();
-  for (int d = 32; d >= 1; d >>= 1) {
+  for (int d = (int)NT >> 1; d >= 1; d >>= 1) {
     if ((int)l < d) {
       fe a, o;
       for (int k = 0; k < 8; k++) { a.v[k] = part[l * 8 + k]; o.v[k] = part[(l + d) * 8 + k]; }
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64) k_brp_public(BrpDims D, uint32_t batch, co
     fe_store(out_init + ((size_t)b * (2 + D.nr) + 1) * 8, t);
   }
   const fe two_t2 = fe_dbl<1>(t2);
-  for (uint32_t j = l; j < D.nr; j += 64) {
+  for (uint32_t j = l; j < D.nr; j += NT) {
     const uint32_t fl = range_flags[j];            // bit 0: output, bit 1: assumed
     fe ic = (fl & 2u) ? fe_zero() : x2(j);
     if (D.conserve) ic = (fl & 1u) ? fe_sub<1>(ic, x) : fe_add<1>(ic, x);
@@ -479,9 +479,15 @@ namespace bppp {
 int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint32_t *q, uint32_t *sp, uint32_t *pub_norm, uint32_t *pub_lin_c, uint32_t *init_sc) {
   bppp_ctx *ctx = rp->ctx;
   const bppp_brp_tabs *t = rp->btabs;
-  const size_t lds = ((size_t)t->D.nr + 64) * 32;
+  // lanes per proof: a lane pays ~60 multiplications for its first powers of q0 and q0^-1 whatever its share of the positions, and 1024 proofs at one
+  // wavefront each leave the SIMDs at one wavefront (VALU-busy 0.44 at the 64 x 64-bit shape, profiles/r04_pmc_binary_verify_per_kernel.csv): long
+  // norm vectors take 2 or 4 wavefronts per proof while the batch does not fill the chip by itself
+  unsigned nt = 64;
+  // (measured, 64 x 64-bit shape: 1024 proofs 2.43 / 2.15 / 2.25 ms per verify call at 64 / 128 / 256 lanes, 4096 proofs 4.90 / 5.23 / 5.38 ms)
+  while (nt < 256 && (size_t)t->D.nlen >= (size_t)nt * 16 && batch * (nt / 64) < 2048) nt <<= 1;
+  const size_t lds = ((size_t)t->D.nr + nt) * 32;
   if (lds > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_brp_public, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_brp_public<<<dim3((unsigned)batch), dim3(64), lds, ctx->stream>>>(t->D, (uint32_t)batch, t->pos_range, t->pos_coeff, t->range_min, t->range_flags, t->net_public, ch, q, sp,
+  k_brp_public<<<dim3((unsigned)batch), dim3(nt), lds, ctx->stream>>>(t->D, (uint32_t)batch, t->pos_range, t->pos_coeff, t->range_min, t->range_flags, t->net_public, ch, q, sp,
                                                                      pub_norm, pub_lin_c, init_sc);
   BPPP_HIP(ctx, hipGetLastError());
   return BPPP_OK;
