@@ -143,6 +143,60 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     else aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
   }
 }
+// THOUSANDS of instances of a FEW DOZEN terms (the inner-product prover's rows at the examples/64bit shape: 1 + 6 + 16 = 23 terms): with one wavefront per
+// instance 23 of 64 lanes work and the epilogue — a 6-level shuffle tree and one inversion — costs as much as the 17 additions of the walk.  Here LPI lanes
+// serve an instance (64 / LPI instances per wavefront), each lane walks ceil(nterms / LPI) terms, a log2(LPI)-level segmented tree joins them and the
+// 64 / LPI inversions of a wavefront run side by side.
+template <int LPI>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_comb_msm_packed(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
+                                                                                                  const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst,
+                                                                                                  uint32_t *__restrict__ out) {
+  const uint32_t sub = threadIdx.x % LPI, inst = blockIdx.x * (64 / LPI) + threadIdx.x / LPI;
+  const bool active = inst < ninst;
+  const uint32_t mask = (1u << c) - 1u;
+  const uint32_t *sc = scalars + (size_t)(active ? inst : 0) * nterms * 8;
+  xyzz acc = xyzz_inf();
+  CombRaw pend; pend.a = pend.b = pend.c = pend.d = make_uint4(0, 0, 0, 0);
+  bool pend_ok = false, pend_neg = false;
+  for (uint32_t i = sub; i < nterms; i += LPI) {
+    fe s = fe_load(sc + (size_t)i * 8);
+    if (!active) s = fe_zero();
+    const bool nz = !fe_is_zero(s);
+    fe t, tmp;
+    raw_sub(t, fr_modulus(), s);
+    const bool neg = raw_sub(tmp, t, s) != 0;                    // reduceScalar (Commitment.hs:276-279)
+    uint32_t sp[9];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
+    sp[8] = (uint32_t)cy + K.k[8];
+    const uint32_t *ti = tab + (size_t)i * D * 16;
+#pragma unroll 1
+    for (int w = 0; w < W; w++) {
+      const int d = (int)(sp[0] & mask) - (int)D;
+#pragma unroll
+      for (int q = 0; q < 8; q++) sp[q] = (sp[q] >> c) | (sp[q + 1] << (32 - c));
+      sp[8] >>= c;
+      CombRaw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_uint4(0, 0, 0, 0);
+      const bool ok = nz && d != 0, nneg = (d < 0) != neg;
+      if (ok) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint4 *e = (const uint4 *)(ti + ((size_t)w * T * D + (mag - 1)) * 16);
+        nxt.a = e[0]; nxt.b = e[1]; nxt.c = e[2]; nxt.d = e[3];
+      }
+      if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+      pend = nxt; pend_ok = ok; pend_neg = nneg;
+    }
+  }
+  if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+#pragma unroll
+  for (int dd = LPI / 2; dd >= 1; dd >>= 1) {
+    xyzz o = xyzz_shfl_down(acc, dd);
+    if ((int)sub + dd < LPI) xyzz_add(acc, o);
+  }
+  if (sub == 0 && active) aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
+}
+
 // MANY instances of a FEW terms each (the prover's input commitments v g + ty H0 + bl H1: batch x #values instances over the first
 // three registered points): one LANE per instance walks its terms and digits; zero scalars and zero digits cost nothing
 __global__ void __launch_bounds__(64) k_comb_lanes(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
@@ -245,6 +299,15 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   if (!ninst) return BPPP_OK;
   CombK K; memset(&K, 0, sizeof K);
   for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
+  // a few dozen terms per instance, thousands of instances: several instances per wavefront (k_comb_msm_packed)
+  if (nterms <= 48 && ninst >= 512 && !t->ctx->tune.comb_no_packed) {
+    const unsigned lpi = nterms <= 24 ? 8 : 16;
+    const unsigned grid_p = (unsigned)((ninst * lpi + 63) / 64);
+    if (lpi == 8) k_comb_msm_packed<8><<<dim3(grid_p), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, d_out_aff);
+    else k_comb_msm_packed<16><<<dim3(grid_p), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, d_out_aff);
+    if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_msm: launch failed");
+    return BPPP_OK;
+  }
   // wavefronts per SIMD the register allocation aims at: 2 (225 VGPRs) measured 2 % ahead of 3 (168); 4 (128) spills and is 2.4 x slower
   const int wpe = t->ctx->tune.comb_wpe ? t->ctx->tune.comb_wpe : 2;
   // few instances: several wavefronts per instance (up to one per group of 64 terms), so that a launch is ~1024 wavefronts wide and

@@ -15,8 +15,9 @@
 //   k_ipb_expand    the two rows of 1 + linLen + nrmLen scalars over the original basis [g | H | G]
 //   k_ipb_collapse  makeEs e = (1/e, e) (:68), s += sL / e + e sR, the vector folds (:86-101, :162-170), the coefficient products
 //   k_ipb_witness   getWitness: Norm (nx x - ny y, nx x + ny y) (:222-223), Linear x (:160)
-// One workgroup per proof throughout (a proof's vectors are short: nrmLen / 2 and linLen entries); Fr in 10 x 26-bit limbs (fr26.hip.h),
-// canonical 8 x 32 values in memory.
+// `lp` lanes per proof in the per-proof kernels — the smallest power of two >= the longer of the two vectors, at least 8 — and 256 / lp proofs per
+// workgroup (a single-value proof has 8 pairs and 6 linear entries: a workgroup per proof left 250 lanes idle); Fr in 10 x 26-bit limbs
+// (fr26.hip.h), canonical 8 x 32 values in memory.
 #include <algorithm>
 #include <vector>
 #include "comb.hpp"
@@ -36,31 +37,34 @@ BPPP_DI fe ipb_half() {                                   // (n + 1) / 2
   for (int i = 0; i < 8; i++) h.v[i] = (tt.v[i] >> 1) | (i < 7 ? tt.v[i + 1] << 31 : carry << 31);
   return h;
 }
-// sum of `cnt` (<= 2) values per thread over the workgroup; result valid on thread 0.  lds: blockDim.x * 2 * 8 words
-BPPP_DI void ipb_block_sum2(fe v[2], uint32_t *lds) {
-  const int t = threadIdx.x;
-  for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) lds[(t * 2 + k) * 8 + i] = v[k].v[i];
+// sum of two values per lane over the `lp` lanes of a proof (lp a power of two dividing blockDim.x; the proofs of a workgroup run the same
+// steps); result valid on lane 0 of the proof.  lds: blockDim.x * 2 * 8 words
+BPPP_DI void ipb_seg_sum2(fe v[2], uint32_t *lds, uint32_t lp) {
+  const uint32_t tid = threadIdx.x, t = tid % lp;
+  for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) lds[(tid * 2 + k) * 8 + i] = v[k].v[i];
   __syncthreads();
-  for (int d = (int)blockDim.x >> 1; d >= 1; d >>= 1) {
+  for (uint32_t d = lp >> 1; d >= 1; d >>= 1) {
     if (t < d)
       for (int k = 0; k < 2; k++) {
         fe x, y;
-        for (int i = 0; i < 8; i++) { x.v[i] = lds[(t * 2 + k) * 8 + i]; y.v[i] = lds[((t + d) * 2 + k) * 8 + i]; }
+        for (int i = 0; i < 8; i++) { x.v[i] = lds[(tid * 2 + k) * 8 + i]; y.v[i] = lds[((tid + d) * 2 + k) * 8 + i]; }
         x = fe_add<1>(x, y);
-        for (int i = 0; i < 8; i++) lds[(t * 2 + k) * 8 + i] = x.v[i];
+        for (int i = 0; i < 8; i++) lds[(tid * 2 + k) * 8 + i] = x.v[i];
       }
     __syncthreads();
   }
-  if (t == 0) for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) v[k].v[i] = lds[k * 8 + i];
+  if (t == 0) for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) v[k].v[i] = lds[(tid * 2 + k) * 8 + i];
 }
 
-struct IpbDims { uint32_t nlen, llen, m0, xs, ls, T; };     // m0 = ceil(nlen / 2) pairs; xs, ls: per-proof strides of the X / Y and LC / LX buffers
+struct IpbDims { uint32_t nlen, llen, m0, xs, ls, T, batch, lp; };     // m0 = ceil(nlen / 2) pairs; xs, ls: per-proof strides of the X / Y and LC / LX buffers;
+// lp: lanes per proof in the per-proof kernels (a power of two, 8 .. 256; blockDim.x / lp proofs per workgroup: single-value proofs have 8 pairs and 6 linear entries)
 
 __global__ void __launch_bounds__(256) k_ipb_init(IpbDims D, const uint32_t *__restrict__ psv, const uint32_t *__restrict__ rr, const uint32_t *__restrict__ nrm,
                                                   const uint32_t *__restrict__ lc, const uint32_t *__restrict__ lx, uint32_t *__restrict__ X, uint32_t *__restrict__ Y,
                                                   uint32_t *__restrict__ LC, uint32_t *__restrict__ LX, uint32_t *__restrict__ cx, uint32_t *__restrict__ cy,
                                                   uint32_t *__restrict__ cl, uint32_t *__restrict__ stt) {
-  const uint32_t b = blockIdx.x, t = threadIdx.x, bs = blockDim.x;
+  const uint32_t b = blockIdx.x * (blockDim.x / D.lp) + threadIdx.x / D.lp, t = threadIdx.x % D.lp, bs = D.lp;
+  if (b >= D.batch) return;
   const fe r8 = fe_load(rr + (size_t)b * 8);
   const fe ti8 = fe_modinv<1>(fe_dbl<1>(r8));             // 1 / (2r): every lane of the workgroup walks the same division steps
   const fr ti = fr_from_fe(ti8), half = fr_from_fe(ipb_half());
@@ -93,7 +97,9 @@ __global__ void __launch_bounds__(256) k_ipb_round(IpbDims D, uint32_t mc, uint3
                                                    const uint32_t *__restrict__ Y, const uint32_t *__restrict__ LC, const uint32_t *__restrict__ LX,
                                                    uint32_t *__restrict__ stt, uint32_t *__restrict__ og, uint32_t *__restrict__ ol) {
   __shared__ uint32_t lds[256 * 2 * 8];
-  const uint32_t b = blockIdx.x, t = threadIdx.x, bs = blockDim.x;
+  const uint32_t b_raw = blockIdx.x * (blockDim.x / D.lp) + threadIdx.x / D.lp, t = threadIdx.x % D.lp, bs = D.lp;
+  const bool live = b_raw < D.batch;                          // a group past the end recomputes the last proof (it must keep up with the barriers) and stores nothing
+  const uint32_t b = live ? b_raw : D.batch - 1;
   uint32_t *S = stt + (size_t)b * IPB_ST * 8;
   const fr q = fr_load(S + IPB_Q * 8), qi = fr_load(S + IPB_QI * 8), nx = fr_load(S + IPB_NX * 8);
   const fr q2 = fr_sqr(q);
@@ -105,7 +111,7 @@ __global__ void __launch_bounds__(256) k_ipb_round(IpbDims D, uint32_t mc, uint3
   if (np) {
     fr w = ipb_pow(q2, t);
     const fr step = ipb_pow(q2, bs);
-    for (uint32_t p = t; p < np; p += bs) {
+    for (uint32_t p = t; p < np && live; p += bs) {
       const bool has = 2 * p + 1 < mc;
       const fe xl8 = fe_load(xb + (size_t)(2 * p) * 8), yl8 = fe_load(yb + (size_t)(2 * p) * 8);
       const fe xr8 = has ? fe_load(xb + (size_t)(2 * p + 1) * 8) : fe_zero(), yr8 = has ? fe_load(yb + (size_t)(2 * p + 1) * 8) : fe_zero();
@@ -120,7 +126,7 @@ __global__ void __launch_bounds__(256) k_ipb_round(IpbDims D, uint32_t mc, uint3
     }
   }
   fr sl = fr_zero(), sr = fr_zero();
-  for (uint32_t p = t; p < lp; p += bs) {
+  for (uint32_t p = t; p < lp && live; p += bs) {
     const bool has = 2 * p + 1 < lcn;
     const fe xl8 = fe_load(lb + (size_t)(2 * p) * 8), xr8 = has ? fe_load(lb + (size_t)(2 * p + 1) * 8) : fe_zero();
     const fr cl_ = fr_load(cb + (size_t)(2 * p) * 8), cr = has ? fr_load(cb + (size_t)(2 * p + 1) * 8) : fr_zero();
@@ -129,11 +135,11 @@ __global__ void __launch_bounds__(256) k_ipb_round(IpbDims D, uint32_t mc, uint3
     fe_store(rl + (size_t)(2 * p) * 8, xr8); fe_store(rl + (size_t)(2 * p + 1) * 8, fe_zero());
   }
   fe v[2] = {fr_to_fe(l), fr_to_fe(r_)};
-  ipb_block_sum2(v, lds);
+  ipb_seg_sum2(v, lds, D.lp);
   __syncthreads();
   fe u[2] = {fr_to_fe(sl), fr_to_fe(sr)};
-  ipb_block_sum2(u, lds);
-  if (t == 0) {
+  ipb_seg_sum2(u, lds, D.lp);
+  if (t == 0 && live) {
     const fr kk = fr_mul_int(nx, 4);                      // s nx ny with s = 4 (makeNorm), ny = 1 in the unscaled recursion
     fr sL = fr_from_fe(u[0]), sR = fr_from_fe(u[1]);
     if (mc) {
@@ -178,7 +184,9 @@ __global__ void __launch_bounds__(256) k_ipb_collapse(IpbDims D, uint32_t round,
                                                       const uint32_t *__restrict__ LX, uint32_t *__restrict__ Xo, uint32_t *__restrict__ Yo, uint32_t *__restrict__ LCo,
                                                       uint32_t *__restrict__ LXo, uint32_t *__restrict__ cx, uint32_t *__restrict__ cy, uint32_t *__restrict__ cl,
                                                       uint32_t *__restrict__ flag) {
-  const uint32_t b = blockIdx.x, t = threadIdx.x, bs = blockDim.x;
+  const uint32_t b_raw = blockIdx.x * (blockDim.x / D.lp) + threadIdx.x / D.lp, t = threadIdx.x % D.lp, bs = D.lp;
+  const bool live = b_raw < D.batch;
+  const uint32_t b = live ? b_raw : D.batch - 1;
   uint32_t *S = stt + (size_t)b * IPB_ST * 8;
   const fe e8 = fe_load(es + (size_t)b * 8);
   const fe ei8 = fe_modinv<1>(e8);                        // 0 -> 0; a zero challenge fails the batch (flag), as the host version does
@@ -187,13 +195,13 @@ __global__ void __launch_bounds__(256) k_ipb_collapse(IpbDims D, uint32_t round,
   const fr eq = fr_mul(e, q), rhox = fr_mul(qi, ei);
   const fe s8 = fe_load(S + IPB_S * 8), sl8 = fe_load(S + IPB_SL * 8), sr8 = fe_load(S + IPB_SR * 8), nx8 = fe_load(S + IPB_NX * 8);
   __syncthreads();                                         // every lane holds the old state before lane 0 advances it
-  if (t == 0) {
+  if (t == 0 && live) {
     if (fe_is_zero(e8)) atomicOr(flag, 1u);
     fr_store(S + IPB_S * 8, fr_add(fr_from_fe(s8), fr_add(fr_mul(ei, fr_from_fe(sl8)), fr_mul(e, fr_from_fe(sr8)))));
     if (mc) { fr_store(S + IPB_NX * 8, fr_mul(fr_from_fe(nx8), qi)); fr_store(S + IPB_Q * 8, fr_sqr(q)); fr_store(S + IPB_QI * 8, fr_sqr(qi)); }
   }
   const uint32_t *xb = X + (size_t)b * D.xs * 8, *yb = Y + (size_t)b * D.xs * 8;
-  for (uint32_t p = t; 2 * p < mc; p += bs) {
+  for (uint32_t p = t; 2 * p < mc && live; p += bs) {
     fr nx = fr_load(xb + (size_t)(2 * p) * 8), ny = fr_load(yb + (size_t)(2 * p) * 8);
     if (2 * p + 1 < mc) {
       nx = fr_add(nx, fr_mul(eq, fr_load(xb + (size_t)(2 * p + 1) * 8)));
@@ -201,14 +209,14 @@ __global__ void __launch_bounds__(256) k_ipb_collapse(IpbDims D, uint32_t round,
     }
     fr_store(Xo + ((size_t)b * D.xs + p) * 8, nx); fr_store(Yo + ((size_t)b * D.xs + p) * 8, ny);
   }
-  if (mc)
+  if (mc && live)
     for (uint32_t i = t; i < D.m0; i += bs)
       if ((i >> round) & 1u) {
         uint32_t *a = cx + ((size_t)b * D.m0 + i) * 8, *c = cy + ((size_t)b * D.m0 + i) * 8;
         fr_store(a, fr_mul(fr_load(a), rhox)); fr_store(c, fr_mul(fr_load(c), e));
       }
   const uint32_t *cb = LC + (size_t)b * D.ls * 8, *lb = LX + (size_t)b * D.ls * 8;
-  for (uint32_t p = t; 2 * p < lcn; p += bs) {
+  for (uint32_t p = t; 2 * p < lcn && live; p += bs) {
     fr nc = fr_load(cb + (size_t)(2 * p) * 8), nl = fr_load(lb + (size_t)(2 * p) * 8);
     if (2 * p + 1 < lcn) {
       nc = fr_add(nc, fr_mul(ei, fr_load(cb + (size_t)(2 * p + 1) * 8)));
@@ -216,7 +224,7 @@ __global__ void __launch_bounds__(256) k_ipb_collapse(IpbDims D, uint32_t round,
     }
     fr_store(LCo + ((size_t)b * D.ls + p) * 8, nc); fr_store(LXo + ((size_t)b * D.ls + p) * 8, nl);
   }
-  if (lcn)
+  if (lcn && live)
     for (uint32_t i = t; i < D.llen; i += bs)
       if ((i >> round) & 1u) { uint32_t *c = cl + ((size_t)b * D.llen + i) * 8; fr_store(c, fr_mul(fr_load(c), ei)); }
 }
@@ -252,7 +260,11 @@ int ipb_prove_stream(bppp_ctx *ctx, const CombTable *comb, RppTranscript &tr, si
   if (!ctx || !comb || !B || nlen + llen == 0 || comb->T != 1 + llen + nlen || work_bytes < ipb_work_bytes(B, nlen, llen)) return BPPP_ERR_ARG;
   hipStream_t st = ctx->stream;
   const size_t m0 = (nlen + 1) / 2, xs = ev(m0) + 2, ls = ev(llen) + 2, T = 1 + llen + nlen;
-  IpbDims D{(uint32_t)nlen, (uint32_t)llen, (uint32_t)m0, (uint32_t)xs, (uint32_t)ls, (uint32_t)T};
+  // lanes per proof: the smallest power of two >= the longer vector (at least 8), 256 / lp proofs per 256-lane workgroup
+  uint32_t lp = 8;
+  while (lp < 256 && lp < std::max(m0, llen)) lp <<= 1;
+  IpbDims D{(uint32_t)nlen, (uint32_t)llen, (uint32_t)m0, (uint32_t)xs, (uint32_t)ls, (uint32_t)T, (uint32_t)B, lp};
+  const unsigned pgrid = (unsigned)((B * lp + 255) / 256);   // workgroups of the per-proof kernels
   Carver cv(work, work_bytes);
   uint32_t *X[2], *Y[2], *LC[2], *LX[2];
   for (int i = 0; i < 2; i++) { X[i] = cv.take<uint32_t>(B * xs * 8); Y[i] = cv.take<uint32_t>(B * xs * 8); LC[i] = cv.take<uint32_t>(B * ls * 8); LX[i] = cv.take<uint32_t>(B * ls * 8); }
@@ -260,21 +272,20 @@ int ipb_prove_stream(bppp_ctx *ctx, const CombTable *comb, RppTranscript &tr, si
   uint32_t *stt = cv.take<uint32_t>(B * IPB_ST * 8), *og = cv.take<uint32_t>(B * 4 * ev(m0) * 8 + 8), *ol = cv.take<uint32_t>(B * 2 * ev(llen) * 8 + 8);
   uint32_t *full = cv.take<uint32_t>(2 * B * T * 8), *cscratch = cv.take<uint32_t>(comb_scratch_bytes(2 * B) / 4 + 16), *flag = cv.take<uint32_t>(16);
   BPPP_HIP(ctx, hipMemsetAsync(flag, 0, 4, st));
-  auto threads_for = [](size_t n) { unsigned t = 64; while (t < 256 && t < n) t <<= 1; return t; };
-  k_ipb_init<<<dim3((unsigned)B), dim3(threads_for(std::max(m0, llen))), 0, st>>>(D, d_psv, d_rr, d_nrm, d_lc, d_lx, X[0], Y[0], LC[0], LX[0], cx, cy, cl, stt);
+  k_ipb_init<<<dim3(pgrid), dim3(256), 0, st>>>(D, d_psv, d_rr, d_nrm, d_lc, d_lx, X[0], Y[0], LC[0], LX[0], cx, cy, cl, stt);
   BPPP_HIP(ctx, hipGetLastError());
   size_t mc = m0, lcn = llen;
   int cur = 0;
   for (size_t round = 0; round < k; round++) {
-    const size_t me = ev(mc), le = ev(lcn), np = std::max((mc + 1) / 2, (lcn + 1) / 2);
-    k_ipb_round<<<dim3((unsigned)B), dim3(threads_for(np)), 0, st>>>(D, (uint32_t)mc, (uint32_t)lcn, (uint32_t)me, (uint32_t)le, X[cur], Y[cur], LC[cur], LX[cur], stt, og, ol);
+    const size_t me = ev(mc), le = ev(lcn);
+    k_ipb_round<<<dim3(pgrid), dim3(256), 0, st>>>(D, (uint32_t)mc, (uint32_t)lcn, (uint32_t)me, (uint32_t)le, X[cur], Y[cur], LC[cur], LX[cur], stt, og, ol);
     k_ipb_expand<<<dim3((unsigned)((T + 255) / 256), (unsigned)(2 * B)), dim3(256), 0, st>>>(D, (uint32_t)round, (uint32_t)me, (uint32_t)le, stt, og, ol, cx, cy, cl, full);
     BPPP_HIP(ctx, hipGetLastError());
     uint32_t *lr = d_resp + round * B * 32;
     int rc = comb_msm(comb, full, 2 * B, lr, st, false, 0, cscratch, comb_scratch_bytes(2 * B));
     if (rc) return fail(ctx, rc, bppp_last_error(comb->ctx));
     rc = tr.call(lr, first_call + round); if (rc) return rc;
-    k_ipb_collapse<<<dim3((unsigned)B), dim3(threads_for(std::max(mc, lcn))), 0, st>>>(D, (uint32_t)round, (uint32_t)mc, (uint32_t)lcn, tr.es, stt, X[cur], Y[cur], LC[cur],
+    k_ipb_collapse<<<dim3(pgrid), dim3(256), 0, st>>>(D, (uint32_t)round, (uint32_t)mc, (uint32_t)lcn, tr.es, stt, X[cur], Y[cur], LC[cur],
                                                                                         LX[cur], X[1 - cur], Y[1 - cur], LC[1 - cur], LX[1 - cur], cx, cy, cl, flag);
     BPPP_HIP(ctx, hipGetLastError());
     mc = (mc + 1) / 2; lcn = (lcn + 1) / 2; cur = 1 - cur;
