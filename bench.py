@@ -116,7 +116,7 @@ def stage_rows(tab, top: int = 8):
              "wait_inst_frac": v.get("wait_inst_frac"), "valu_busy_est": v.get("valu_busy_est")} for k, v in rows]
 
 
-def live_msm_traffic(log2n: int, timeout_s: float = 150.0):
+def live_msm_traffic(log2n: int, timeout_s: float = 90.0):
     """HBM bytes of one k_acc_points launch measured IN THIS RUN: two child processes of this script under rocprofv3 --pmc (FETCH_SIZE, then
     WRITE_SIZE: separate passes, counters only, the program directly after `--`), headline leg only.  gfx950 corrections as the guide's HBM
     section prescribes: both counters in KB, FETCH_SIZE counts a 128-B request as 64 B (x2).  Returns (bytes, source) or (None, reason)."""
