@@ -318,8 +318,13 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   const uint32_t groups = (uint32_t)((nterms + 63) / 64);
   // (round 4: also a few thousand LONG instances — the binary prover's 2 x 1024 rows of 4099 terms are exactly one wavefront per slot of the
   // chip, the X rows twice as long as the R rows: the launch then lasts as long as an X row on a half-idle SIMD.  Aim at ~8192 wavefronts.)
-  if (d_scratch && ninst < COMB_SPLIT_BELOW && groups > 1) {
-    tparts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((COMB_SPLIT_BELOW + ninst - 1) / ninst));
+  // (the wide target only for long instances, >= 32 groups of 64 terms: a 774-term row walks 13 terms per lane, and splitting the
+  // 4096 rows of a half-batch in two costs a join launch for nothing; the round 1-3 rule — about 1024 wavefronts — serves the rest)
+  // (measured, norm-linear prover: 4096 / 2048 / 1024 proofs 90.3 / 54.5 / 36.3 ms with the wide target for every shape, 84.6 / 49.4 / 32.9 ms with it for
+  // long instances only)
+  const size_t target = groups >= 32 ? COMB_SPLIT_BELOW : 1024;
+  if (d_scratch && ninst < target && groups > 1) {
+    tparts = std::min<uint32_t>(std::min<uint32_t>(groups, 64u), (uint32_t)((target + ninst - 1) / ninst));
     while (tparts > 1 && (size_t)ninst * tparts * XYZZ_WORDS * 4 > scratch_bytes) tparts--;
     if (tparts == groups && !t->ctx->tune.comb_no_wsplit) {
       wsplit = std::min<uint32_t>(std::min<uint32_t>(64u / tparts, 4u), (uint32_t)(1024 / std::max<size_t>(1, ninst * tparts)));
