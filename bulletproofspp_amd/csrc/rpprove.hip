@@ -514,9 +514,9 @@ static int prove_batch_one(bppp_rp *rp, size_t batch, const uint64_t *amounts, c
   const Setup &st = rp->st;
   uint32_t max_base = 0;
   for (const RangeData &rd : st.rds) max_base = std::max(max_base, rd.base);
-  // the device algebra looks digits up in a 256-entry table of reciprocals; wider bases (and BPPP_RP_HOST_ALGEBRA=1, kept for
-  // comparison) take the host-algebra path: same bytes out
-  if (max_base > 256 || rp->opt.host_algebra || (st.flavour && !rp->comb)) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
+  // the device algebra looks digits up in a per-proof table of reciprocals held in LDS (256 entries, up to 2048 for wider digit bases); bases beyond
+  // that (and BPPP_RP_HOST_ALGEBRA=1, kept for comparison) take the host-algebra path: same bytes out
+  if (max_base > 2048 || (max_base > 256 && st.rds.size() > 256) || rp->opt.host_algebra || (st.flavour && !rp->comb)) return prove_batch_host(rp, batch, amounts, types, blinds, rand_prefix, prefix_len, coms_files, proof_files, index_base);
   hipSetDevice(ctx->device);
   const size_t B = batch, nr = st.rds.size(), nlen = st.nlen, llen = st.llen, k = st.rounds, T = 1 + llen + nlen;
   if (nr >= (1u << 16)) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges");

@@ -116,7 +116,7 @@ BPPP_DI void wave_batch_invert(uint32_t *vals, uint32_t *pre, uint32_t *sa, uint
   __syncthreads();
 }
 
-static constexpr uint32_t INV_E = 0, INV_R0 = 1, INV_DIG = 2;     // layout of the inverse table: e, r0, e + s (s < 256), e + type_i
+static constexpr uint32_t INV_E = 0, INV_R0 = 1, INV_DIG = 2;     // layout of the inverse table: e, r0, e + s (s < D.maxb), e + type_i
 
 // ------------------------------------------------------------------------------------------------ phase 2
 __global__ void __launch_bounds__(64) k_rpp_phase2(PDims D, TrrpDims TD, const uint32_t *__restrict__ pos_kind, const uint32_t *__restrict__ pos_range,
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) k_rpp_phase2(PDims D, TrrpDims TD, const u
                                                    const uint32_t *__restrict__ ch, uint32_t *__restrict__ row_r, uint32_t *__restrict__ ccbuf,
                                                    uint32_t *__restrict__ invtab) {
   extern __shared__ uint32_t lds[];
-  const uint32_t t = threadIdx.x, b = blockIdx.x, m = INV_DIG + 256 + D.nr;
+  const uint32_t t = threadIdx.x, b = blockIdx.x, m = INV_DIG + D.maxb + D.nr;
   uint32_t *vals = lds, *pre = vals + (size_t)m * 8, *sa = pre + (size_t)m * 8, *sb = sa + 64 * 8, *bm = sb + 64 * 8;   // bm: [TRRP_MAX_SLOTS]
   const uint32_t *c = ch + (size_t)b * 56;
   const fe e = fe_load(c), x = fe_load(c + 8), r0 = fe_load(c + 16);
@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(64) k_rpp_phase2(PDims D, TrrpDims TD, const u
     fe a;
     if (i == INV_E) a = e;
     else if (i == INV_R0) a = r0;
-    else if (i < INV_DIG + 256) a = fe_add<1>(e, pf_small(i - INV_DIG));
-    else a = fe_add<1>(e, fe_load(in_sc + ((size_t)b * D.nr + (i - INV_DIG - 256)) * 24 + 8));      // e + type of input i
+    else if (i < INV_DIG + D.maxb) a = fe_add<1>(e, pf_small(i - INV_DIG));
+    else a = fe_add<1>(e, fe_load(in_sc + ((size_t)b * D.nr + (i - INV_DIG - D.maxb)) * 24 + 8));      // e + type of input i
     lput(vals, i, a);
   }
   __syncthreads();
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) k_rpp_phase2(PDims D, TrrpDims TD, const u
     fe rr, cc = fe_zero();
     if (kind == K_TYPING) {
       const uint32_t rg = pos_range[i];
-      rr = pfm(fe_load(in_sc + ((size_t)b * D.nr + rg) * 24), lget(vals, INV_DIG + 256 + rg));     // v / (e + t)
+      rr = pfm(fe_load(in_sc + ((size_t)b * D.nr + rg) * 24), lget(vals, INV_DIG + D.maxb + rg));     // v / (e + t)
     } else {
       rr = lget(vals, INV_DIG + dig[(size_t)b * D.nlen + i]);                                      // 1 / (e + d)
       const uint32_t sy = pos_sym[i];
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) k_rpp_phase2(PDims D, TrrpDims TD, const u
     fe_store(row + 4 * 8, fe_load(r + 13 * 8)); fe_store(row + 5 * 8, err7); fe_store(row + 6 * 8, fe_zero());
   }
   for (uint32_t j = 6 + t; j < D.llen; j += 64) fe_store(row + (size_t)(1 + j) * 8, fe_zero());
-  for (uint32_t i = t; i < INV_DIG + 256; i += 64) fe_store(invtab + ((size_t)b * (INV_DIG + 256) + i) * 8, lget(vals, i));
+  for (uint32_t i = t; i < INV_DIG + D.maxb; i += 64) fe_store(invtab + ((size_t)b * (INV_DIG + D.maxb) + i) * 8, lget(vals, i));
 }
 
 // ------------------------------------------------------------------------------------------------ phase 3
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64) k_rpp_phase3(PDims D, TrrpDims TD, const u
   uint32_t *sa = lds, *x2 = sa + 64 * 8 * 6, *bm = x2 + (size_t)D.nr * 8, *sh = bm + TRRP_MAX_SLOTS * 8;      // sa: 6 reduction rows; sh: [4] inverses etc.
   const uint32_t *c = ch + (size_t)b * 56;
   const fe e = fe_load(c), x = fe_load(c + 8), q = fe_load(c + 24), xp = fe_load(c + 32), r1 = fe_load(c + 40);
-  const uint32_t *it = invtab + (size_t)b * (INV_DIG + 256) * 8;
+  const uint32_t *it = invtab + (size_t)b * (INV_DIG + D.maxb) * 8;
   const fe e_inv = fe_load(it + INV_E * 8), r0_inv = fe_load(it + INV_R0 * 8);
   fe q0 = pfs(q);                                     // qPowers': powers' (q^2) of the NL norm (NormArgument.hs:148),
   if (TD.flavour) q0 = fe_neg<1>(q0);                 // powers' (-q^2) of the IP one (InnerProductArgument.hs:231)
@@ -415,6 +415,8 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   const size_t B = in.batch, nr = S.rds.size(), nlen = S.nlen, llen = S.llen, k = S.rounds, T = 1 + llen + nlen;
   PDims D; D.nlen = (uint32_t)nlen; D.llen = (uint32_t)llen; D.nr = (uint32_t)nr; D.T = (uint32_t)T; D.has_types = S.has_types ? 1u : 0u;
   D.nd = (uint32_t)(14 + (llen - 5) + nlen);
+  D.maxb = 256;
+  for (const bppp_rps::RangeData &rd : S.rds) while (D.maxb < rd.base && D.maxb < 2048) D.maxb <<= 1;       // bases above 2048 take the host-algebra route (csrc/rpprove.hip)
   const bppp_trrp *tb = rp->tabs;
   const TrrpDims TD = tb->D;
   // text capacity per proof: every commitment of the final transcript (4 + nr + 2k points), right-aligned, 16 bytes of slack at the end
@@ -431,7 +433,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     dig = cv.take<uint32_t>(B * nlen); mul = cv.take<uint32_t>(B * nlen); mss = cv.take<uint32_t>(B * (llen - 6) + 1);
     rnd = cv.take<uint32_t>(B * (size_t)D.nd * 8);
     rows_dm_m = cv.take<uint32_t>(2 * B * T * 8); row_r = cv.take<uint32_t>(B * T * 8); row_bl = cv.take<uint32_t>(B * T * 8);
-    ccbuf = cv.take<uint32_t>(B * nlen * 8); invtab = cv.take<uint32_t>(B * (INV_DIG + 256) * 8); aux = cv.take<uint32_t>(B * 24);
+    ccbuf = cv.take<uint32_t>(B * nlen * 8); invtab = cv.take<uint32_t>(B * (size_t)(INV_DIG + D.maxb) * 8); aux = cv.take<uint32_t>(B * 24);
     ch = cv.take<uint32_t>(B * 56); es = cv.take<uint32_t>(B * 8); tstart = cv.take<uint32_t>(B);
     ptbuf = cv.take<uint32_t>(B * (2 + nr) * 16);
     a_s = cv.take<uint32_t>(B * 8); a_q = cv.take<uint32_t>(B * 8); a_lx = cv.take<uint32_t>(B * llen * 8); a_nx = cv.take<uint32_t>(B * nlen * 8);
@@ -467,7 +469,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   int rc = rpp_commit_inputs(rp, in_sc, B * nr, in_pt); if (rc) return rc;
   BPPP_HIP(ctx, hipMemcpyAsync(out.input_coms, in_pt, B * nr * 64, hipMemcpyDeviceToHost, st));
   if (stream_mode) {
-    const size_t lds2 = (2 * (INV_DIG + 256 + nr) + 128 + TRRP_MAX_SLOTS) * 32, lds3 = ((size_t)6 * 64 + nr + TRRP_MAX_SLOTS + 4) * 32;
+    const size_t lds2 = (2 * (INV_DIG + D.maxb + nr) + 128 + TRRP_MAX_SLOTS) * 32, lds3 = ((size_t)6 * 64 + nr + TRRP_MAX_SLOTS + 4) * 32;
     if (lds2 > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges for the device prover");
     if (lds2 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (lds3 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
@@ -526,7 +528,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     }
     rc = oracle(pts.data(), 0); if (rc) return rc;
   }
-  const size_t m2 = INV_DIG + 256 + nr;
+  const size_t m2 = INV_DIG + D.maxb + nr;
   const size_t lds2 = (2 * m2 + 128 + TRRP_MAX_SLOTS) * 32;
   if (lds2 > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges for the device prover");
   if (lds2 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

@@ -456,3 +456,26 @@ def test_native_setup_refuses_what_the_reference_missizes_and_what_is_too_large(
     hnd = C.c_void_p()
     rc = gpu.lib.bppp_rp_create(gpu.h, 0, 0, C.cast(rng, C.c_void_p), 1, None, 0, C.c_void_p(arr.ctypes.data), arr.shape[0], None, C.byref(hnd))
     assert rc != 0 and b"too large" in gpu.lib.bppp_last_error(gpu.h)
+
+
+def test_device_prover_with_a_digit_base_above_256(gpu):
+    """a shared range of base 1000 (linLen 6 + 999) next to a base-4 one: the device phases keep a 1024-entry reciprocal table per proof (round 4; bases above 256
+    took the host-algebra route before) — same bytes as the host-algebra route and as the host protocol code, and the batch verifies"""
+    rds = [RP.make_range_data(1000, 0, 10**6, True, True, False), RP.make_range_data(4, 0, 256, True, True, False)]
+    pts = O.hash_points(b"base 1000", 2 + 6 + 999 + 3 + 8 + 8)
+    st = RP.setup(RP.GpuBackend(gpu), pts, False, [], rds, "NL")
+    assert st.lin_len == 6 + 999 + 3
+    nat = RP.NativeRangeProofs(gpu, st)
+    rnd = random.Random(1000)
+    B = 4
+    inputs = [[(rnd.randrange(10**6), 0, rnd.randrange(O.N)), (rnd.randrange(256), 0, rnd.randrange(O.N))] for _ in range(B)]
+    inputs[0][0] = (999999, 0, 5); inputs[1][0] = (0, 0, 6); inputs[2][0] = (999 * 1000 + 999, 0, 7)
+    prefixes = [b"base1000 %d" % b for b in range(B)]
+    with _options(nat, comb_min=1, comb_bits=6):
+        got = nat.prove_batch(inputs, prefixes)
+        with _options(nat, host_algebra=1):
+            assert nat.prove_batch(inputs, prefixes) == got
+    proof = RP.prove(st, RP.witness(st, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0]))
+    assert got[0] == E.encode_proof(4, proof)
+    assert nat.verify_batch([c for c, _ in got], [p for _, p in got])
+    nat.close()
