@@ -128,3 +128,31 @@ def test_basis_2_14_and_lifetime(gpu, oracle_lib):
     assert bas.msm(d_s, n, 1) == [want]
     gpu.free(d_s)
     bas.close()
+
+
+def test_comb_many_short_instances(gpu, oracle_lib):
+    """Hundreds of instances of a few dozen terms (the inner-product prover's rows: 1 + 6 + 16 = 23 terms) take k_comb_msm_packed — 8 or 16 lanes per
+    instance, several instances per wavefront (csrc/comb.hip, round 4): the same points as the bucket route for 3, 23, 24, 25 and 48 terms (the lane
+    counts' boundaries), and 49 terms (one wavefront per instance again); zero rows, sparse rows, sign-boundary scalars, an infinity point in the basis."""
+    n, batch = 60, 600
+    pts, rnd = _case(n, 31)
+    bas = gpu.basis(points_to_array(pts), batch_hint=batch)
+    bas.enable_comb(window_bits=7, budget_bytes=64 << 20)
+    for n_terms in (3, 23, 24, 25, 48, 49):
+        sc = [[rnd.randrange(O.N) for _ in range(n_terms)] for _ in range(batch)]
+        sc[0] = [0] * n_terms
+        sc[1] = [s_ if i & 1 else 0 for i, s_ in enumerate(sc[1])]
+        sc[2][0], sc[2][1], sc[2][2] = O.N - 1, (O.N + 1) // 2, (O.N - 1) // 2
+        sc[batch - 1] = [1] * n_terms
+        sc[batch - 2] = [0] * (n_terms - 1) + [rnd.randrange(O.N)]               # only the last lane's last term
+        d_s = gpu.to_device(np.concatenate([scalars_to_array(r) for r in sc]))
+        d_p = gpu.to_device(points_to_array(pts[:n_terms]))
+        try:
+            got = bas.msm(d_s, n_terms, batch)
+            plain = gpu.msm_batch_device(d_s, d_p, n_terms, batch, shared_points=True)
+        finally:
+            gpu.free(d_s); gpu.free(d_p)
+        assert got == plain and got[0] is None, "comb differs from the bucket route at %d terms" % n_terms
+        for b in (1, 2, 7, batch - 2, batch - 1):
+            assert got[b] == oracle_lib.inner_product(list(zip(sc[b], pts[:n_terms])))
+    bas.close()
