@@ -156,7 +156,7 @@ int brp_device_prove(bppp_rp *rp, const BrpHostInputs &in, BrpOutputs &out) {
     p_sp = cv.take<uint32_t>(B * 8); p_norm = cv.take<uint32_t>(B * nlen * 8); p_cs = cv.take<uint32_t>(B * 16); p_init = cv.take<uint32_t>(B * (2 + nr) * 8);
     text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<uint8_t>(RppTranscript::hdr_bytes(2 + k) + 16);
     d_resp = cv.take<uint32_t>(k * B * 32 + 16); d_com = cv.take<uint32_t>(2 * B * 16 + 16);
-    cscratch = cv.take<uint32_t>(comb_scratch_bytes(B) / 4 + 16);
+    cscratch = cv.take<uint32_t>(comb_rows_scratch_bytes(B) / 4 + 16);
     if (!pass) { int rc = rpp_ensure_pwork(rp, cv.off); if (rc) return rc; }
   }
   BPPP_HIP(ctx, hipMemcpyAsync(in_sc, in.in_sc, B * nr * 96, hipMemcpyHostToDevice, st));
@@ -165,8 +165,8 @@ int brp_device_prove(bppp_rp *rp, const BrpHostInputs &in, BrpOutputs &out) {
   // the oracle calls of proveBRPM: oracle' (dCom : nComs) -> q x r (:179), oracle [blCom] -> t (:189); small batches hash on the host cores
   RppTranscript tr;
   int rc = tr.begin(rp, B, {RppCall{(uint32_t)(1 + nr), 3, 0}, RppCall{1, 1, 6}}, k, B <= rp->opt.host_oracle_prove, text, tstart, hdrs, ch, es); if (rc) return rc;
-  auto comb = [&](const uint32_t *rows, uint32_t *dst) -> int {
-    int r_ = comb_msm(rp->comb, rows, B, dst, st, false, 0, cscratch, comb_scratch_bytes(B));
+  auto comb = [&](const uint32_t *rows, uint32_t *dst, int hint) -> int {
+    int r_ = comb_msm(rp->comb, rows, B, dst, st, hint, 0, cscratch, comb_rows_scratch_bytes(B));
     return r_ ? fail(ctx, r_, bppp_last_error(rp->comb->ctx)) : BPPP_OK;
   };
   uint32_t *c_d = d_com, *c_bl = d_com + B * 16;
@@ -175,7 +175,7 @@ int brp_device_prove(bppp_rp *rp, const BrpHostInputs &in, BrpOutputs &out) {
   BPPP_HIP(ctx, hipGetLastError());
   rc = rpp_commit_inputs(rp, in_sc, B * nr, in_pt); if (rc) return rc;                 // scalarRPW' (Internal.hs:56-57): v g + bl h0
   BPPP_HIP(ctx, hipMemcpyAsync(out.input_coms, in_pt, B * nr * 64, hipMemcpyDeviceToHost, st));
-  rc = comb(row_d, c_d); if (rc) return rc;
+  rc = comb(row_d, c_d, COMB_ROWS_ANY); if (rc) return rc;                   // bits and a few blinders: most scalars are 0 or 1
   BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf, (1 + nr) * 64, c_d, 64, 64, B, hipMemcpyDeviceToDevice, st));
   BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf + 16, (1 + nr) * 64, in_pt, nr * 64, nr * 64, B, hipMemcpyDeviceToDevice, st));
   rc = tr.call(ptbuf, 0); if (rc) return rc;
@@ -184,7 +184,7 @@ int brp_device_prove(bppp_rp *rp, const BrpHostInputs &in, BrpOutputs &out) {
   if (lds2 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_brpp_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
   k_brpp_phase2<<<dim3((unsigned)B), dim3(256), lds2, st>>>(D, (uint32_t)nd, tb->pos_range, tb->pos_coeff, rnd, bits, ch, row_bl, aux);
   BPPP_HIP(ctx, hipGetLastError());
-  rc = comb(row_bl, c_bl); if (rc) return rc;
+  rc = comb(row_bl, c_bl, COMB_ROWS_DENSE); if (rc) return rc;
   rc = tr.call(c_bl, 1); if (rc) return rc;
   rc = brp_public_device(rp, B, ch, a_q, p_sp, p_norm, p_cs, p_init); if (rc) return rc;
   { const uint64_t n = (uint64_t)B * T;

@@ -39,8 +39,8 @@ void MsmTune::from_env() {
   auto geti = [](const char *n) { const char *e = getenv(n); return e ? atoi(e) : 0; };
   if (const char *e = getenv("BPPP_GCOST")) gcost = atof(e);
   cmin = geti("BPPP_CMIN"); lw = geti("BPPP_LW"); rg = geti("BPPP_RG"); marg_s = geti("BPPP_MARG_S"); lacc = geti("BPPP_LACC");
-  window_batched = geti("BPPP_WINDOW_BATCHED"); comb_wpe = geti("BPPP_COMB_WPE"); reduce_old = getenv("BPPP_REDUCE_OLD") != nullptr;
-  small_c = geti("BPPP_MSM_SMALL_C"); small_len = geti("BPPP_MSM_SMALL_LEN"); small_max = geti("BPPP_MSM_SMALL_MAX"); hist_ch = geti("BPPP_HIST_CH"); no_small = getenv("BPPP_MSM_NO_SMALL") != nullptr; comb_no_wsplit = getenv("BPPP_COMB_NO_WSPLIT") != nullptr; comb_no_packed = getenv("BPPP_COMB_NO_PACKED") != nullptr; no_balance = getenv("BPPP_MSM_NO_BALANCE") != nullptr;
+  window_batched = geti("BPPP_WINDOW_BATCHED"); comb_wpe = geti("BPPP_COMB_WPE"); comb_rows_waves = geti("BPPP_COMB_ROWS_WAVES"); reduce_old = getenv("BPPP_REDUCE_OLD") != nullptr;
+  small_c = geti("BPPP_MSM_SMALL_C"); small_len = geti("BPPP_MSM_SMALL_LEN"); small_max = geti("BPPP_MSM_SMALL_MAX"); hist_ch = geti("BPPP_HIST_CH"); no_small = getenv("BPPP_MSM_NO_SMALL") != nullptr; comb_no_wsplit = getenv("BPPP_COMB_NO_WSPLIT") != nullptr; comb_no_packed = getenv("BPPP_COMB_NO_PACKED") != nullptr; if (getenv("BPPP_COMB_ROWS_MIN_MB")) comb_rows_min_bytes = (size_t)strtoull(getenv("BPPP_COMB_ROWS_MIN_MB"), nullptr, 10) << 20; no_balance = getenv("BPPP_MSM_NO_BALANCE") != nullptr;
 }
 namespace bppp {
 int ctx_aux(bppp_ctx *ctx) {

@@ -197,6 +197,77 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (sub == 0 && active) aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
 }
 
+// LONG rows of FULL-WIDTH scalars, thousands of them (the lockstep argument's round commitments: 2 x batch rows over the whole basis): lane = INSTANCE.
+// The 64 lanes of a wavefront then walk the SAME term and window at the same time, so their 64 gathers fall into ONE table row (D entries of 64 B,
+// 256 KB at c = 13) instead of 64 rows a gigabyte apart: benchmarks/gather_locality.hip measures 50 G gathers/s for that pattern at any table size against
+// 19-20 G/s for one row per lane once the table is beyond 8 GB (address translation) — and k_comb_msm needs 14-15 G/s of them.
+// A wavefront takes `clen` consecutive terms of 64 instances and parks the 64 partial sums for k_comb_join_rows; with `pairs` the even (heavy) instances
+// are dispatched before the odd (light) ones, whose scalars vanish on a pattern that is the same for every instance (a wave-uniform skip).
+template <int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_comb_msm_rows(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
+                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, int pairs, uint32_t ngroups, uint32_t chunks, uint32_t clen,
+                                                 uint32_t *__restrict__ partial) {
+  const uint32_t lane = threadIdx.x, mask = (1u << c) - 1u;
+  uint32_t inst, chunk;
+  if (pairs) {                                                  // ngroups = groups of 64 PAIRS; blocks [0, chunks x ngroups) are the even instances
+    const uint32_t par = blockIdx.x / (chunks * ngroups), rem = blockIdx.x % (chunks * ngroups);
+    chunk = rem / ngroups; inst = 2u * ((rem % ngroups) * 64u + lane) + par;
+  } else { chunk = blockIdx.x / ngroups; inst = (blockIdx.x % ngroups) * 64u + lane; }
+  const bool active = inst < ninst;
+  const uint32_t *sc = scalars + (size_t)(active ? inst : 0) * nterms * 8;
+  const uint32_t i0 = chunk * clen, i1 = min(nterms, i0 + clen);
+  xyzz acc = xyzz_inf();
+  CombRaw pend; pend.a = pend.b = pend.c = pend.d = make_uint4(0, 0, 0, 0);
+  bool pend_ok = false, pend_neg = false;
+  for (uint32_t i = i0; i < i1; i++) {
+    fe s = fe_load(sc + (size_t)i * 8);
+    if (!active) s = fe_zero();
+    const bool nz = !fe_is_zero(s);
+    if (!__any(nz)) continue;
+    fe t, tmp;
+    raw_sub(t, fr_modulus(), s);
+    const bool neg = raw_sub(tmp, t, s) != 0;                    // reduceScalar (Commitment.hs:276-279)
+    uint32_t sp[9];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
+    sp[8] = (uint32_t)cy + K.k[8];
+    const uint32_t *ti = tab + (size_t)i * D * 16;
+#pragma unroll 1
+    for (int w = 0; w < W; w++) {
+      const int d = (int)(sp[0] & mask) - (int)D;
+#pragma unroll
+      for (int q = 0; q < 8; q++) sp[q] = (sp[q] >> c) | (sp[q + 1] << (32 - c));
+      sp[8] >>= c;
+      CombRaw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_uint4(0, 0, 0, 0);
+      const bool ok = nz && d != 0, nneg = (d < 0) != neg;
+      if (ok) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint4 *e = (const uint4 *)(ti + ((size_t)w * T * D + (mag - 1)) * 16);
+        nxt.a = e[0]; nxt.b = e[1]; nxt.c = e[2]; nxt.d = e[3];
+      }
+      if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+      pend = nxt; pend_ok = ok; pend_neg = nneg;
+    }
+  }
+  if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+  if (active) xyzz_store(partial + ((size_t)inst * chunks + chunk) * XYZZ_WORDS, acc);
+}
+// the `parts` partial sums of an instance (any count): lane l adds those at l, l + 64, ..., a shuffle tree joins the lanes, lane 0 normalises
+__global__ void __launch_bounds__(64) k_comb_join_rows(const uint32_t *__restrict__ partial, uint32_t parts, uint32_t *__restrict__ out) {
+  const uint32_t inst = blockIdx.x, lane = threadIdx.x;
+  xyzz acc = xyzz_inf();
+  for (uint32_t p = lane; p < parts; p += 64) {
+    xyzz o = xyzz_load(partial + ((size_t)inst * parts + p) * XYZZ_WORDS);
+    xyzz_add(acc, o);
+  }
+  for (int dd = 32; dd >= 1; dd >>= 1) {
+    xyzz o = xyzz_shfl_down(acc, dd);
+    if ((int)lane + dd < 64) xyzz_add(acc, o);
+  }
+  if (lane == 0) aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
+}
+
 // MANY instances of a FEW terms each (the prover's input commitments v g + ty H0 + bl H1: batch x #values instances over the first
 // three registered points): one LANE per instance walks its terms and digits; zero scalars and zero digits cost nothing
 __global__ void __launch_bounds__(64) k_comb_lanes(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
@@ -292,7 +363,7 @@ int comb_lanes(const CombTable *t, const uint32_t *d_scalars, size_t nterms, siz
   return BPPP_OK;
 }
 
-int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first, size_t nterms, uint32_t *d_scratch,
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, int rows_hint, size_t nterms, uint32_t *d_scratch,
              size_t scratch_bytes) {
   if (!t || !d_scalars || !d_out_aff || ninst >= (1u << 31) || nterms > t->T) return BPPP_ERR_ARG;
   if (!nterms) nterms = t->T;
@@ -307,6 +378,25 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
     else k_comb_msm_packed<16><<<dim3(grid_p), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, d_out_aff);
     if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_msm: launch failed");
     return BPPP_OK;
+  }
+  // long rows of full-width scalars by the thousand (the argument's rounds, the blinded phase rows: rows_hint) over a table beyond the reach of the address translation
+  // caches: lane = instance (k_comb_msm_rows), ~8192 wavefronts of `clen` terms each
+  if (rows_hint != COMB_ROWS_ANY && d_scratch && ninst >= 1024 && nterms >= 256 && t->bytes >= t->ctx->tune.comb_rows_min_bytes) {
+    const bool pairs = rows_hint == COMB_ROWS_PAIRS && !(ninst & 1);
+    const uint32_t ngroups = (uint32_t)(((pairs ? ninst / 2 : ninst) + 63) / 64), gtot = pairs ? 2 * ngroups : ngroups;
+    uint32_t chunks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)(nterms / 8), (std::min<uint32_t>(t->ctx->tune.comb_rows_waves ? (uint32_t)t->ctx->tune.comb_rows_waves : (uint32_t)COMB_ROWS_WAVES, (uint32_t)COMB_ROWS_WAVES) + gtot - 1) / gtot));
+    while (chunks > 1 && (size_t)ninst * chunks * XYZZ_WORDS * 4 > scratch_bytes) chunks--;
+    const uint32_t clen = (uint32_t)((nterms + chunks - 1) / chunks);
+    chunks = (uint32_t)((nterms + clen - 1) / clen);
+    if ((size_t)ninst * chunks * XYZZ_WORDS * 4 <= scratch_bytes) {
+      const dim3 grid_r(gtot * chunks), block_r(64);
+#define COMB_ROWS_LAUNCH(V) k_comb_msm_rows<V><<<grid_r, block_r, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, pairs ? 1 : 0, ngroups, chunks, clen, d_scratch)
+      if (t->ctx->tune.comb_wpe == 3) COMB_ROWS_LAUNCH(3); else COMB_ROWS_LAUNCH(2);
+#undef COMB_ROWS_LAUNCH
+      k_comb_join_rows<<<dim3((unsigned)ninst), dim3(64), 0, st>>>(d_scratch, chunks, d_out_aff);
+      if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_msm: launch failed");
+      return BPPP_OK;
+    }
   }
   // wavefronts per SIMD the register allocation aims at: 2 (225 VGPRs) measured 2 % ahead of 3 (168); 4 (128) spills and is 2.4 x slower
   const int wpe = t->ctx->tune.comb_wpe ? t->ctx->tune.comb_wpe : 2;
@@ -335,7 +425,7 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   const uint32_t parts = tparts * wsplit;
   const int wlen = (t->W + (int)wsplit - 1) / (int)wsplit;
   const dim3 grid((unsigned)(ninst * parts)), block(64);
-  const int hf = (heavy_first && !(ninst & 1)) ? 1 : 0;
+  const int hf = (rows_hint == COMB_ROWS_PAIRS && !(ninst & 1)) ? 1 : 0;
 #define COMB_LAUNCH(V) k_comb_msm<V><<<grid, block, 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint32_t)ninst, hf, parts, tparts, wlen, d_scratch, d_out_aff)
   if (wpe <= 2) COMB_LAUNCH(2); else COMB_LAUNCH(3);
 #undef COMB_LAUNCH

@@ -19,16 +19,22 @@ struct CombTable {
 // that the table stays under `budget_bytes`.
 int comb_create(bppp_ctx *ctx, const uint32_t *d_points, size_t T, int window_bits, size_t budget_bytes, CombTable **out);
 void comb_destroy(CombTable *t);
+// what the caller knows about the scalar rows of a launch: nothing; every row long and of full-width scalars (blinded rows); the same in heavy / light pairs
+enum { COMB_ROWS_ANY = 0, COMB_ROWS_PAIRS = 1, COMB_ROWS_DENSE = 2 };
 // out[inst] = sum_i scalars[inst][i] * P_i for inst < ninst (canonical affine, infinity = zeros); scalars are canonical (< n),
-// [ninst][nterms] in HBM over the first nterms registered points (0 = all T).  Asynchronous on `st`.  heavy_first: instances
-// 2b / 2b + 1 are a heavy / light pair (dispatch order only).
+// [ninst][nterms] in HBM over the first nterms registered points (0 = all T).  Asynchronous on `st`.  rows_hint: COMB_ROWS_PAIRS — instances
+// 2b / 2b + 1 are a heavy / light pair of full-width rows (the light one zero on an index pattern common to all instances); COMB_ROWS_DENSE — full-width
+// rows; either selects the lane-per-instance kernel for >= 1024 long rows over a large table (same results, another schedule).
 // d_scratch (optional, scratch_bytes): with fewer than COMB_SPLIT_BELOW instances several wavefronts share an instance and park their partial sums
 // there (160 B per wavefront; comb_scratch_bytes(ninst) is enough); without it a small launch is one wavefront per instance.
-int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, bool heavy_first = false, size_t nterms = 0,
+int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, int rows_hint = COMB_ROWS_ANY, size_t nterms = 0,
              uint32_t *d_scratch = nullptr, size_t scratch_bytes = 0);
 // many instances of a few terms each over the FIRST nterms registered points, one lane per instance: d_scalars [ninst][nterms]
 int comb_lanes(const CombTable *t, const uint32_t *d_scalars, size_t nterms, size_t ninst, uint32_t *d_out_aff, hipStream_t st);
 static constexpr size_t COMB_SPLIT_BELOW = 8192;      // launches of fewer instances are split into about that many wavefronts
+static constexpr size_t COMB_ROWS_WAVES = 16384;      // k_comb_msm_rows (lane = instance): about that many wavefronts, 64 partial sums each
 inline size_t comb_scratch_bytes(size_t ninst) { return ninst < COMB_SPLIT_BELOW ? (COMB_SPLIT_BELOW + 64 * (ninst < 1024 ? ninst : 1024) + ninst) * 160 : 0; }
+// scratch of a launch with a rows_hint (the argument's rounds, the blinded phase rows): room for the partial sums of either route
+inline size_t comb_rows_scratch_bytes(size_t ninst) { const size_t a = comb_scratch_bytes(ninst), b = (64 * COMB_ROWS_WAVES + 2 * ninst + 128) * 160; return a > b ? a : b; }
 
 }  // namespace bppp

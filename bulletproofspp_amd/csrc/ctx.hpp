@@ -10,7 +10,7 @@
 // Tuning overrides of the MSM plan (benchmarks/sweep_window.py and friends): the BPPP_* environment is read ONCE, when the context is
 // created; 0 / false = the library's heuristic.  No entry point reads the environment per call.
 struct MsmTune {
-  double gcost = 0; int cmin = 0, lw = 0, rg = 0, marg_s = 0, lacc = 0, window_batched = 0, comb_wpe = 0, small_c = 0, small_len = 0, small_max = 0, hist_ch = 0, num_cus = 0; bool reduce_old = false, no_small = false, comb_no_wsplit = false, no_balance = false, comb_no_packed = false;
+  double gcost = 0; int cmin = 0, lw = 0, rg = 0, marg_s = 0, lacc = 0, window_batched = 0, comb_wpe = 0, small_c = 0, small_len = 0, small_max = 0, hist_ch = 0, num_cus = 0; bool reduce_old = false, no_small = false, comb_no_wsplit = false, no_balance = false, comb_no_packed = false; size_t comb_rows_min_bytes = (size_t)4 << 30; int comb_rows_waves = 0;
   void from_env();
 };
 

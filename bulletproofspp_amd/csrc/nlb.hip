@@ -352,7 +352,7 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
     bad |= hipMalloc(&o->coefn, batch * std::max<size_t>(nlen, 1) * 32) != hipSuccess || hipMalloc(&o->coefl, batch * std::max<size_t>(llen, 1) * 32) != hipSuccess;
     bad |= hipMalloc(&o->full, 2 * batch * Tc * 32) != hipSuccess || hipMalloc(&o->dA, batch * 64) != hipSuccess || hipMalloc(&o->d_out, 2 * batch * 64) != hipSuccess;
     bad |= hipMalloc(&o->stt, batch * NLB_ST * 32) != hipSuccess || hipMalloc(&o->d_es, batch * 32) != hipSuccess;
-    if (comb_scratch_bytes(2 * batch)) bad |= hipMalloc(&o->cscratch, comb_scratch_bytes(2 * batch)) != hipSuccess;
+    bad |= hipMalloc(&o->cscratch, comb_rows_scratch_bytes(2 * batch)) != hipSuccess;
   }
   if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
   hipStream_t st = ctx->stream;
@@ -442,7 +442,7 @@ int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR) {
   k_nlb_expand<<<dim3((Tc + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds, o->coefn, o->coefl, (uint32_t)o->n0,
                                                                                 (uint32_t)o->l0, o->full);
   NLB_HIP(o, hipGetLastError());
-  int rc = comb_msm(o->comb, o->full, 2 * B, d_XR, st, true, 0, o->cscratch, comb_scratch_bytes(2 * B));
+  int rc = comb_msm(o->comb, o->full, 2 * B, d_XR, st, COMB_ROWS_PAIRS, 0, o->cscratch, comb_rows_scratch_bytes(2 * B));
   if (rc) return fail(ctx, rc, bppp_last_error(o->comb->ctx));
   return BPPP_OK;
 }

@@ -440,7 +440,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     p_sp = cv.take<uint32_t>(B * 8); p_norm = cv.take<uint32_t>(B * nlen * 8); p_cs = cv.take<uint32_t>(B * llen * 8); p_init = cv.take<uint32_t>(B * (4 + nr) * 8);
     text = cv.take<uint8_t>(B * (size_t)stride + 64); prefix = cv.take<uint8_t>(B * in.prefix_len + 16); hdrs = cv.take<uint8_t>(RppTranscript::hdr_bytes(3 + k) + 16);
     d_resp = cv.take<uint32_t>(k * B * 32 + 16); d_com = cv.take<uint32_t>(4 * B * 16 + 16);
-    cscratch = cv.take<uint32_t>(std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B)) / 4 + 16);
+    cscratch = cv.take<uint32_t>(std::max(comb_rows_scratch_bytes(B), comb_scratch_bytes(2 * B)) / 4 + 16);
     if (!pass) { int rc = rpp_ensure_pwork(rp, cv.off); if (rc) return rc; }
   }
   // ---- uploads: inputs, digits, multiplicities, prefixes
@@ -452,7 +452,7 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
   // fixed-basis mode (comb table in place): the whole proof is ONE stream of kernels — commitments stay on the device until the end,
   // every oracle call reads its points where they lie, and the headers of all 3 + k oracle calls go up here
   const bool stream_mode = rp->comb != nullptr && !rp->opt.fold_points;
-  const size_t cscratch_bytes = std::max(comb_scratch_bytes(B), comb_scratch_bytes(2 * B));
+  const size_t cscratch_bytes = std::max(comb_rows_scratch_bytes(B), comb_scratch_bytes(2 * B));
   // A handful of proofs: the oracle moves to the host.  One GPU lane walks the ~160 SHA-256 blocks of a 64by64 transcript in ~0.6 ms
   // (11 times per proof); a host core needs ~50 us, which pays for the round trip of the new points and the challenges as long as
   // the batch is small (BPPP_RP_HOST_ORACLE_MAX, default 64 proofs: 1 proof 5.2 ms against 12.0 ms, 32 proofs 11.2 against 12.7, level at 128; the
@@ -473,25 +473,25 @@ int rpp_device_prove(bppp_rp *rp, const RppHostInputs &in, RppOutputs &out) {
     if (lds2 > 160 * 1024) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: too many ranges for the device prover");
     if (lds2 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (lds3 > 64 * 1024) BPPP_HIP(ctx, hipFuncSetAttribute((const void *)k_rpp_phase3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-    auto comb = [&](const uint32_t *rows, size_t n, uint32_t *dst) -> int {
-      int r_ = comb_msm(rp->comb, rows, n, dst, st, false, 0, cscratch, cscratch_bytes);
+    auto comb = [&](const uint32_t *rows, size_t n, uint32_t *dst, int hint) -> int {
+      int r_ = comb_msm(rp->comb, rows, n, dst, st, hint, 0, cscratch, cscratch_bytes);
       return r_ ? fail(ctx, r_, bppp_last_error(rp->comb->ctx)) : BPPP_OK;
     };
     uint32_t *c_dmm = d_com, *c_r = d_com + 2 * B * 16, *c_bl = d_com + 3 * B * 16;
     std::vector<uint64_t> hcom_host;
     // (e, x, r0) <- oracle ([dmCom, mCom] ++ nComs)   (TypedReciprocal.hs:412)
-    rc = comb(rows_dm_m, 2 * B, c_dmm); if (rc) return rc;
+    rc = comb(rows_dm_m, 2 * B, c_dmm, COMB_ROWS_ANY); if (rc) return rc;          // digits and multiplicities: small scalars
     BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf, (2 + nr) * 64, c_dmm, 128, 128, B, hipMemcpyDeviceToDevice, st));
     BPPP_HIP(ctx, hipMemcpy2DAsync(ptbuf + 32, (2 + nr) * 64, in_pt, nr * 64, nr * 64, B, hipMemcpyDeviceToDevice, st));
     rc = oracle_dev(ptbuf, 0); if (rc) return rc;
     k_rpp_phase2<<<dim3((unsigned)B), dim3(64), lds2, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_sym, tb->syms, in_sc, dig, rnd, ch, row_r, ccbuf, invtab);
     // (q, x', r1) <- oracle [rCom]
-    rc = comb(row_r, B, c_r); if (rc) return rc;
+    rc = comb(row_r, B, c_r, COMB_ROWS_DENSE); if (rc) return rc;                  // reciprocals: full width
     rc = oracle_dev(c_r, 1); if (rc) return rc;
     k_rpp_phase3<<<dim3((unsigned)B), dim3(64), lds3, st>>>(D, TD, tb->pos_kind, tb->pos_range, tb->pos_slot, tb->pos_coeff, tb->range_assumed, tb->syms, tb->cs_slot, tb->cs_sym,
                                                             in_sc, dig, mul, rnd, ch, rows_dm_m, row_r, ccbuf, invtab, row_bl, aux);
     // t <- oracle [blCom]; public constants and linear weights by the verifier's kernel; the combined witness
-    rc = comb(row_bl, B, c_bl); if (rc) return rc;
+    rc = comb(row_bl, B, c_bl, COMB_ROWS_DENSE); if (rc) return rc;
     rc = oracle_dev(c_bl, 2); if (rc) return rc;
     BPPP_HIP(ctx, hipGetLastError());
     rc = bppp_trrp_public_device(rp->tabs, B, ch, a_q, p_sp, p_norm, p_cs, p_init); if (rc) return rc;

@@ -108,3 +108,57 @@ def test_native_prover_full_size_equals_oracle_backend(gpu, oracle_lib, name, ty
     plain.set_option("comb_budget", 0)
     assert plain.prove_batch(inputs[:1], prefixes[:1])[0] == want
     plain.close()
+
+
+def test_lane_per_instance_comb_rows_write_the_same_files(monkeypatch, oracle_lib):
+    """round 4: >= 1024 long rows of full-width scalars (the argument's X / R rows, the blinded phase rows) over a large comb table run with one LANE
+    per instance (k_comb_msm_rows + k_comb_join_rows, csrc/comb.hip) — another schedule of the same sums.  examples/64by64, 1030 proofs (2060 round
+    rows in heavy / light pairs, 1030 dense phase rows: neither a multiple of 64), on a context where every table qualifies (BPPP_COMB_ROWS_MIN_MB=0):
+    proof 0 is the oracle backend's byte for byte, and the batch equals the one a context with the route switched off writes."""
+    import bulletproofspp_amd as b
+    schema = _schema("64by64", False)
+    st_o = RP.setup_from_schema(OracleBackend(oracle_lib), schema)
+    rnd = random.Random("rows")
+    B, count = 1030, len(st_o.rds)
+    inputs = [[(rnd.randrange(2**64), 0, rnd.randrange(O.N)) for _ in range(count)] for _ in range(B)]
+    prefixes = [b"rows %04d" % i for i in range(B)]
+    want = E.encode_proof(4, RP.prove(st_o, RP.witness(st_o, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0])))
+    files = {}
+    for tag, min_mb, waves in (("rows", "0", "0"), ("rows, few wavefronts", "0", "300"), ("off", "100000000", "0")):
+        monkeypatch.setenv("BPPP_COMB_ROWS_MIN_MB", min_mb)
+        monkeypatch.setenv("BPPP_COMB_ROWS_WAVES", waves)
+        g = b.Bppp(0)
+        nat = RP.NativeRangeProofs(g, RP.setup_from_schema(RP.GpuBackend(g), schema))
+        nat.set_option("comb_min", 1); nat.set_option("comb_bits", 8)
+        files[tag] = nat.prove_batch(inputs, prefixes)
+        if tag == "rows":
+            assert nat.verify_batch([c for c, _ in files[tag]], [p for _, p in files[tag]])
+        nat.close()
+    assert files["rows"][0] == want
+    assert files["rows"] == files["off"] and files["rows, few wavefronts"] == files["off"]
+
+
+def test_lane_per_instance_comb_rows_binary_shape(monkeypatch):
+    """the same at the 64 x 64-bit BINARY shape (rows of 4099 terms; 1027 proofs: 2054 round rows, 1027 dense rows of the blinding commitment)"""
+    import bulletproofspp_amd as b
+    from bulletproofspp_amd import rangeproof_binary as BRP
+    count, amount, B = 64, 10000, 1027
+    rds = [BRP.make_range_data(0, 2**64, True, False)] * count
+    pts = O.hash_points(b"binary rows", 4 + 64 * count)
+    rnd = random.Random("binary rows")
+    inputs = []
+    for _ in range(B):
+        d = [rnd.randrange(-5000, 5000) for _ in range(count // 2)]
+        inputs.append([(amount + x, rnd.randrange(RP.N)) for x in d] + [(amount - x, rnd.randrange(RP.N)) for x in d])
+    prefixes = [b"binrows %04d" % i for i in range(B)]
+    files = {}
+    for tag, min_mb in (("rows", "0"), ("off", "100000000")):
+        monkeypatch.setenv("BPPP_COMB_ROWS_MIN_MB", min_mb)
+        g = b.Bppp(0)
+        nat = BRP.NativeBinaryRangeProofs(g, BRP.setup(RP.GpuBackend(g), pts, True, rds, amount * count, "NL"))
+        nat.set_option("comb_min", 1); nat.set_option("comb_bits", 9)
+        files[tag] = nat.prove_batch(inputs, prefixes)
+        if tag == "rows":
+            assert nat.verify_batch([c for c, _ in files[tag]], [p for _, p in files[tag]])
+        nat.close()
+    assert files["rows"] == files["off"]
