@@ -1003,7 +1003,7 @@ def main():
         comb_traffic = None
         try:
             pk = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["prover_4096_proofs_64by64"]["by_kernel"]
-            ck = next(v for k_, v in pk.items() if "k_comb_msm" in k_)
+            ck = next(v for k_, v in pk.items() if "k_comb_msm<" in k_)        # (not k_comb_msm_rows: this leg runs bppp_msm_basis, one wavefront per instance)
             # the profile's launches average SQ_WAVES instances (one wavefront per instance): scale to this launch's `inst` instances
             comb_traffic = (ck["fetch_bytes_per_launch_x2"] + ck["write_bytes_per_launch"]) / ck["sq_per_launch"]["SQ_WAVES"] * inst
         except Exception:
