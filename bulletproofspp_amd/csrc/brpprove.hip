@@ -227,7 +227,7 @@ int prove_batch_binary(bppp_rp *rp, size_t batch, const uint64_t *amounts, const
 // The same proofs with proveBRPM's field algebra, randomness and transcript on the device (csrc/brpprove_dev.hip): the host checks the
 // witness (witnessBRP, Binary.hs:158-166), extracts the binary digits of the plain amounts (makeDigits :56-69) and writes the files.
 int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len,
-                                  uint8_t *coms_files, uint8_t *proof_files) {
+                                  uint8_t *coms_files, uint8_t *proof_files, size_t index_base) {
   bppp_ctx *ctx = rp->ctx;
   hipSetDevice(ctx->device);
   const Setup &st = rp->st;
@@ -274,7 +274,7 @@ int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, c
       if (err) { failed = (int)b; errs[b] = err; }
     }
   });
-  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string((size_t)failed) + ": " + errs[failed]);
+  if (failed >= 0) return fail(ctx, BPPP_ERR_ARG, "rp_prove_batch: proof " + std::to_string(index_base + (size_t)failed) + ": " + errs[failed]);
   lap("witness, digits (host)");
   std::vector<uint64_t> c_d(B * 8), c_bl(B * 8), resp(B * (k ? k : 1) * 16), wn(B * st.fn * 4 + 4), wl(B * st.fl * 4 + 4);
   BrpHostInputs in{B, h_in_sc, bits, rand_prefix, prefix_len};

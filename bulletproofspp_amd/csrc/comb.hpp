@@ -24,7 +24,7 @@ enum { COMB_ROWS_ANY = 0, COMB_ROWS_PAIRS = 1, COMB_ROWS_DENSE = 2 };
 // out[inst] = sum_i scalars[inst][i] * P_i for inst < ninst (canonical affine, infinity = zeros); scalars are canonical (< n),
 // [ninst][nterms] in HBM over the first nterms registered points (0 = all T).  Asynchronous on `st`.  rows_hint: COMB_ROWS_PAIRS — instances
 // 2b / 2b + 1 are a heavy / light pair of full-width rows (the light one zero on an index pattern common to all instances); COMB_ROWS_DENSE — full-width
-// rows; either selects the lane-per-instance kernel for >= 1024 long rows over a large table (same results, another schedule).
+// rows; either selects the lane-per-instance kernel for >= 512 long rows over a large table (same results, another schedule).
 // d_scratch (optional, scratch_bytes): with fewer than COMB_SPLIT_BELOW instances several wavefronts share an instance and park their partial sums
 // there (160 B per wavefront; comb_scratch_bytes(ninst) is enough); without it a small launch is one wavefront per instance.
 int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, int rows_hint = COMB_ROWS_ANY, size_t nterms = 0,

@@ -496,7 +496,7 @@ int brp_public_device(bppp_rp *rp, size_t batch, const uint32_t *ch, uint32_t *q
 
 void RpOptions::from_env() {
   auto num = [](const char *name, size_t &dst) { if (const char *e = getenv(name)) dst = (size_t)atol(e); };
-  num("BPPP_RP_COMB_MIN", comb_min); num("BPPP_RP_SPLIT_MIN", split_min); num("BPPP_RP_HASH_FORK_MAX", hash_fork_max);
+  num("BPPP_RP_COMB_MIN", comb_min); num("BPPP_RP_SPLIT_MIN", split_min); num("BPPP_RP_SPLIT_MIN_BINARY", split_min_binary); num("BPPP_RP_HASH_FORK_MAX", hash_fork_max);
   if (const char *e = getenv("BPPP_RP_COMB_GB")) comb_budget = (size_t)std::max(1, atoi(e)) << 30;
   if (const char *e = getenv("BPPP_RP_COMB_BITS")) comb_bits = atoi(e);
   if (const char *e = getenv("BPPP_RP_HOST_ORACLE_MAX")) host_oracle_verify = host_oracle_prove = (size_t)atol(e);
@@ -702,6 +702,8 @@ int bppp_rp_create_binary(bppp_ctx *ctx, int flavour, int conserve, const bppp_r
     rp->h_H.assign(points_xy + 16, points_xy + 32);
     rp->h_G.assign(points_xy + 32, points_xy + 32 + 8 * st.nlen);
     rp->tag = oracle_tag ? oracle_tag : "";
+    rp->c_ranges.assign(ranges, ranges + nranges); rp->c_points.assign(points_xy, points_xy + 8 * (4 + st.nlen));
+    rp->c_conserve = conserve; memcpy(rp->c_net_public, net_public, 32);
     hipSetDevice(ctx->device);
     BPPP_HIP(ctx, hipMalloc(&rp->d_basis, (3 + st.nlen) * 64));
     BPPP_HIP(ctx, hipHostMalloc((void **)&rp->hflag, 64, hipHostMallocDefault));
@@ -748,8 +750,12 @@ int rp_ensure_twin(bppp_rp *rp) {
   bppp_ctx *ctx = rp->ctx;
   int rc = bppp_ctx_create(ctx->device, &rp->twin_ctx);
   if (rc) { rp->twin_ctx = nullptr; return fail(ctx, rc, "rp: creating the second context failed"); }
-  rc = bppp_rp_create(rp->twin_ctx, rp->st.flavour, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
-                      rp->c_points.data(), rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
+  if (rp->st.kind == 1)
+    rc = bppp_rp_create_binary(rp->twin_ctx, rp->st.flavour, rp->c_conserve, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_net_public, rp->c_points.data(),
+                               rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
+  else
+    rc = bppp_rp_create(rp->twin_ctx, rp->st.flavour, rp->c_has_types, rp->c_ranges.data(), rp->c_ranges.size(), rp->c_pubs.empty() ? nullptr : rp->c_pubs.data(), rp->c_pubs.size(),
+                        rp->c_points.data(), rp->c_points.size() / 8, rp->tag.c_str(), &rp->twin);
   if (rc) {
     const std::string m = bppp_last_error(rp->twin_ctx);
     bppp_ctx_destroy(rp->twin_ctx); rp->twin_ctx = nullptr; rp->twin = nullptr;

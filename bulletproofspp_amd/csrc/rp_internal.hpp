@@ -71,6 +71,7 @@ struct RpOptions {
   int comb_bits = 0;                  // BPPP_RP_COMB_BITS: force a window width (0 = widest that fits the budget)
   bool no_comb = false;               // BPPP_RP_NO_COMB
   size_t split_min = 4096;            // BPPP_RP_SPLIT_MIN: smallest batch run as two half-batches in flight
+  size_t split_min_binary = 1024;     // BPPP_RP_SPLIT_MIN_BINARY: the same for RangeProof.Binary handles (rows of thousands of terms: fewer proofs fill the chip)
   bool no_split = false;              // BPPP_RP_NO_SPLIT
   size_t host_oracle_verify = 8;      // BPPP_RP_HOST_ORACLE_MAX: largest batch whose transcript hashing runs on the host (verifier)
   size_t host_oracle_prove = 64;      //                          ... (prover)
@@ -107,6 +108,7 @@ struct bppp_rp {
   // the creation arguments, kept so that a second handle on its OWN context (stream, workspaces) can be made: a large prove batch
   // runs as two half-batches in flight, the host shares of one under the kernels of the other (csrc/rpprove.hip)
   std::vector<bppp_rp_range> c_ranges; std::vector<bppp_rp_public> c_pubs; std::vector<uint64_t> c_points; int c_has_types = 0;
+  int c_conserve = 0; uint64_t c_net_public[4] = {0, 0, 0, 0};      // bppp_rp_create_binary's arguments, for the twin handle
   bppp_rp *twin = nullptr; bppp_ctx *twin_ctx = nullptr; bool is_twin = false;
   // fixed-base comb over [g | H | G] (csrc/comb.hip): the range-proof commitments and the argument's round commitments of large
   // batches; the twin handle uses its parent's table

@@ -157,7 +157,7 @@ int ip_argument_lockstep(bppp_rp *rp, size_t B, size_t k, const uint64_t *psv_in
 int prove_batch_binary(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len, uint8_t *coms_files,
                        uint8_t *proof_files);
 int prove_batch_binary_dev(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *blinds, const uint8_t *rand_prefix, size_t prefix_len, uint8_t *coms_files,
-                           uint8_t *proof_files);
+                           uint8_t *proof_files, size_t index_base = 0);
 }  // namespace bppp
 
 extern "C" {

@@ -157,8 +157,14 @@ def test_lane_per_instance_comb_rows_binary_shape(monkeypatch):
         g = b.Bppp(0)
         nat = BRP.NativeBinaryRangeProofs(g, BRP.setup(RP.GpuBackend(g), pts, True, rds, amount * count, "NL"))
         nat.set_option("comb_min", 1); nat.set_option("comb_bits", 9)
+        if tag == "off":
+            nat.set_option("split_min", 0)          # one batch on one context; "rows" runs as two half-batches in flight (>= 1024 binary proofs)
         files[tag] = nat.prove_batch(inputs, prefixes)
         if tag == "rows":
             assert nat.verify_batch([c for c, _ in files[tag]], [p for _, p in files[tag]])
+            bad = [list(r) for r in inputs]
+            bad[1000][3] = (2**64, bad[1000][3][1])                  # in the SECOND half: the message names the proof's position in the batch
+            with pytest.raises(Exception, match="proof 1000: value outside its range"):
+                nat.prove_batch(bad, prefixes)
         nat.close()
     assert files["rows"] == files["off"]
