@@ -386,7 +386,7 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
     return BPPP_OK;
   }
   // long rows of full-width scalars by the thousand (the argument's rounds, the blinded phase rows: rows_hint) over a table beyond the reach of the address translation
-  // caches: lane = instance (k_comb_msm_rows), ~8192 wavefronts of `clen` terms each
+  // caches: lane = instance (k_comb_msm_rows), ~16384 wavefronts of `clen` terms each
   if (rows_hint != COMB_ROWS_ANY && d_scratch && ninst >= 512 && nterms >= 256 && t->bytes >= t->ctx->tune.comb_rows_min_bytes) {
     const bool pairs = rows_hint == COMB_ROWS_PAIRS && !(ninst & 1);
     const uint32_t ngroups = (uint32_t)(((pairs ? ninst / 2 : ninst) + 63) / 64), gtot = pairs ? 2 * ngroups : ngroups;
