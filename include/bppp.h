@@ -440,11 +440,12 @@ int bppp_rp_verify_shard_device(bppp_rp *rp, size_t batch, uint64_t index_offset
  * hashing; the host cores extract the digits of the plain amounts.  MEMORY: at the first batch of 1024 proofs or more, or once it has proved that many in smaller batches (bppp_rp_set_option COMB_MIN), the handle
  * builds a fixed-base comb table over the setup's basis [g | H | G] and keeps it until it is destroyed — the widest window (<= 18
  * bits) whose table fits 32 GB: c = 16, 27.6 GB for the 774 points of 64by64, built in ~0.3 s (BPPP_RP_COMB_GB=<GB> changes the budget:
- * 64 GB (c = 17) measured 1 % faster, 128 GB (c = 18) 5 % — the gathers over a larger table cost most of what the fewer additions save;
+ * 64 GB (c = 17) and 128 GB (c = 18) measured level with it — the gathers over longer table rows cost what the fewer additions save;
  * BPPP_RP_COMB_BITS=<c> forces a width: c = 13 is 4.1 GB and ~15 % more additions; BPPP_RP_NO_COMB=1 keeps the bucket route and
  * the point-folding argument, which smaller batches use anyway).  A batch of 4096 proofs or more runs as two half-batches in
  * flight, the second on a twin handle with its own context that this handle creates and owns and that shares the table
- * (BPPP_RP_SPLIT_MIN=<n> moves the threshold, BPPP_RP_NO_SPLIT=1 disables it); a handle serves one call at a time.  Same
+ * (BPPP_RP_SPLIT_MIN=<n> moves the threshold, BPPP_RP_NO_SPLIT=1 disables it; a RangeProof.Binary handle splits from 1024 proofs,
+ * BPPP_RP_SPLIT_MIN_BINARY); a handle serves one call at a time.  Same
  * randomness and inputs => byte-identical files to the host protocol code (bulletproofspp_amd/rangeproof.py: prove +
  * encoding.encode_proof), on every one of these routes, which the tests assert. */
 int bppp_rp_prove_batch(bppp_rp *rp, size_t batch, const uint64_t *amounts, const uint64_t *types, const uint64_t *blinds, const uint8_t *rand_prefix,
