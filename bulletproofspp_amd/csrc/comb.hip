@@ -13,6 +13,10 @@
 // k_comb_msm: one wavefront per instance, lane l takes one term of every 64; the table entry of the NEXT digit is requested
 // before the addition of the current one is issued, so the 64-B gathers (random over the table: HBM, not cache) hide under ~2.8 k
 // VALU instructions each.  The 64 lane sums meet in a shuffle tree; lane 0 normalises.  VALU-bound like k_acc_points.
+//
+// k_comb_msm_rows (round 4): thousands of LONG rows of full-width scalars (the argument's rounds) over a table of tens of GB — lane = instance, the
+// wavefront walks (term, window) in lockstep and its 64 gathers fall into ONE table row; k_comb_join_rows adds the partial sums of an instance.
+// k_comb_msm_packed: thousands of rows of a few dozen terms (8 or 16 lanes per instance).  k_comb_lanes: one lane per three-term instance.
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
