@@ -106,7 +106,10 @@ bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const ui
     for (auto &kv : sums) if (!kv.second.is_zero()) { ps.err = "amounts of some type do not balance"; return false; }
   }
   ps.d.assign(st.nlen, U256::zero()); ps.mi.assign(st.nlen, U256::zero()); ps.pv.assign(st.nlen, U256::one());
-  ps.ms_shared.assign(st.llen - 6, U256::zero());
+  // the shared multiplicities are counts of digits: summed as integers (64 ranges x 255 digit values of modular additions per proof were most of
+  // this function's time), converted once at the end
+  std::vector<uint32_t> &msc = ps.tmp_msc;
+  msc.assign(st.llen - 6, 0u);
   std::vector<size_t> base_off(st.m_bases.size(), 0);
   for (size_t k = 1; k < st.m_bases.size(); k++) base_off[k] = base_off[k - 1] + st.m_bases[k - 1] - 1;
   auto moff = [&](uint32_t base) { size_t k = std::lower_bound(st.m_bases.begin(), st.m_bases.end(), base) - st.m_bases.begin(); return base_off[k]; };
@@ -120,20 +123,21 @@ bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const ui
     std::vector<uint32_t> &ds = ps.tmp_ds, &cnt = ps.tmp_cnt, &ms = ps.tmp_ms;       // reused across ranges and proofs
     bppp_rps::digits_into(rd, bppp_rps::u_sub(amt[i], rd.lo), ds);
     const uint32_t b = rd.base;
-    // ms aligned with ns = [1 | hasBit] ++ [1 .. b-1]: the bit itself, then how often each non-zero digit value occurs (:141-145)
-    cnt.assign(b, 0);
-    for (size_t j = rd.has_bit ? 1 : 0; j < ds.size(); j++) cnt[ds[j]]++;
-    ms.clear();
-    if (rd.has_bit) ms.push_back(ds[0]);
-    for (uint32_t s = 1; s < b; s++) ms.push_back(cnt[s]);
     const size_t p0 = st.first_pos[i];
     if (rd.shared) {
+      // the digits go to their positions; their multiplicities to the shared table of this base (baseMss, :363-370; the bit's to base 2), one
+      // count per non-zero digit (ms aligned with ns = [1 | hasBit] ++ [1 .. b-1], :141-145)
       for (size_t j = 0; j < ds.size(); j++) ps.d[p0 + j] = small(ds[j]);
-      size_t k = 0;                                        // baseMss (:363-370): the bit's multiplicity goes to base 2
-      if (rd.has_bit) { U256 &a = ps.ms_shared[moff(2)]; a = fa(a, small(ms[0])); k = 1; }
+      if (rd.has_bit) msc[moff(2)] += ds[0];
       const size_t o = moff(b);
-      for (uint32_t s = 0; s + 1 < b; s++) { U256 &a = ps.ms_shared[o + s]; a = fa(a, small(ms[k + s])); }
+      for (size_t j = rd.has_bit ? 1 : 0; j < ds.size(); j++) if (ds[j]) msc[o + ds[j] - 1]++;
     } else {
+      // ms aligned with ns = [1 | hasBit] ++ [1 .. b-1]: the bit itself, then how often each non-zero digit value occurs (:141-145)
+      cnt.assign(b, 0);
+      for (size_t j = rd.has_bit ? 1 : 0; j < ds.size(); j++) cnt[ds[j]]++;
+      ms.clear();
+      if (rd.has_bit) ms.push_back(ds[0]);
+      for (uint32_t s = 1; s < b; s++) ms.push_back(cnt[s]);
       const size_t ln = std::max(ds.size(), ms.size());
       for (size_t j = 0; j < ln; j++) {
         if (j < ds.size()) ps.d[p0 + j] = small(ds[j]);
@@ -141,6 +145,8 @@ bool make_witness(const Setup &st, PState &ps, const uint64_t *amounts, const ui
       }
     }
   }
+  ps.ms_shared.resize(st.llen - 6);
+  for (size_t j = 0; j < msc.size(); j++) ps.ms_shared[j] = small(msc[j]);
   return true;
 }
 

@@ -83,7 +83,7 @@ struct PState {
   size_t npoints = 0;
   Rnd rnd;
   std::string err;
-  std::vector<uint32_t> tmp_ds, tmp_cnt, tmp_ms;   // make_witness scratch
+  std::vector<uint32_t> tmp_ds, tmp_cnt, tmp_ms, tmp_msc;   // make_witness scratch
 };
 
 // shaOracle (app/Main.hs:75-80) over ZKPT's transcript (src/ZKP.hs:96-101): the new commitments go IN FRONT; output n hashes
