@@ -13,7 +13,7 @@
 #include "ec.hip.h"
 
 namespace bppp {
-int msm_run_ex(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *, size_t);
+int msm_run_ex(bppp_ctx *, const void *, const void *, size_t, size_t, int, int, uint64_t *, size_t, uint32_t *);
 
 // one lane per point: the chain P, 2^c P, 2^(2c) P, ... (c doublings and one normalisation per step; canonical affine rows)
 __global__ void __launch_bounds__(64) k_basis_table(const uint32_t *__restrict__ pts, uint32_t n, int c, int W, uint32_t *__restrict__ table) {
@@ -137,7 +137,7 @@ int bppp_msm_basis(bppp_basis *h, const void *d_scalars, size_t n_terms, size_t 
     BPPP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BPPP_OK;
   }
-  return msm_run_ex(ctx, d_scalars, h->table, n_terms, batch, 1, h->c, out_xy, h->n);
+  return msm_run_ex(ctx, d_scalars, h->table, n_terms, batch, 1, h->c, out_xy, h->n, nullptr);
 }
 
 // Adds the comb table tab[w][i][d-1] = d 2^(c w) P_i (csrc/comb.hip) to a registered basis: bppp_msm_basis of >= 64 instances then

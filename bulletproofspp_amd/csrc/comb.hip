@@ -278,6 +278,58 @@ __global__ void __launch_bounds__(64) k_comb_join_rows(const uint32_t *__restric
   if (sub == 0 && active) aff_store(out + (size_t)inst * 16, xyzz_to_aff(acc));
 }
 
+// The level-L basis of every proof, materialised (the lockstep argument's late rounds, csrc/nlb.hip): scalars [ninst][1 + l0 + n0] are the fold
+// coefficients of a proof over [g | lin | norm] (g's slot unused); group q of 2^L consecutive points of the lin part, then of the norm part, is summed with
+// its coefficients into out[inst][1 + q] (canonical affine; out[inst][0] is not written).  Lane = instance as in k_comb_msm_rows: one wavefront per
+// (64 instances, group), nothing to join.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_comb_msm_groups(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
+                                                 const uint32_t *__restrict__ scalars, uint32_t nterms, uint32_t ninst, uint32_t ngroups, uint32_t l0, uint32_t n0, int L, uint32_t l0r,
+                                                 uint32_t out_stride, uint32_t *__restrict__ out) {
+  const uint32_t lane = threadIdx.x, mask = (1u << c) - 1u;
+  const uint32_t q = blockIdx.x / ngroups, inst = (blockIdx.x % ngroups) * 64u + lane;
+  const bool active = inst < ninst;
+  const uint32_t *sc = scalars + (size_t)(active ? inst : 0) * nterms * 8;
+  uint32_t i0, i1;
+  if (q < l0r) { i0 = 1u + (q << L); i1 = min(1u + l0, i0 + (1u << L)); }
+  else { i0 = 1u + l0 + ((q - l0r) << L); i1 = min(1u + l0 + n0, i0 + (1u << L)); }
+  xyzz acc = xyzz_inf();
+  CombRaw pend; pend.a = pend.b = pend.c = pend.d = make_uint4(0, 0, 0, 0);
+  bool pend_ok = false, pend_neg = false;
+  for (uint32_t i = i0; i < i1; i++) {
+    fe s = fe_load(sc + (size_t)i * 8);
+    if (!active) s = fe_zero();
+    const bool nz = !fe_is_zero(s);
+    if (!__any(nz)) continue;
+    fe t, tmp;
+    raw_sub(t, fr_modulus(), s);
+    const bool neg = raw_sub(tmp, t, s) != 0;                    // reduceScalar (Commitment.hs:276-279)
+    uint32_t sp[9];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cy += (uint64_t)(neg ? t.v[k] : s.v[k]) + K.k[k]; sp[k] = (uint32_t)cy; cy >>= 32; }
+    sp[8] = (uint32_t)cy + K.k[8];
+    const uint32_t *ti = tab + (size_t)i * D * 16;
+#pragma unroll 1
+    for (int w = 0; w < W; w++) {
+      const int d = (int)(sp[0] & mask) - (int)D;
+#pragma unroll
+      for (int k = 0; k < 8; k++) sp[k] = (sp[k] >> c) | (sp[k + 1] << (32 - c));
+      sp[8] >>= c;
+      CombRaw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_uint4(0, 0, 0, 0);
+      const bool ok = nz && d != 0, nneg = (d < 0) != neg;
+      if (ok) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint4 *e = (const uint4 *)(ti + ((size_t)w * T * D + (mag - 1)) * 16);
+        nxt.a = e[0]; nxt.b = e[1]; nxt.c = e[2]; nxt.d = e[3];
+      }
+      if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+      pend = nxt; pend_ok = ok; pend_neg = nneg;
+    }
+  }
+  if (pend_ok) xyzz_madd(acc, comb_aff(pend, pend_neg));
+  if (active) aff_store(out + ((size_t)inst * out_stride + 1u + q) * 16, xyzz_to_aff(acc));
+}
+
 // MANY instances of a FEW terms each (the prover's input commitments v g + ty H0 + bl H1: batch x #values instances over the first
 // three registered points): one LANE per instance walks its terms and digits; zero scalars and zero digits cost nothing
 __global__ void __launch_bounds__(64) k_comb_lanes(const uint32_t *__restrict__ tab, uint32_t T, int c, int W, uint32_t D, CombK K,
@@ -370,6 +422,18 @@ int comb_lanes(const CombTable *t, const uint32_t *d_scalars, size_t nterms, siz
   for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
   k_comb_lanes<<<dim3((unsigned)((ninst + 63) / 64)), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)nterms, (uint64_t)ninst, d_out_aff);
   if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_lanes: launch failed");
+  return BPPP_OK;
+}
+
+int comb_groups(const CombTable *t, const uint32_t *d_scalars, size_t ninst, size_t l0, size_t n0, int L, uint32_t *d_out_aff, size_t out_stride, hipStream_t st) {
+  if (!t || !d_scalars || !d_out_aff || !ninst || 1 + l0 + n0 != t->T || L < 1 || L > 20) return BPPP_ERR_ARG;
+  const size_t l0r = (l0 + ((size_t)1 << L) - 1) >> L, n0r = (n0 + ((size_t)1 << L) - 1) >> L, ngroups = (ninst + 63) / 64;
+  if (out_stride < 1 + l0r + n0r || ngroups * (l0r + n0r) >= (1ull << 31)) return BPPP_ERR_ARG;
+  CombK K; memset(&K, 0, sizeof K);
+  for (int w = 0; w < t->W; w++) { const int bit = w * t->c + t->c - 1; if (bit < 288) K.k[bit >> 5] |= 1u << (bit & 31); }
+  k_comb_msm_groups<<<dim3((unsigned)(ngroups * (l0r + n0r))), dim3(64), 0, st>>>(t->tab, (uint32_t)t->T, t->c, t->W, (uint32_t)t->D, K, d_scalars, (uint32_t)t->T, (uint32_t)ninst,
+                                                                               (uint32_t)ngroups, (uint32_t)l0, (uint32_t)n0, L, (uint32_t)l0r, (uint32_t)out_stride, d_out_aff);
+  if (hipGetLastError() != hipSuccess) return fail(t->ctx, BPPP_ERR_HIP, "comb_groups: launch failed");
   return BPPP_OK;
 }
 

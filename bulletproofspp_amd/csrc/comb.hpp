@@ -29,6 +29,9 @@ enum { COMB_ROWS_ANY = 0, COMB_ROWS_PAIRS = 1, COMB_ROWS_DENSE = 2 };
 // there (160 B per wavefront; comb_scratch_bytes(ninst) is enough); without it a small launch is one wavefront per instance.
 int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32_t *d_out_aff, hipStream_t st, int rows_hint = COMB_ROWS_ANY, size_t nterms = 0,
              uint32_t *d_scratch = nullptr, size_t scratch_bytes = 0);
+// sums of GROUPS of 2^L consecutive registered points: d_scalars [ninst][T] over [g | lin (l0) | norm (n0)], out[inst][1 + q] = the q-th group's sum (lin groups,
+// then norm groups; out rows are out_stride points apart, slot 0 untouched) — the level-L basis of each proof of the lockstep argument
+int comb_groups(const CombTable *t, const uint32_t *d_scalars, size_t ninst, size_t l0, size_t n0, int L, uint32_t *d_out_aff, size_t out_stride, hipStream_t st);
 // many instances of a few terms each over the FIRST nterms registered points, one lane per instance: d_scalars [ninst][nterms]
 int comb_lanes(const CombTable *t, const uint32_t *d_scalars, size_t nterms, size_t ninst, uint32_t *d_out_aff, hipStream_t st);
 static constexpr size_t COMB_SPLIT_BELOW = 8192;      // launches of fewer instances are split into about that many wavefronts

@@ -810,15 +810,22 @@ static RecodeK make_recode_k(int c, int W, int acnt = -1) {
 }
 
 int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points, int window_bits, uint64_t *out_xy,
-               size_t table_stride);
+               size_t table_stride, uint32_t *d_out_dev = nullptr);
 int msm_run(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points,
             int window_bits, uint64_t *out_xy) {
   return msm_run_ex(ctx, d_scalars, d_points, n, batch, shared_points, window_bits, out_xy, 0);
 }
+// the same batch of MSMs with the results LEFT IN HBM (d_out [batch][16], canonical affine) and nothing waited for: a link in a stream of kernels
+// (the lockstep argument's late rounds over per-proof bases, csrc/nlb.hip).  batch > 4.
+int msm_batch_dev(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points, int window_bits, uint32_t *d_out) {
+  if (!d_out || batch <= 4 || !n) return fail(ctx, BPPP_ERR_ARG, "msm_batch_dev: bad arguments");
+  uint64_t dummy[8];
+  return msm_run_ex(ctx, d_scalars, d_points, n, batch, shared_points, window_bits, dummy, 0, d_out);
+}
 // table_stride != 0: d_points is a precomputed table [W][table_stride] of 2^(c w) P_i for the given window_bits = c (bppp_basis):
 // all windows of an instance share one bucket set, so there is one bucket reduction per instance and no window combine
 int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points, int window_bits, uint64_t *out_xy,
-               size_t table_stride) {
+               size_t table_stride, uint32_t *d_out_dev) {
   using namespace bppp_host;
   if (!out_xy) return fail(ctx, BPPP_ERR_ARG, "msm: null output");
   if (n == 0 || batch == 0) { memset(out_xy, 0, 64 * (batch ? batch : 1)); return BPPP_OK; }
@@ -827,7 +834,7 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
   // ---- one small or mid-size MSM: k_msm_small over (window, slice of <= 4096 terms) workgroups, the slices of a window joined by one
   // wavefront each, then the host's Horner combine over the W window sums
   const size_t small_max = ctx->tune.small_max ? (size_t)ctx->tune.small_max : MSM_SMALL_DEFAULT_MAX;
-  if (batch == 1 && !table_stride && !window_bits && n <= small_max && !ctx->tune.no_small) {
+  if (batch == 1 && !table_stride && !window_bits && n <= small_max && !ctx->tune.no_small && !d_out_dev) {
     const int c = ctx->tune.small_c >= 5 && ctx->tune.small_c <= 8 ? ctx->tune.small_c : 6, M = 1 << (c - 1);
     const bool bal = 256 % c != 0 && !ctx->tune.no_balance;
     const int Wr = (256 + c - 1) / c, acnt = bal ? 256 - Wr * (c - 1) : 256 / c + 1, W = bal ? Wr + 1 : 256 / c + 1;
@@ -946,6 +953,11 @@ int msm_run_ex(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_
     }
     prof_mark(ctx, 5);
     // 5. window combine
+    if (d_out_dev) {
+      k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.Wc, c, p.marg ? p.mg.a : 0, (uint32_t)batch, d_out_dev);
+      BPPP_HIP(ctx, hipGetLastError());
+      return BPPP_OK;
+    }
     if (batch > 4) {
       k_window_combine<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(winsum, p.Wc, c, p.marg ? p.mg.a : 0, (uint32_t)batch, out_aff);
       BPPP_HIP(ctx, hipMemcpyAsync(out_xy, out_aff, batch * 64, hipMemcpyDeviceToHost, st));

@@ -199,6 +199,20 @@ __global__ void __launch_bounds__(256) k_nlb_coef_update(uint32_t *__restrict__ 
     fr_store(c, fr_mul(fr_load(c), fr_load(A + (size_t)b * 16 + 8)));
   }
 }
+// rows [b][1 + l0 + n0] = [0 | coefl_b | coefn_b]: the fold coefficients of a proof in the comb table's order (the scalars of comb_groups)
+__global__ void __launch_bounds__(256) k_nlb_coef_rows(const uint32_t *__restrict__ coefn, const uint32_t *__restrict__ coefl, uint32_t n0, uint32_t l0, uint32_t *__restrict__ rows) {
+  const uint32_t b = blockIdx.y, pos = blockIdx.x * 256 + threadIdx.x, Tc = 1 + l0 + n0;
+  if (pos >= Tc) return;
+  fe v = fe_zero();
+  if (pos >= 1 && pos <= l0) v = fe_load(coefl + ((size_t)b * l0 + (pos - 1)) * 8);
+  else if (pos > l0) v = fe_load(coefn + ((size_t)b * n0 + (pos - 1 - l0)) * 8);
+  fe_store(rows + ((size_t)b * Tc + pos) * 8, v);
+}
+// slot 0 of every proof's materialised basis: g
+__global__ void __launch_bounds__(64) k_nlb_set_g(const uint32_t *__restrict__ g, uint32_t batch, uint32_t stride, uint32_t *__restrict__ pb) {
+  const uint32_t b = blockIdx.x * 4 + threadIdx.x / 16, t = threadIdx.x % 16;
+  if (b < batch) pb[(size_t)b * stride * 16 + t] = g[t];
+}
 __global__ void __launch_bounds__(256) k_nlb_fill_one(uint32_t *__restrict__ v, uint64_t count) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < count) fe_store(v + i * 8, fe_one());
@@ -260,6 +274,7 @@ __global__ void __launch_bounds__(64) k_nlb_collapse_state(const uint32_t *__res
 }
 }  // namespace bppp
 
+namespace bppp { int msm_batch_dev(bppp_ctx *ctx, const void *d_scalars, const void *d_points, size_t n, size_t batch, int shared_points, int window_bits, uint32_t *d_out); }
 using namespace bppp;
 using namespace bppp_host;
 
@@ -284,6 +299,10 @@ struct bppp_nlb {
   const bppp::CombTable *comb; // fixed-basis mode: comb over [g | lin | norm]; the points are never folded (P[] is not allocated)
   uint32_t *coefn, *coefl, *full, *dA, *d_out, *stt, *d_es, *cscratch;   // stt: per-proof round state in HBM (k_nlb_tails / k_nlb_collapse_state)
   uint32_t folds;              // completed folds (the level shift of an original index)
+  // re-basing (long bases): after `rebase_level` folds the level basis of every proof is materialised once (comb_groups) and the remaining rounds commit
+  // by bucket MSMs over these per-proof points — Tm = 1 + l0r + n0r terms instead of 1 + l0 + n0 table walks
+  uint32_t rebase_level, folds0; bool rebased; size_t n0r, l0r;
+  uint32_t *pbasis, *coefn_r, *coefl_r, *full_r;
   int cur;
   std::vector<U256> q, qinv, nn, ln, s, sX, sR;
 };
@@ -303,6 +322,7 @@ void bppp_nlb_destroy(bppp_nlb *o) {
   hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; k++) { hipFree(o->x[k]); hipFree(o->lx[k]); hipFree(o->lc[k]); hipFree(o->P[k]); }
   hipFree(o->sc); hipFree(o->sums); hipFree(o->qs); hipFree(o->dK);
+  hipFree(o->pbasis); hipFree(o->coefn_r); hipFree(o->coefl_r); hipFree(o->full_r);
   hipFree(o->coefn); hipFree(o->coefl); hipFree(o->full); hipFree(o->dA); hipFree(o->d_out); hipFree(o->stt); hipFree(o->d_es); hipFree(o->cscratch);
   delete o;
   ctx_release(ctx);
@@ -340,6 +360,21 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   for (int k = 0; k < 2; k++) { o->x[k] = o->lx[k] = o->lc[k] = o->P[k] = nullptr; }
   o->sc = o->sums = o->qs = nullptr; o->dK = nullptr;
   o->comb = comb; o->coefn = o->coefl = o->full = o->dA = o->d_out = o->stt = o->d_es = o->cscratch = nullptr; o->folds = 0;
+  o->rebase_level = 0; o->folds0 = 0; o->rebased = false; o->n0r = o->l0r = 0; o->pbasis = o->coefn_r = o->coefl_r = o->full_r = nullptr;
+  if (comb && on_device) {
+    // BPPP_NLB_REBASE=<level> forces it (0: never); by default a basis of >= 2048 points is re-based at the first level of <= 528 points when the batch
+    // fills a bucket-MSM launch (64 x 64-bit binary proofs, 4099 points, 1024 proofs: level 2 / 3 / 4 / 5 = 89 / 76 / 80 / 85 ms against 100 without)
+    const char *e = getenv("BPPP_NLB_REBASE");
+    auto terms_at = [&](uint32_t L) { return 1 + ((llen + ((size_t)1 << L) - 1) >> L) + ((nlen + ((size_t)1 << L) - 1) >> L); };
+    if (e) o->rebase_level = (uint32_t)atoi(e);
+    else if (nlen + llen >= 2048 && batch >= 64) {
+      uint32_t L = 1;
+      while (L < 20 && terms_at(L) > 528) L++;
+      o->rebase_level = L;
+    }
+    if (o->rebase_level > 20 || 2 * batch <= 4) o->rebase_level = 0;
+    if (o->rebase_level) { o->l0r = (llen + ((size_t)1 << o->rebase_level) - 1) >> o->rebase_level; o->n0r = (nlen + ((size_t)1 << o->rebase_level) - 1) >> o->rebase_level; }
+  }
   bool bad = false;
   for (int k = 0; k < 2; k++) {
     bad |= hipMalloc(&o->x[k], batch * o->xstride * 32) != hipSuccess || hipMalloc(&o->lx[k], batch * o->lstride * 32) != hipSuccess;
@@ -353,6 +388,11 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
     bad |= hipMalloc(&o->full, 2 * batch * Tc * 32) != hipSuccess || hipMalloc(&o->dA, batch * 64) != hipSuccess || hipMalloc(&o->d_out, 2 * batch * 64) != hipSuccess;
     bad |= hipMalloc(&o->stt, batch * NLB_ST * 32) != hipSuccess || hipMalloc(&o->d_es, batch * 32) != hipSuccess;
     bad |= hipMalloc(&o->cscratch, comb_rows_scratch_bytes(2 * batch)) != hipSuccess;
+    if (o->rebase_level) {
+      const size_t Tm = 1 + o->l0r + o->n0r;
+      bad |= hipMalloc(&o->pbasis, batch * Tm * 64) != hipSuccess || hipMalloc(&o->full_r, 2 * batch * Tm * 32) != hipSuccess;
+      bad |= hipMalloc(&o->coefn_r, batch * std::max<size_t>(o->n0r, 1) * 32) != hipSuccess || hipMalloc(&o->coefl_r, batch * std::max<size_t>(o->l0r, 1) * 32) != hipSuccess;
+    }
   }
   if (bad) { bppp_nlb_destroy(o); return fail(ctx, BPPP_ERR_HIP, "nlb_create: hipMalloc failed"); }
   hipStream_t st = ctx->stream;
@@ -439,6 +479,28 @@ int nlb_round_commit_dev(bppp_nlb *o, uint32_t *d_XR) {
                                                                  o->qs, (uint32_t)T, o->sc, o->sums);
   k_nlb_tails<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st>>>(o->sums, o->qs, o->stt, (uint32_t)B, (uint32_t)o->n, (uint32_t)o->l, (uint32_t)T, o->sc);
   const uint32_t Tc = (uint32_t)(1 + o->l0 + o->n0);
+  if (o->rebase_level && !o->rebased && o->folds == o->rebase_level) {
+    // the level basis of every proof, once: G'_p = sum_{i >> L == p} coef_i G_i (one table walk over the coefficients), g in slot 0; from here on the
+    // coefficients restart at 1 over these points
+    const uint32_t Tm = (uint32_t)(1 + o->l0r + o->n0r);
+    k_nlb_coef_rows<<<dim3((Tc + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->coefn, o->coefl, (uint32_t)o->n0, (uint32_t)o->l0, o->full);
+    NLB_HIP(o, hipGetLastError());
+    int rcg = comb_groups(o->comb, o->full, B, o->l0, o->n0, (int)o->rebase_level, o->pbasis, Tm, st);
+    if (rcg) return fail(ctx, rcg, bppp_last_error(o->comb->ctx));
+    k_nlb_set_g<<<dim3((unsigned)((B + 3) / 4)), dim3(64), 0, st>>>(o->comb->tab, (uint32_t)B, Tm, o->pbasis);      // tab[0][0][0] = 1 * P_0 = g
+    const uint64_t cn = (uint64_t)B * o->n0r, cl = (uint64_t)B * o->l0r;
+    if (cn) k_nlb_fill_one<<<dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st>>>(o->coefn_r, cn);
+    if (cl) k_nlb_fill_one<<<dim3((unsigned)((cl + 255) / 256)), dim3(256), 0, st>>>(o->coefl_r, cl);
+    NLB_HIP(o, hipGetLastError());
+    o->rebased = true; o->folds0 = o->folds;
+  }
+  if (o->rebased) {
+    const uint32_t Tm = (uint32_t)(1 + o->l0r + o->n0r);
+    k_nlb_expand<<<dim3((Tm + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds - o->folds0, o->coefn_r, o->coefl_r,
+                                                                                  (uint32_t)o->n0r, (uint32_t)o->l0r, o->full_r);
+    NLB_HIP(o, hipGetLastError());
+    return msm_batch_dev(ctx, o->full_r, o->pbasis, Tm, 2 * B, 2, 0, d_XR);      // X and R of a proof share that proof's points
+  }
   k_nlb_expand<<<dim3((Tc + 255) / 256, (unsigned)(2 * B)), dim3(256), 0, st>>>(o->sc, (uint32_t)T, (uint32_t)ne, o->folds, o->coefn, o->coefl, (uint32_t)o->n0,
                                                                                 (uint32_t)o->l0, o->full);
   NLB_HIP(o, hipGetLastError());
@@ -459,10 +521,12 @@ int nlb_round_collapse_dev(bppp_nlb *o, const uint32_t *d_es) {
   NLB_HIP(o, hipMemsetAsync(o->x[d], 0, B * o->xstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lx[d], 0, B * o->lstride * 32, st));
   NLB_HIP(o, hipMemsetAsync(o->lc[d], 0, B * o->lstride * 32, st));
-  const uint32_t maxp = (uint32_t)std::max(n2, l2), maxc = (uint32_t)std::max(o->n0, o->l0);
+  const size_t cn0 = o->rebased ? o->n0r : o->n0, cl0 = o->rebased ? o->l0r : o->l0;
+  const uint32_t maxp = (uint32_t)std::max(n2, l2), maxc = (uint32_t)std::max(cn0, cl0);
   if (maxp) k_nlb_fold_scalars<<<dim3((maxp + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->x[c], o->lc[c], o->lx[c], (uint32_t)o->n, (uint32_t)o->l,
                                                                                            (uint32_t)o->xstride, (uint32_t)o->lstride, o->dK, o->x[d], o->lc[d], o->lx[d]);
-  k_nlb_coef_update<<<dim3((maxc + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->coefn, o->coefl, (uint32_t)(o->n ? o->n0 : 0), (uint32_t)(o->l ? o->l0 : 0), o->folds, o->dA);
+  k_nlb_coef_update<<<dim3((maxc + 255) / 256, (unsigned)B), dim3(256), 0, st>>>(o->rebased ? o->coefn_r : o->coefn, o->rebased ? o->coefl_r : o->coefl, (uint32_t)(o->n ? cn0 : 0),
+                                                                                 (uint32_t)(o->l ? cl0 : 0), o->folds - (o->rebased ? o->folds0 : 0u), o->dA);
   NLB_HIP(o, hipGetLastError());
   o->n = o->n ? n2 : 0; o->l = o->l ? l2 : 0; o->cur = d; o->folds++;
   return BPPP_OK;

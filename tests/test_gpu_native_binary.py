@@ -128,7 +128,7 @@ def test_native_binary_on_the_reference_example(gpu):
     nat_ip.close(); nat.close()
 
 
-def test_native_binary_at_the_64_by_64_bit_shape(gpu):
+def test_native_binary_at_the_64_by_64_bit_shape(gpu, monkeypatch):
     """BASELINE config 3 read literally — a 64 x 64-bit aggregated BINARY range proof: 64 outputs in [0, 2^64), nrmLen 4096, 10 rounds,
     conserved against one public input.  The lockstep prover's files verify, the end-to-end verifier derives the challenges the host
     protocol code derives from the same files (both transcript-hashing routes), and a tampered member is identified.  (Byte equality
@@ -150,6 +150,11 @@ def test_native_binary_at_the_64_by_64_bit_shape(gpu):
     # the device-resident route over a (narrow, 1.3-GB) comb table of the 4099 points: byte-identical to the host-algebra route above
     nat.set_option("comb_min", 1); nat.set_option("comb_bits", 9); nat.set_option("host_oracle_max", 0)
     assert nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)]) == files
+    # ... and with the argument re-based after 3 / 4 folds (the default for batches of 64 proofs or more: csrc/nlb.hip): the same bytes
+    for level in ("3", "4"):
+        monkeypatch.setenv("BPPP_NLB_REBASE", level)
+        assert nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)]) == files
+    monkeypatch.delenv("BPPP_NLB_REBASE")
     nat.set_option("host_oracle_max", 2**64 - 1)
     seed = hashlib.sha256(b"binary 64by64").digest()
     lift = E.gpu_lift_x(gpu)

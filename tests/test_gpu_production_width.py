@@ -154,6 +154,9 @@ def test_lane_per_instance_comb_rows_binary_shape(monkeypatch):
     files = {}
     for tag, min_mb in (("rows", "0"), ("off", "100000000")):
         monkeypatch.setenv("BPPP_COMB_ROWS_MIN_MB", min_mb)
+        # "rows" also re-bases the argument after three folds (the default for a basis of 4099 points: the level-3 basis of every proof materialised by
+        # comb_groups, the last seven rounds bucket MSMs over those 514 points, csrc/nlb.hip); "off" walks the table in every round
+        monkeypatch.setenv("BPPP_NLB_REBASE", "0" if tag == "off" else "3")
         g = b.Bppp(0)
         nat = BRP.NativeBinaryRangeProofs(g, BRP.setup(RP.GpuBackend(g), pts, True, rds, amount * count, "NL"))
         nat.set_option("comb_min", 1); nat.set_option("comb_bits", 9)
@@ -168,3 +171,27 @@ def test_lane_per_instance_comb_rows_binary_shape(monkeypatch):
                 nat.prove_batch(bad, prefixes)
         nat.close()
     assert files["rows"] == files["off"]
+
+
+@pytest.mark.parametrize("level", [1, 2, 5])
+def test_rebased_argument_writes_the_oracle_backends_bytes(monkeypatch, gpu, oracle_lib, level):
+    """the re-based lockstep argument (BPPP_NLB_REBASE=<level>: per-proof level basis by comb_groups, later rounds by bucket MSMs over it) on a shape with
+    odd lengths on the way down (examples/64by64: nrmLen 512, linLen 261 -> groups of 2 / 4 / 32 points, the last ones short): byte for byte the proof of
+    the reference's prover over the oracle backend, with the device and the host oracle"""
+    monkeypatch.setenv("BPPP_NLB_REBASE", str(level))
+    schema = _schema("64by64", False)
+    st_g = RP.setup_from_schema(RP.GpuBackend(gpu), schema)
+    st_o = RP.setup_from_schema(OracleBackend(oracle_lib), schema)
+    rnd = random.Random(level)
+    B, count = 5, len(st_g.rds)
+    inputs = [[(rnd.randrange(2**64), 0, rnd.randrange(O.N)) for _ in range(count)] for _ in range(B)]
+    prefixes = [b"rebase %d %d" % (level, i) for i in range(B)]
+    want = E.encode_proof(4, RP.prove(st_o, RP.witness(st_o, inputs[0]), RP.sha256_oracle(), RP.hash_to_scalar(prefixes[0])))
+    nat = RP.NativeRangeProofs(gpu, st_g)
+    nat.set_option("comb_min", 1); nat.set_option("comb_bits", 8)
+    for host_oracle_max in (0, 2**64 - 1):
+        nat.set_option("host_oracle_max", host_oracle_max)
+        files = nat.prove_batch(inputs, prefixes)
+        assert files[0] == want
+        assert nat.verify_batch([c for c, _ in files], [p for _, p in files])
+    nat.close()
