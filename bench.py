@@ -525,10 +525,13 @@ def bench_binary_verify(gpu, torch, dev, batch: int, steps: int, cpu_baseline_le
                     "member rejected and identified",
            "prove": {"value": batch / pdt2, "unit": "proofs/s", "ms_per_batch": pdt2 * 1e3, "first_call_ms": pdt * 1e3,
                      "scope": "bppp_rp_prove_batch on the binary handle, second call (the first builds the comb table of the 4099 basis points: first_call_ms): "
-                              "proveBRPM + proveBPM as ONE stream of kernels (csrc/brpprove_dev.hip, csrc/nlb.hip fixed-basis mode, csrc/rpp_transcript.hip), every "
-                              "commitment a comb MSM; the host extracts the binary digits and writes the files",
-                     "bound": "10 rounds x (4099 + 2050) + 4099 full-width terms per proof x 20 windows (c = 13) = 1.31 M mixed additions = 13.1 M field "
-                              "multiplications per proof: at the accumulate kernel's ~170 G mulmod/s that is ~77 us per proof, ~13 k proofs/s for this algorithm"}}
+                              "proveBRPM + proveBPM as ONE stream of kernels (csrc/brpprove_dev.hip, csrc/nlb.hip fixed-basis mode, csrc/rpp_transcript.hip), two "
+                              "half-batches in flight; the phase commitments and the first three rounds are comb MSMs over the setup's 4099 points, then the level-3 "
+                              "basis of every proof is materialised by one table walk and the last seven rounds are bucket MSMs over those 514 points; the host "
+                              "extracts the binary digits and writes the files",
+                     "bound": "per proof: 3 rounds x (4099 + 2050) + 4099 (blCom) + 4098 (level basis) full-width terms x 20 windows (c = 13) = 0.53 M mixed additions, "
+                              "+ 7 rounds x 2 bucket MSMs of 514 terms (~25 k additions each) = 0.88 M in all (1.31 M with every round on the table): at the "
+                              "accumulate kernels' ~15 G additions/s ~59 us per proof, ~17 k proofs/s for this schedule"}}
     bytes_per_proof = (ninit + 2 * k) * 96 + (shp["norm_len"] + shp["lin_len"] + 1) * 32
     btab = profile_table("verify_binary_1024_64x64bit") if batch == 1024 else None
     ach = batch * steps * bytes_per_proof / dt / 1e9
