@@ -107,6 +107,35 @@ def profile_table(key: str):
         return None
 
 
+def prover_rows_roofline():
+    """k_comb_msm_rows, the norm-linear prover's dominant kernel (lane = instance; csrc/comb.hip), from the committed profiles of
+    `BPPP_RP_NO_SPLIT=1 python benchmarks/prove_timing.py 4096` (benchmarks/profile_round.sh: a --kernel-trace --stats pass for the mean duration,
+    separate --pmc passes for FETCH_SIZE / WRITE_SIZE / SQ_*): 16 round launches of 4096 X rows (774 terms) + 4096 R rows (387 non-zero terms) and 4 launches of
+    4096 dense phase rows; algorithmic bytes per term: its 32-B scalar and one 64-B table row for each of the 16 non-zero windows (c = 16)."""
+    import csv
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["prover_4096_proofs_64by64"]["by_kernel"]
+        key = next(k for k in tab if "k_comb_msm_rows" in k)
+        v = tab[key]
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_prove_4096_kernel_stats.csv"))))
+        ms = next(float(r["AverageNs"]) / 1e6 for r in rows if "k_comb_msm_rows" in r["Name"])
+    except Exception:
+        return None
+    terms = (16 * 4096 * (774 + 387) + 4 * 4096 * 774) / 20.0
+    alg = terms * (32 + 16 * 64)
+    sq = v["sq_per_launch"]
+    return {"bound": "hbm", "kernel": "k_comb_msm_rows", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"], "fetch_bytes_raw": v["fetch_bytes_per_launch_raw"], "ms_per_launch": ms,
+            "valu_busy_est": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (1024 * ms * 1e-3 * 2.4e9), "wait_inst_frac": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+            "valu_insts_per_addition": sq["SQ_INSTS_VALU"] * 64 / (terms * 16),
+            "traffic_source": "static: profiles/traffic.json + profiles/r04_prove_4096_kernel_stats.csv (rocprofv3 passes of benchmarks/profile_round.sh over the one-context "
+                              "prover, 20 launches per batch), not measured in this run; the gathers are 64-B requests, for which gfx950's x2 on FETCH_SIZE overstates — the raw "
+                              "count equals the algorithmic bytes",
+            "limiter": "valu",
+            "note": "mean over the 20 launches of a 4096-proof batch: %.2f M terms x (32-B scalar + 16 windows x 64-B table row) per launch / mean duration; the kernel is "
+                    "VALU-bound (one mixed addition per table row: ~1.9 k VALU instructions, 0.74 VALU-busy)" % (terms / 1e6)}
+
+
 def stage_rows(tab, top: int = 8):
     """the largest kernels of a profiled verifier call: ms, HBM bytes (FETCH x2 + WRITE), wait fraction, VALU-busy estimate"""
     if not tab:
@@ -1175,8 +1204,11 @@ def main():
         if verify is not None:
             out["verify"] = verify
         if prove is not None:
-            if fixed_batch is not None:
-                prove["roofline"] = fixed_batch["roofline"]       # the prover's dominant kernel, timed live on the prover's shape in that leg
+            rr = prover_rows_roofline()
+            if rr is not None:
+                prove["roofline"] = rr                            # the prover's dominant kernel from the committed profile of the same command
+            elif fixed_batch is not None:
+                prove["roofline"] = fixed_batch["roofline"]       # the comb kernel of the unhinted route, timed live on the prover's shape in that leg
             out["prove"] = prove
         if verify_ip is not None:
             out["verify_ip"] = verify_ip
