@@ -363,11 +363,11 @@ int nlb_create_impl(bppp_ctx *ctx, size_t batch, const uint64_t *s, const uint64
   o->rebase_level = 0; o->folds0 = 0; o->rebased = false; o->n0r = o->l0r = 0; o->pbasis = o->coefn_r = o->coefl_r = o->full_r = nullptr;
   if (comb && on_device) {
     // BPPP_NLB_REBASE=<level> forces it (0: never); by default a basis of >= 2048 points is re-based at the first level of <= 528 points when the batch
-    // fills a bucket-MSM launch (64 x 64-bit binary proofs, 4099 points, 1024 proofs: level 2 / 3 / 4 / 5 = 89 / 76 / 80 / 85 ms against 100 without)
+    // fills a bucket-MSM launch (>= 384 proofs) (64 x 64-bit binary proofs, 4099 points, 1024 proofs: level 2 / 3 / 4 / 5 = 89 / 76 / 80 / 85 ms against 100 without)
     const char *e = getenv("BPPP_NLB_REBASE");
     auto terms_at = [&](uint32_t L) { return 1 + ((llen + ((size_t)1 << L) - 1) >> L) + ((nlen + ((size_t)1 << L) - 1) >> L); };
     if (e) o->rebase_level = (uint32_t)atoi(e);
-    else if (nlen + llen >= 2048 && batch >= 64) {
+    else if (nlen + llen >= 2048 && batch >= 384) {      // 64 / 128 / 256 / 512 binary proofs: 22.3 / 31.5 / 38.7 / 64.9 ms without, 26.5 / 32.6 / 39.2 / 54.2 ms with
       uint32_t L = 1;
       while (L < 20 && terms_at(L) > 528) L++;
       o->rebase_level = L;

@@ -150,7 +150,7 @@ def test_native_binary_at_the_64_by_64_bit_shape(gpu, monkeypatch):
     # the device-resident route over a (narrow, 1.3-GB) comb table of the 4099 points: byte-identical to the host-algebra route above
     nat.set_option("comb_min", 1); nat.set_option("comb_bits", 9); nat.set_option("host_oracle_max", 0)
     assert nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)]) == files
-    # ... and with the argument re-based after 3 / 4 folds (the default for batches of 64 proofs or more: csrc/nlb.hip): the same bytes
+    # ... and with the argument re-based after 3 / 4 folds (the default for batches of 384 proofs or more: csrc/nlb.hip): the same bytes
     for level in ("3", "4"):
         monkeypatch.setenv("BPPP_NLB_REBASE", level)
         assert nat.prove_batch(inputs, [b"bin64 %d" % b for b in range(B)]) == files
