@@ -458,7 +458,7 @@ int comb_msm(const CombTable *t, const uint32_t *d_scalars, size_t ninst, uint32
   if (rows_hint != COMB_ROWS_ANY && d_scratch && ninst >= 512 && nterms >= 256 && t->bytes >= t->ctx->tune.comb_rows_min_bytes) {
     const bool pairs = rows_hint == COMB_ROWS_PAIRS && !(ninst & 1);
     const uint32_t ngroups = (uint32_t)(((pairs ? ninst / 2 : ninst) + 63) / 64), gtot = pairs ? 2 * ngroups : ngroups;
-    uint32_t chunks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)(nterms / (ninst >= 1024 ? 8 : 4)), (std::min<uint32_t>(t->ctx->tune.comb_rows_waves ? (uint32_t)t->ctx->tune.comb_rows_waves : (uint32_t)COMB_ROWS_WAVES, (uint32_t)COMB_ROWS_WAVES) + gtot - 1) / gtot));
+    uint32_t chunks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)(nterms / 4), (std::min<uint32_t>(t->ctx->tune.comb_rows_waves ? (uint32_t)t->ctx->tune.comb_rows_waves : (uint32_t)COMB_ROWS_WAVES, (uint32_t)COMB_ROWS_WAVES) + gtot - 1) / gtot));
     while (chunks > 1 && (size_t)ninst * chunks * XYZZ_WORDS * 4 > scratch_bytes) chunks--;
     const uint32_t clen = (uint32_t)((nterms + chunks - 1) / chunks);
     chunks = (uint32_t)((nterms + clen - 1) / clen);
