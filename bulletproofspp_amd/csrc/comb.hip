@@ -90,11 +90,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   // zeros follow a power-of-two pattern in the index (the argument's R scalars vanish on every left half) every lane then has the
   // same share, and the wavefront of such an instance takes half the steps.
   uint32_t k0 = w0 < W ? 64u * tpart : nterms, k = tpart, sp[9];      // (an empty window range: nothing to do)
-  int w = w1;                                                  // w == w1: this lane needs its next term
+  int w = w1, wend = w1;                                       // w == wend: this lane needs its next term
   bool neg = false, live = true;
   const uint32_t *ti = tab;
   while (__any(live)) {
-    if (live && w == w1) {
+    if (live && w >= wend) {
       live = false;
       while (k0 < nterms) {
         const uint32_t i = k0 + ((lane + 21u * k) & 63u);
@@ -105,6 +105,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         fe t, tmp;
         raw_sub(t, fr_modulus(), s);                           // n - s
         neg = raw_sub(tmp, t, s) != 0;                         // s > n - s: take n - s and the negated point (reduceScalar, Commitment.hs:276-279)
+        // a SHORT scalar (range-proof digits, bits, multiplicities) has no digit beyond window ceil(bits / c) (that one only as a carry): its lane
+        // moves on after those instead of stepping through all W windows
+        uint32_t hw = 1u; int top = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint32_t v = neg ? t.v[q] : s.v[q]; if (v) { hw = v; top = q; } }
+        const int nw = (32 * top + (32 - __builtin_clz(hw)) + c - 1) / c + 1;
+        if (nw <= w0) continue;                                // nothing of this term in this wavefront's window range
         uint64_t cy = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) { cy += (uint64_t)(neg ? t.v[q] : s.v[q]) + K.k[q]; sp[q] = (uint32_t)cy; cy >>= 32; }
@@ -115,6 +122,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
           sp[8] >>= c;
         }
         ti = tab + (size_t)i * D * 16;
+        wend = min(w1, nw);
         w = w0; live = true;
         break;
       }
